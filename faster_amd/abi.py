@@ -1,0 +1,103 @@
+"""numpy / ctypes mirror of the C ABI structs declared in include/fasterhip.h.
+
+The layouts are checked against `sizeof` exported by the shared libraries in tests/test_abi.py.
+Field meaning: see include/fasterhip.h (each field cites the SolverGurobi member it replaces).
+"""
+import ctypes
+
+import numpy as np
+
+FH_MAX_SEG = 16
+FH_MAX_POLY = 8
+FH_MAX_FACES = 256
+FH_MAX_FACES_POLY = 64
+
+FH_ST_OPTIMAL, FH_ST_INFEASIBLE, FH_ST_NODE_LIMIT, FH_ST_ITER_LIMIT, FH_ST_BAD_INPUT = range(5)
+
+problem_dtype = np.dtype(
+    [
+        ("n_seg", "<i4"),
+        ("n_poly", "<i4"),
+        ("force_final_pos", "<i4"),
+        ("face_begin", "<i4"),
+        ("face_off", "<i4", (FH_MAX_POLY + 1,)),
+        ("reserved", "<i4", (3,)),
+        ("dc", "<f8"),
+        ("v_max", "<f8"),
+        ("a_max", "<f8"),
+        ("j_max", "<f8"),
+        ("f_init", "<f8"),
+        ("f_final", "<f8"),
+        ("f_inc", "<f8"),
+        ("x0", "<f8", (9,)),
+        ("xf", "<f8", (9,)),
+    ],
+    align=True,
+)
+
+face_dtype = np.dtype([("a", "<f8", (3,)), ("b", "<f8")], align=True)
+
+result_dtype = np.dtype(
+    [
+        ("solved", "<i4"),
+        ("trials", "<i4"),
+        ("status", "<i4"),
+        ("nodes", "<i4"),
+        ("qp_iters", "<i4"),
+        ("reserved", "<i4"),
+        ("factor", "<f8"),
+        ("dt", "<f8"),
+        ("cost", "<f8"),
+        ("coeff", "<f8", (FH_MAX_SEG, 12)),
+        ("assign", "i1", (FH_MAX_SEG,)),
+    ],
+    align=True,
+)
+
+state_dtype = np.dtype([("pos", "<f8", (3,)), ("vel", "<f8", (3,)), ("accel", "<f8", (3,)), ("jerk", "<f8", (3,))], align=True)
+
+params_dtype = np.dtype([("feas_tol", "<f8"), ("dep_tol", "<f8"), ("max_nodes", "<i4"), ("max_iters", "<i4")], align=True)
+
+assert problem_dtype.itemsize == 264, problem_dtype.itemsize
+assert face_dtype.itemsize == 32
+assert result_dtype.itemsize == 1600, result_dtype.itemsize
+assert state_dtype.itemsize == 96
+assert params_dtype.itemsize == 24
+
+
+def default_params():
+    p = np.zeros((), dtype=params_dtype)
+    p["feas_tol"] = 1e-9
+    p["dep_tol"] = 1e-10
+    p["max_nodes"] = 100000
+    p["max_iters"] = 2000
+    return p
+
+
+def ptr(a):
+    """void* to the first byte of a C-contiguous numpy array."""
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def make_problems(n):
+    pr = np.zeros(n, dtype=problem_dtype)
+    return pr
+
+
+def pack_faces(polys):
+    """polys: list of (A[F,3], b[F]) -> (faces array, face_off list)"""
+    off = [0]
+    rows = []
+    for A, b in polys:
+        A = np.asarray(A, dtype=np.float64).reshape(-1, 3)
+        b = np.asarray(b, dtype=np.float64).reshape(-1)
+        assert A.shape[0] == b.shape[0]
+        for i in range(A.shape[0]):
+            rows.append((A[i], b[i]))
+        off.append(off[-1] + A.shape[0])
+    faces = np.zeros(len(rows), dtype=face_dtype)
+    for i, (a, bb) in enumerate(rows):
+        faces[i]["a"] = a
+        faces[i]["b"] = bb
+    return faces, off

@@ -1,0 +1,160 @@
+/* fasterhip.h — C ABI of the MI355X-native batched trajectory-optimisation core.
+ *
+ * This is the drop-in boundary for ONE hot path of mit-acl/faster: the Gurobi-backed
+ * SolverGurobi::genNewTraj() / callOptimizer() / fillX()
+ * (reference: faster/src/solverGurobi.cpp:426-477, :549-657, :122-168).
+ *
+ * The reference has no FFI for this path: the boundary there is the C++ class SolverGurobi
+ * (faster/include/solverGurobi.hpp:61-186) held by value by Faster (faster/include/faster.hpp:74-75).
+ * The replacement class `SolverHip` (faster_amd/host/solver_hip.hpp) keeps that class surface
+ * and forwards to the entry points declared here; INTEGRATION.md shows the binding.
+ *
+ * Everything crossing this boundary is plain C: pointers, sizes, PODs. No torch, no HIP types
+ * (a stream is passed as void*).  All arithmetic of the path is FP64.
+ *
+ * One `fh_problem` == one genNewTraj() call (the complete factor line search, every trial a
+ * mixed-integer QP over the segment->polytope assignment).  Problems are independent.
+ */
+#ifndef FASTERHIP_H
+#define FASTERHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_MAX_SEG 16         /* max N (segments); reference default N_=10 (solverGurobi.hpp:136), yaml 6 */
+#define FH_MAX_POLY 8         /* max polytopes per problem (BASELINE config 5: <=8) */
+#define FH_MAX_FACES 256      /* max faces per problem, summed over its polytopes */
+#define FH_MAX_FACES_POLY 64  /* max faces of one polytope */
+
+/* status codes in fh_result.status */
+enum {
+  FH_ST_OPTIMAL = 0,     /* some factor gave an optimal MIQP solution  (reference: GRB_OPTIMAL)      */
+  FH_ST_INFEASIBLE = 1,  /* every factor in the window was infeasible   (reference: genNewTraj()==false) */
+  FH_ST_NODE_LIMIT = 2,  /* branch-and-bound node cap hit (treated as not solved)                    */
+  FH_ST_ITER_LIMIT = 3,  /* active-set iteration cap hit  (treated as not solved, cf. GRB_NUMERIC)   */
+  FH_ST_BAD_INPUT = 4    /* sizes out of range / non-finite input                                    */
+};
+
+/* return codes of the entry points */
+enum {
+  FH_OK = 0,
+  FH_ERR_ARG = -1,     /* null pointer / bad size */
+  FH_ERR_DEVICE = -2,  /* HIP runtime error (message via fh_last_error) */
+  FH_ERR_NOMEM = -3
+};
+
+/* One genNewTraj() call.  Mirrors the inputs stored by the SolverGurobi setters:
+ *   setN (solverGurobi.cpp:60-63), setDC (:293-296), setBounds (:409-416),
+ *   setFactorInitialAndFinalAndIncrement (:418-424), setForceFinalConstraint (:170-173),
+ *   setX0/setXf (:298-330; order pos xyz, vel xyz, accel xyz), setPolytopes (:175-178). */
+typedef struct fh_problem {
+  int32_t n_seg;           /* N_  (1..FH_MAX_SEG)                                              */
+  int32_t n_poly;          /* polytopes_.size() (0..FH_MAX_POLY); 0 => no corridor constraints */
+  int32_t force_final_pos; /* forceFinalConstraint_: 1 whole trajectory, 0 safe trajectory      */
+  int32_t face_begin;      /* index of this problem's first face in the batch face array        */
+  int32_t face_off[FH_MAX_POLY + 1]; /* polytope p owns faces [face_begin+face_off[p], face_begin+face_off[p+1]) */
+  int32_t reserved[3];
+  double dc;               /* DC                                                               */
+  double v_max, a_max, j_max;
+  double f_init, f_final, f_inc; /* factor window; the loop accumulates `f += f_inc` in double   */
+  double x0[9];            /* x0_[9]                                                           */
+  double xf[9];            /* xf_[9] (pos used only for dt when force_final_pos==0)            */
+} fh_problem;
+
+/* A face is the row (a_x, a_y, a_z, b) of A x <= b  (LinearConstraint3D,
+ * thirdparty/DecompROS/DecompUtil/include/decomp_geometry/polyhedron.h:115-185). 32 B, AoS. */
+typedef struct fh_face {
+  double a[3];
+  double b;
+} fh_face;
+
+/* What genNewTraj() leaves behind: return value, trials_, factor_that_worked_, dt_, ObjVal,
+ * the 12*N polynomial coefficients in the reference variable order
+ * [ax ay az bx by bz cx cy cz dx dy dz] per segment (solverGurobi.cpp:70-84), and the binary matrix
+ * collapsed to one polytope index per segment. */
+typedef struct fh_result {
+  int32_t solved;    /* 1 <=> genNewTraj() returned true                               */
+  int32_t trials;    /* trials_                                                         */
+  int32_t status;    /* FH_ST_*                                                         */
+  int32_t nodes;     /* branch-and-bound nodes evaluated over all trials (diagnostic)   */
+  int32_t qp_iters;  /* active-set iterations over all trials (diagnostic)              */
+  int32_t reserved;
+  double factor;     /* factor_that_worked_ (valid iff solved)                          */
+  double dt;         /* dt_ of the last trial                                           */
+  double cost;       /* objective: sum_t sum_axis (6 a)^2  (solverGurobi.cpp:113-119)   */
+  double coeff[FH_MAX_SEG][12];
+  int8_t assign[FH_MAX_SEG]; /* polytope index per segment, -1 if n_poly==0          */
+} fh_result;
+
+/* Solver tolerances / limits (the counterpart of Gurobi parameters left at default by the
+ * reference).  Obtain defaults with fh_default_params(). */
+typedef struct fh_params {
+  double feas_tol;    /* a row is violated iff  a.x - b > feas_tol   (default 1e-9)          */
+  double dep_tol;     /* |z|/|g| below this => candidate row linearly dependent (1e-10)      */
+  int32_t max_nodes;  /* per trial branch-and-bound node cap          (default 100000)       */
+  int32_t max_iters;  /* per QP active-set iteration cap              (default 2000)         */
+} fh_params;
+
+/* One sample of fillX(): pos, vel, accel, jerk (faster_types.hpp:79-165 `state`, yaw/dyaw unused
+ * by the solver).  12 doubles = 96 B. */
+typedef struct fh_state {
+  double pos[3], vel[3], accel[3], jerk[3];
+} fh_state;
+
+typedef struct fh_ctx fh_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* device < 0: use the current HIP device. Replaces the GRBEnv/GRBModel member initialisers
+ * (solverGurobi.hpp:154-155). */
+int fh_create(fh_ctx** out, int device);
+void fh_destroy(fh_ctx* ctx);
+const char* fh_last_error(const fh_ctx* ctx);
+void fh_default_params(fh_params* p);
+int fh_set_params(fh_ctx* ctx, const fh_params* p);
+/* Kernels run on this stream (hipStream_t as void*); NULL => the context's own stream. */
+int fh_set_stream(fh_ctx* ctx, void* hip_stream);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* Batch of genNewTraj() calls, inputs/outputs in HOST memory (copies in/out, synchronous).
+ * Replaces SolverGurobi::genNewTraj() (solverGurobi.cpp:426-477) incl. every callOptimizer()
+ * (:549-657) it issues.  `faces` holds n_faces rows addressed through fh_problem.face_begin. */
+int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
+                   fh_result* results);
+
+/* Same, with every pointer already resident in device memory (HBM). Asynchronous on the
+ * context's stream; call fh_sync() before reading results. */
+int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n,
+                          fh_result* d_results);
+
+/* resetX()+fillX() (solverGurobi.cpp:382-388, :122-168) for a batch: problem i writes
+ * counts[i] = max(2,(int)(N*dt/DC)) states to states[i*max_samples ...]; if counts[i] > max_samples
+ * only max_samples are written (counts still reports the full size). Unsolved problems give 0. */
+int fh_sample_batch(fh_ctx* ctx, const fh_problem* problems, const fh_result* results, int n, int max_samples,
+                    fh_state* states, int32_t* counts);
+int fh_sample_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_result* d_results, int n,
+                           int max_samples, fh_state* d_states, int32_t* d_counts);
+
+/* Whole -> safe hand-off of Faster::replan (faster/src/faster.cpp:456-475, :506-524) for synthetic
+ * pairs: for pair i take R = sample number (int)(r_frac*count_i) of the whole
+ * trajectory (fillX semantics) as x0 of safe problem i (pos, vel, accel); everything else in
+ * d_safe[i] is left as the caller prepared it. Unsolved whole problems mark the safe problem with
+ * n_seg = 0 (skipped, result status FH_ST_BAD_INPUT). Device pointers, asynchronous. */
+int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, int n,
+                        double r_frac, fh_problem* d_safe);
+
+int fh_sync(fh_ctx* ctx);
+
+/* Timing of the last fh_solve_batch_device launch on the context stream, measured with HIP
+ * events recorded around the solve kernel (ms); <0 if unavailable. Synchronises. */
+double fh_last_kernel_ms(fh_ctx* ctx);
+
+/* library / build identification, e.g. "fasterhip 0.1 gfx950" */
+const char* fh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTERHIP_H */
