@@ -1,0 +1,99 @@
+"""Pins the CPU oracle (oracle/faster_oracle.c) to every fixture the reference holds for the solver path.
+
+The reference has NO expected outputs for SolverGurobi: the only fixture is the hard-coded
+corridor of faster/other/gurobi_continuous.cpp (inputs).  The expected values below come from the survey's
+independent SciPy computation and from oracle/py_model.py run here — parity unpinned.
+"""
+import numpy as np
+import pytest
+
+from faster_amd import abi, corridor
+
+
+def _case(fx, c, **kw):
+    return corridor.fixture_problem(fx, c["N"], c["vaj"], c["force_final"], c["polys"], c["x0"], c["xf"], **kw)
+
+
+@pytest.mark.parametrize("name", ["KA-1", "KA-2", "KA-3", "KA-4"])
+def test_known_answer(oracle, fixture_corridor, known_answers, name):
+    c = known_answers["cases"][name]
+    pr, faces = _case(fixture_corridor, c)
+    r = oracle.solve_batch(pr, faces)[0]
+    assert r["solved"] == 1 and r["status"] == abi.FH_ST_OPTIMAL
+    assert r["trials"] == c["trials"] and r["factor"] == c["factor"]
+    assert list(r["assign"][: c["N"]]) == c["assign"]
+    if "dt_init" in c:  # float-cast semantics of getDTInitial (solverGurobi.cpp:662-670,751)
+        assert oracle.dt_initial(pr) == c["dt_init"]
+        assert r["dt"] == c["dt"]
+        assert r["cost"] == pytest.approx(c["cost"], rel=1e-10)
+    else:
+        # the survey's dt_init is one float ulp off the reference's float/int division; compare at its dt
+        assert r["dt"] == pytest.approx(c["dt"], rel=1e-7)
+        st, r2 = oracle.miqp_dt(pr, faces, c["dt"])
+        assert st == abi.FH_ST_OPTIMAL
+        assert r2["cost"] == pytest.approx(c["cost"], rel=c.get("cost_tol", 1e-10))
+        assert list(r2["assign"][: c["N"]]) == c["assign"]
+
+
+def test_dt_initial_is_float_division(oracle, fixture_corridor, known_answers):
+    """dt_initial = max(float...) / N_ is a float/int division (solverGurobi.cpp:751)."""
+    c = known_answers["cases"]["KA-2"]
+    pr, _ = _case(fixture_corridor, c)
+    expect = float(np.float32(np.sqrt(2 * 9.0 / 5.0)) / np.float32(6))  # t_a on x dominates
+    assert oracle.dt_initial(pr) == expect
+
+
+def test_runners_up_and_first_feasible_factor(oracle, fixture_corridor, known_answers):
+    c = known_answers["cases"]["KA-1"]
+    pr, faces = _case(fixture_corridor, c)
+    for cost, assign in c["runners_up"]:
+        st, r = oracle.miqp_dt(pr, faces, c["dt"], assign=assign)
+        assert st == abi.FH_ST_OPTIMAL
+        assert r["cost"] == pytest.approx(cost, rel=2e-8)
+    # factors 1 and 2 are infeasible for every assignment (App. B)
+    dti = oracle.dt_initial(pr)
+    for f in (1.0, 2.0):
+        st, _ = oracle.miqp_dt(pr, faces, f * dti)
+        assert st == abi.FH_ST_INFEASIBLE
+
+
+def test_feasible_assignment_counts(oracle, fixture_corridor, known_answers):
+    """Brute force over ALL P^N assignments agrees with branch and bound and with the survey's counts."""
+    c = known_answers["cases"]["KA-2"]
+    pr, faces = _case(fixture_corridor, c)
+    nfeas, r = oracle.bruteforce_dt(pr, faces, c["dt"])
+    assert nfeas == c["n_feasible"]
+    assert r["cost"] == pytest.approx(c["cost"], rel=1e-7)
+    assert list(r["assign"][:6]) == c["assign"]
+
+
+@pytest.mark.parametrize("name", ["KA-1", "KA-3"])
+def test_unreduced_scipy_model_agrees(oracle, fixture_corridor, known_answers, name):
+    """Second opinion: SLSQP on the reference's own 12N-coefficient formulation (oracle/py_model.py)."""
+    from oracle import py_model
+
+    c = known_answers["cases"][name]
+    polys = [(np.array(fixture_corridor["polytopes"][p]["A"]), np.array(fixture_corridor["polytopes"][p]["b"])) for p in c["polys"]]
+    remap = {p: i for i, p in enumerate(c["polys"])}
+    s = py_model.solve_fixed(c["N"], c["dt"], c["x0"], c["xf"], *c["vaj"], bool(c["force_final"]), polys,
+                             [remap.get(a, a) for a in c["assign"]])
+    assert s is not None
+    pr, faces = _case(fixture_corridor, c)
+    r = oracle.solve_batch(pr, faces)[0]
+    assert s[0] == pytest.approx(r["cost"], rel=1e-9)
+    np.testing.assert_allclose(s[1], r["coeff"][: c["N"]], atol=2e-6)
+
+
+def test_sampling_matches_fillx_semantics(oracle, fixture_corridor, known_answers):
+    """resetX/fillX (solverGurobi.cpp:382-388,122-168): first sample at t=DC, last sample has zero vel/acc/jerk."""
+    c = known_answers["cases"]["KA-3"]
+    pr, faces = _case(fixture_corridor, c)
+    r = oracle.solve_batch(pr, faces)[0]
+    X = oracle.sample(pr[0], r)
+    n = max(2, int(c["N"] * r["dt"] / 0.01))
+    assert X.shape[0] == n
+    co = r["coeff"][0]
+    tau = 0.01
+    np.testing.assert_allclose(X[0]["pos"], co[0:3] * tau**3 + co[3:6] * tau**2 + co[6:9] * tau + co[9:12], rtol=0, atol=1e-14)
+    assert np.all(X[-1]["vel"] == 0) and np.all(X[-1]["accel"] == 0) and np.all(X[-1]["jerk"] == 0)
+    assert np.all(X[-2]["jerk"] == 6 * r["coeff"][c["N"] - 1][0:3])
