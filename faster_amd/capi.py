@@ -1,0 +1,141 @@
+"""ctypes binding of the C ABI (include/fasterhip.h) — the product path.
+
+There is no CPU fallback: if faster_amd/libfasterhip.so is missing this module raises, and every entry
+point fails with FH_ERR_DEVICE when no HIP device is present.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfasterhip.so")
+
+SYMBOLS = [
+    "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
+    "fh_solve_batch", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device",
+    "fh_sync", "fh_last_kernel_ms", "fh_version",
+]
+
+_LIB = None
+
+
+class FasterHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise FasterHipError("%s is missing: run `python -m faster_amd.build` (hipcc --offload-arch=gfx950). "
+                                 "There is no CPU fallback for the hot path." % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+        L.fh_create.restype = i32
+        L.fh_create.argtypes = [ctypes.POINTER(vp), i32]
+        L.fh_destroy.restype = None
+        L.fh_destroy.argtypes = [vp]
+        L.fh_last_error.restype = ctypes.c_char_p
+        L.fh_last_error.argtypes = [vp]
+        L.fh_default_params.restype = None
+        L.fh_default_params.argtypes = [vp]
+        L.fh_set_params.restype = i32
+        L.fh_set_params.argtypes = [vp, vp]
+        L.fh_set_stream.restype = i32
+        L.fh_set_stream.argtypes = [vp, vp]
+        L.fh_solve_batch.restype = i32
+        L.fh_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.fh_solve_batch_device.restype = i32
+        L.fh_solve_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        L.fh_sample_batch.restype = i32
+        L.fh_sample_batch.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+        L.fh_sample_batch_device.restype = i32
+        L.fh_sample_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+        L.fh_pair_glue_device.restype = i32
+        L.fh_pair_glue_device.argtypes = [vp, vp, vp, vp, i32, f64, f64, i32, vp, vp]
+        L.fh_sync.restype = i32
+        L.fh_sync.argtypes = [vp]
+        L.fh_last_kernel_ms.restype = f64
+        L.fh_last_kernel_ms.argtypes = [vp]
+        L.fh_version.restype = ctypes.c_char_p
+        _LIB = L
+    return _LIB
+
+
+class Context:
+    """One solver context (one HIP stream). Mirrors one SolverGurobi object's GRBEnv/GRBModel."""
+
+    def __init__(self, device=-1):
+        self._h = ctypes.c_void_p()
+        rc = lib().fh_create(ctypes.byref(self._h), device)
+        if rc != 0:
+            msg = lib().fh_last_error(self._h).decode() if self._h else "fh_create failed"
+            if self._h:
+                lib().fh_destroy(self._h)
+                self._h = None
+            raise FasterHipError("fh_create: rc=%d %s" % (rc, msg))
+
+    def close(self):
+        if self._h:
+            lib().fh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FasterHipError("%s: rc=%d %s" % (what, rc, lib().fh_last_error(self._h).decode()))
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params).reshape(1)
+        self._check(lib().fh_set_params(self._h, abi.ptr(p)), "fh_set_params")
+
+    def set_stream(self, stream_ptr):
+        self._check(lib().fh_set_stream(self._h, ctypes.c_void_p(stream_ptr)), "fh_set_stream")
+
+    def sync(self):
+        self._check(lib().fh_sync(self._h), "fh_sync")
+
+    def last_kernel_ms(self):
+        return lib().fh_last_kernel_ms(self._h)
+
+    # ---- host-pointer entry points (numpy in, numpy out) ----
+    def solve_batch(self, problems, faces):
+        problems = np.ascontiguousarray(problems)
+        faces = np.ascontiguousarray(faces)
+        assert problems.dtype == abi.problem_dtype and faces.dtype == abi.face_dtype
+        res = np.zeros(problems.shape[0], dtype=abi.result_dtype)
+        fptr = abi.ptr(faces) if faces.shape[0] else None
+        self._check(lib().fh_solve_batch(self._h, abi.ptr(problems), fptr, faces.shape[0], problems.shape[0], abi.ptr(res)),
+                    "fh_solve_batch")
+        return res
+
+    def sample_batch(self, problems, results, max_samples):
+        problems = np.ascontiguousarray(problems)
+        results = np.ascontiguousarray(results)
+        n = problems.shape[0]
+        states = np.zeros((n, max_samples), dtype=abi.state_dtype)
+        counts = np.zeros(n, dtype=np.int32)
+        self._check(lib().fh_sample_batch(self._h, abi.ptr(problems), abi.ptr(results), n, max_samples, abi.ptr(states),
+                                          abi.ptr(counts)), "fh_sample_batch")
+        return states, counts
+
+    # ---- device-pointer entry points (raw addresses; memory owned by the caller, e.g. torch tensors) ----
+    def solve_batch_device(self, d_problems, d_faces, n, max_seg, max_faces, d_results):
+        self._check(lib().fh_solve_batch_device(self._h, d_problems, d_faces, n, max_seg, max_faces, d_results),
+                    "fh_solve_batch_device")
+
+    def sample_batch_device(self, d_problems, d_results, n, max_samples, d_states, d_counts):
+        self._check(lib().fh_sample_batch_device(self._h, d_problems, d_results, n, max_samples, d_states, d_counts),
+                    "fh_sample_batch_device")
+
+    def pair_glue_device(self, d_whole, d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces):
+        self._check(lib().fh_pair_glue_device(self._h, d_whole, d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly,
+                                              d_safe, d_safe_faces), "fh_pair_glue_device")

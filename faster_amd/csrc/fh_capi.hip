@@ -1,0 +1,251 @@
+// fh_capi.hip — host side of the C ABI (include/fasterhip.h): context, buffers, kernel dispatch.
+// Built with hipcc for gfx950 only into faster_amd/libfasterhip.so.  No CPU fallback exists: every entry
+// point needs a HIP device and reports FH_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/fasterhip.h"
+#include "fh_sample.hip.hpp"
+#include "fh_solve.hip.hpp"
+
+struct fh_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_timing = false;
+  fh_params par;
+  std::string err;
+  // staging buffers of the host-pointer entry points (grown on demand, reused)
+  void* d_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[6] = {0, 0, 0, 0, 0, 0};
+};
+
+#define FH_HIP(call)                                                                            \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess) {                                                                    \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                            \
+      return FH_ERR_DEVICE;                                                                     \
+    }                                                                                           \
+  } while (0)
+
+static int ensure(fh_ctx* ctx, int slot, size_t bytes) {
+  if (bytes <= ctx->d_cap[slot]) return FH_OK;
+  if (ctx->d_buf[slot]) FH_HIP(hipFree(ctx->d_buf[slot]));
+  ctx->d_buf[slot] = nullptr;
+  ctx->d_cap[slot] = 0;
+  size_t want = std::max(bytes, (size_t)4096);
+  FH_HIP(hipMalloc(&ctx->d_buf[slot], want));
+  ctx->d_cap[slot] = want;
+  return FH_OK;
+}
+
+template <int NSEG>
+static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n, int max_faces,
+                        fh_result* d_results) {
+  const size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
+  auto kern = fh::solve_kernel<NSEG>;
+  FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  FH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, ctx->stream, d_problems, d_faces, n, max_faces, ctx->par, d_results);
+  FH_HIP(hipGetLastError());
+  FH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->have_timing = true;
+  return FH_OK;
+}
+
+extern "C" {
+
+const char* fh_version(void) { return "fasterhip 0.1 gfx950"; }
+
+void fh_default_params(fh_params* p) {
+  if (!p) return;
+  p->feas_tol = 1e-9;
+  p->dep_tol = 1e-10;
+  p->max_nodes = 100000;
+  p->max_iters = 2000;
+}
+
+int fh_create(fh_ctx** out, int device) {
+  if (!out) return FH_ERR_ARG;
+  *out = nullptr;
+  fh_ctx* ctx = new (std::nothrow) fh_ctx();
+  if (!ctx) return FH_ERR_NOMEM;
+  fh_default_params(&ctx->par);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    // keep the context so that the caller can read the message; every other call will fail too
+    ctx->err = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    *out = ctx;
+    ctx->device = -1;
+    return FH_ERR_DEVICE;
+  }
+  if (device >= 0) {
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+      ctx->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+      *out = ctx;
+      ctx->device = -1;
+      return FH_ERR_DEVICE;
+    }
+  }
+  *out = ctx;
+  FH_HIP(hipGetDevice(&ctx->device));
+  FH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->own_stream;
+  FH_HIP(hipEventCreate(&ctx->ev0));
+  FH_HIP(hipEventCreate(&ctx->ev1));
+  return FH_OK;
+}
+
+void fh_destroy(fh_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->device >= 0) {
+    for (int i = 0; i < 6; i++)
+      if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  }
+  delete ctx;
+}
+
+const char* fh_last_error(const fh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fh_set_params(fh_ctx* ctx, const fh_params* p) {
+  if (!ctx || !p) return FH_ERR_ARG;
+  if (!(p->feas_tol > 0) || !(p->dep_tol > 0) || p->max_nodes < 1 || p->max_iters < 1) return FH_ERR_ARG;
+  ctx->par = *p;
+  return FH_OK;
+}
+
+int fh_set_stream(fh_ctx* ctx, void* hip_stream) {
+  if (!ctx) return FH_ERR_ARG;
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return FH_OK;
+}
+
+int fh_sync(fh_ctx* ctx) {
+  if (!ctx) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+
+int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n, int max_seg,
+                          int max_faces, fh_result* d_results) {
+  if (!ctx || n < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n == 0) return FH_OK;
+  if (!d_problems || !d_results) return FH_ERR_ARG;
+  if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
+  if (max_faces <= 0 || max_faces > FH_MAX_FACES) max_faces = FH_MAX_FACES;
+  max_faces = (max_faces + 7) & ~7;
+  FH_HIP(hipMemsetAsync(d_results, 0, sizeof(fh_result) * (size_t)n, ctx->stream));
+  if (max_seg <= 6) return launch_solve<6>(ctx, d_problems, d_faces, n, max_faces, d_results);
+  if (max_seg <= 10) return launch_solve<10>(ctx, d_problems, d_faces, n, max_faces, d_results);
+  return launch_solve<FH_MAX_SEG>(ctx, d_problems, d_faces, n, max_faces, d_results);
+}
+
+int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
+                   fh_result* results) {
+  if (!ctx || n < 0 || n_faces < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n == 0) return FH_OK;
+  if (!problems || !results || (n_faces > 0 && !faces)) return FH_ERR_ARG;
+  int max_seg = 1, max_faces = 8;
+  for (int i = 0; i < n; i++) {
+    const fh_problem& p = problems[i];
+    if (p.n_seg >= 1 && p.n_seg <= FH_MAX_SEG) max_seg = std::max(max_seg, (int)p.n_seg);
+    if (p.n_poly >= 1 && p.n_poly <= FH_MAX_POLY) {
+      const int nf = p.face_off[p.n_poly];
+      if (nf >= 0 && nf <= FH_MAX_FACES) {
+        // the kernel cannot see n_faces: reject corridors that point outside the face array here
+        if (p.face_begin < 0 || (int64_t)p.face_begin + nf > n_faces) {
+          ctx->err = "fh_solve_batch: problem " + std::to_string(i) + " addresses faces outside [0, n_faces)";
+          return FH_ERR_ARG;
+        }
+        max_faces = std::max(max_faces, nf);
+      }
+    }
+  }
+  int rc;
+  if ((rc = ensure(ctx, 0, sizeof(fh_problem) * (size_t)n)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 1, sizeof(fh_face) * (size_t)std::max<int64_t>(n_faces, 1))) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 2, sizeof(fh_result) * (size_t)n)) != FH_OK) return rc;
+  FH_HIP(hipMemcpyAsync(ctx->d_buf[0], problems, sizeof(fh_problem) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if (n_faces > 0)
+    FH_HIP(hipMemcpyAsync(ctx->d_buf[1], faces, sizeof(fh_face) * (size_t)n_faces, hipMemcpyHostToDevice, ctx->stream));
+  rc = fh_solve_batch_device(ctx, (const fh_problem*)ctx->d_buf[0], (const fh_face*)ctx->d_buf[1], n, max_seg, max_faces,
+                             (fh_result*)ctx->d_buf[2]);
+  if (rc != FH_OK) return rc;
+  FH_HIP(hipMemcpyAsync(results, ctx->d_buf[2], sizeof(fh_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+
+int fh_sample_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_result* d_results, int n, int max_samples,
+                           fh_state* d_states, int32_t* d_counts) {
+  if (!ctx || n < 0 || max_samples < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n == 0) return FH_OK;
+  if (!d_problems || !d_results || !d_counts || (max_samples > 0 && !d_states)) return FH_ERR_ARG;
+  hipLaunchKernelGGL(fh::sample_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_problems, d_results, n, max_samples,
+                     d_states, d_counts);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_sample_batch(fh_ctx* ctx, const fh_problem* problems, const fh_result* results, int n, int max_samples,
+                    fh_state* states, int32_t* counts) {
+  if (!ctx || n < 0 || max_samples < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n == 0) return FH_OK;
+  if (!problems || !results || !counts || (max_samples > 0 && !states)) return FH_ERR_ARG;
+  int rc;
+  const size_t sbytes = sizeof(fh_state) * (size_t)n * (size_t)max_samples;
+  if ((rc = ensure(ctx, 0, sizeof(fh_problem) * (size_t)n)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 2, sizeof(fh_result) * (size_t)n)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 3, std::max(sbytes, (size_t)16))) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 4, sizeof(int32_t) * (size_t)n)) != FH_OK) return rc;
+  FH_HIP(hipMemcpyAsync(ctx->d_buf[0], problems, sizeof(fh_problem) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  FH_HIP(hipMemcpyAsync(ctx->d_buf[2], results, sizeof(fh_result) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  FH_HIP(hipMemsetAsync(ctx->d_buf[3], 0, std::max(sbytes, (size_t)16), ctx->stream));
+  rc = fh_sample_batch_device(ctx, (const fh_problem*)ctx->d_buf[0], (const fh_result*)ctx->d_buf[2], n, max_samples,
+                              (fh_state*)ctx->d_buf[3], (int32_t*)ctx->d_buf[4]);
+  if (rc != FH_OK) return rc;
+  if (sbytes) FH_HIP(hipMemcpyAsync(states, ctx->d_buf[3], sbytes, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipMemcpyAsync(counts, ctx->d_buf[4], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+
+int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const fh_face* d_faces,
+                        int n, double r_frac, double shrink, int max_safe_poly, fh_problem* d_safe, fh_face* d_safe_faces) {
+  if (!ctx || n < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n == 0) return FH_OK;
+  if (!d_whole || !d_whole_results || !d_safe) return FH_ERR_ARG;
+  if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
+  hipLaunchKernelGGL(fh::pair_glue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_whole,
+                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+double fh_last_kernel_ms(fh_ctx* ctx) {
+  if (!ctx || ctx->device < 0 || !ctx->have_timing) return -1.0;
+  if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+}  // extern "C"

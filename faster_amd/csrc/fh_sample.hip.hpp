@@ -1,0 +1,152 @@
+// fh_sample.hip.hpp — resetX()+fillX() and the whole->safe hand-off on the device (gfx950, wave64).
+//
+// sample_kernel  : SolverGurobi::resetX (:382-388) + fillX (:122-168) of /root/reference/faster/src/solverGurobi.cpp.
+//                  One wavefront per trajectory.  The sample clock is the reference's repeated `t = t + DC`
+//                  (NOT (i+1)*DC: the rounding of the running sum decides which segment a sample on a knot
+//                  belongs to), so every lane runs the scalar clock and keeps the tick that is its own; the 64
+//                  states of a tile are transposed through LDS and written as one contiguous 6 KiB burst
+//                  (16 B per lane per store) instead of 96-B-strided scalars.
+// pair_glue_kernel: the data dependency whole -> safe of Faster::replan (faster/src/faster.cpp:456-475, :506-524)
+//                  for synthetic pairs: R = sample (int)(r_frac*count) of the whole
+//                  trajectory becomes x0 of the safe problem; the safe corridor is the run of up to
+//                  `max_safe_poly` consecutive polytopes starting at the first one that contains R, each shrunk
+//                  by `shrink` metres (emulating the unknown-space inflation).  One thread per pair.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/fasterhip.h"
+
+namespace fh {
+
+__device__ __forceinline__ int sample_count(const fh_problem& pr, const fh_result& rs) {
+  int size = (int)((double)((int)pr.n_seg) * rs.dt / pr.dc);  // :384
+  return size < 2 ? 2 : size;                                  // :385
+}
+
+__device__ __forceinline__ void eval_state(const double* c, double tau, bool last, fh_state& s) {
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    s.pos[a] = c[0 + a] * tau * tau * tau + c[3 + a] * tau * tau + c[6 + a] * tau + c[9 + a];  // getPos :761-767
+    s.vel[a] = 3 * c[0 + a] * tau * tau + 2 * c[3 + a] * tau + c[6 + a];                      // getVel :769-774
+    s.accel[a] = 6 * c[0 + a] * tau + 2 * c[3 + a];                                           // getAccel :776-781
+    s.jerk[a] = 6 * c[0 + a];                                                                 // getJerk :783-788
+    if (last) { s.vel[a] = 0; s.accel[a] = 0; s.jerk[a] = 0; }                                // :165-167
+  }
+}
+
+__global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict__ problems, const fh_result* __restrict__ results,
+                                                    int n, int max_samples, fh_state* __restrict__ states,
+                                                    int32_t* __restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) double tile[64 * 12];
+  __shared__ double coef[FH_MAX_SEG * 12];
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const int lane = threadIdx.x;
+  const fh_problem& pr = problems[b];
+  const fh_result& rs = results[b];
+  if (!rs.solved || pr.n_seg < 1 || pr.n_seg > FH_MAX_SEG) {
+    if (lane == 0) counts[b] = 0;
+    return;
+  }
+  const int N = pr.n_seg;
+  const double dt = rs.dt, DC = pr.dc;
+  const int size = sample_count(pr, rs);
+  if (lane == 0) counts[b] = size;
+  for (int i = lane; i < N * 12; i += 64) coef[i] = rs.coeff[i / 12][i % 12];
+  __syncthreads();
+  const int nwrite = size < max_samples ? size : max_samples;
+  fh_state* out = states + (size_t)b * (size_t)max_samples;
+  double t = 0;
+  int interval = 0;
+  for (int base = 0; base < nwrite; base += 64) {
+    double my_t = 0;
+    int my_int = 0;
+    const int lim = (nwrite - base) < 64 ? (nwrite - base) : 64;
+    for (int j = 0; j < lim; j++) {  // the reference's scalar clock, :131-135
+      t = t + DC;
+      if (t > dt * (interval + 1)) interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
+      if (j == lane) { my_t = t; my_int = interval; }
+    }
+    if (lane < lim) {
+      fh_state s;
+      eval_state(&coef[my_int * 12], my_t - my_int * dt, (base + lane) == size - 1, s);
+      double* tl = &tile[lane * 12];
+#pragma unroll
+      for (int a = 0; a < 3; a++) { tl[a] = s.pos[a]; tl[3 + a] = s.vel[a]; tl[6 + a] = s.accel[a]; tl[9 + a] = s.jerk[a]; }
+    }
+    __syncthreads();
+    // contiguous burst: lim*12 doubles, two per lane per store
+    double2* dst = reinterpret_cast<double2*>(out + base);
+    const double2* src = reinterpret_cast<const double2*>(tile);
+    for (int i = lane; i < lim * 6; i += 64) dst[i] = src[i];
+    __syncthreads();
+  }
+}
+
+__global__ void pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
+                                 const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink, int max_safe_poly,
+                                 fh_problem* __restrict__ safe, fh_face* __restrict__ sfaces) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const fh_problem& pw = whole[b];
+  const fh_result& rw = wres[b];
+  fh_problem& ps = safe[b];
+  if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
+    ps.n_seg = 0;
+    return;
+  }
+  const int N = pw.n_seg;
+  const double dt = rw.dt, DC = pw.dc;
+  const int size = sample_count(pw, rw);
+  int k = (int)(r_frac * (double)size);
+  if (k > size - 1) k = size - 1;
+  if (k < 0) k = 0;
+  double t = 0;
+  int interval = 0;
+  for (int i = 0; i <= k; i++) {
+    t = t + DC;
+    if (t > dt * (interval + 1)) interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
+  }
+  fh_state R;
+  eval_state(rw.coeff[interval], t - interval * dt, k == size - 1, R);
+  for (int a = 0; a < 3; a++) {
+    ps.x0[a] = R.pos[a];
+    ps.x0[3 + a] = R.vel[a];
+    ps.x0[6 + a] = R.accel[a];
+  }
+  // first polytope (shrunk) that contains R, else the least violated one
+  const int P = pw.n_poly;
+  int start = 0;
+  double best = INFINITY;
+  bool found = false;
+  for (int p = 0; p < P && !found; p++) {
+    double worst = -INFINITY;
+    for (int f = pw.face_off[p]; f < pw.face_off[p + 1]; f++) {
+      const fh_face fc = wfaces[pw.face_begin + f];
+      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+      worst = fmax(worst, fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - shrink * nr));
+    }
+    if (worst <= 0) { start = p; found = true; }
+    else if (worst < best) { best = worst; start = p; }
+  }
+  int cnt = P - start;
+  if (cnt > max_safe_poly) cnt = max_safe_poly;
+  if (P == 0) cnt = 0;
+  ps.n_poly = cnt;
+  ps.face_begin = pw.face_begin;
+  int o = 0;
+  ps.face_off[0] = 0;
+  for (int p = 0; p < cnt; p++) {
+    for (int f = pw.face_off[start + p]; f < pw.face_off[start + p + 1]; f++) {
+      fh_face fc = wfaces[pw.face_begin + f];
+      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+      fc.b -= shrink * nr;
+      sfaces[pw.face_begin + o] = fc;
+      o++;
+    }
+    ps.face_off[p + 1] = o;
+  }
+  for (int p = cnt; p < FH_MAX_POLY; p++) ps.face_off[p + 1] = o;
+}
+
+}  // namespace fh

@@ -1,0 +1,766 @@
+// fh_solve.hip.hpp — the genNewTraj() kernel for gfx950 (CDNA4, wave64).  Hand-written HIP, FP64.
+//
+// Replaces, for a whole batch at once, SolverGurobi::genNewTraj() and every callOptimizer() it issues
+// (/root/reference/faster/src/solverGurobi.cpp:426-477, :549-657): time allocation (getDTInitial :659-759,
+// findDT :494-497), the model the reference rebuilds per trial (:180-291, :332-407, :499-524, :86-120) and the
+// MIQP solve that Gurobi performs inside m.optimize() (:566).
+//
+// Mapping to the machine
+//   * one problem (= one genNewTraj call) per 64-lane wavefront, one wavefront per workgroup; the grid is the
+//     batch, so the hardware dispatcher load-balances problems of different difficulty across the 256 CUs;
+//   * control flow is wave-uniform: the whole search (factor loop -> branch and bound -> dual active set) is a
+//     scalar program; the 64 lanes are the data-parallel axis inside every step (rows of the constraint scan,
+//     rows/columns of the QR factors, (segment, polytope) pairs of the leaf test);
+//   * everything a solve touches lives in LDS (thin QR of the active normals, states, control points, the
+//     polytope faces staged once per problem with coalesced 32-B face loads); HBM traffic is the compulsory
+//     problem read and result write only;
+//   * the constraint matrix is never formed: rows are (face normal) x (Toeplitz weight of the triple integrator)
+//     and are evaluated from the control points (3 FMAs per row).
+//
+// Algorithm (same as the CPU oracle restates, oracle/faster_oracle.c): jerk-space QP min |x|^2, dual active-set
+// (Goldfarb-Idnani with identity Hessian, thin QR by re-orthogonalised Gram-Schmidt, Givens on removal), exact
+// branch and bound over "segment t in polytope p" with lazily branched segments; the first child of a node is
+// warm-started from its parent's factorisation (the dual method stays dual feasible when rows are added).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fasterhip.h"
+
+namespace fh {
+
+#define FH_SYNC() __syncthreads()
+#define FH_MAX_TRIALS 4096
+
+enum { K_EQ = 0, K_JBOX = 1, K_VBOX = 2, K_ABOX = 3, K_POLY = 4 };
+// weight kinds of a row: which linear functional of the state at the start of segment tt
+enum { W_P = 0, W_CP1 = 1, W_CP2 = 2, W_V = 3, W_A = 4, W_KINDS = 5 };
+
+__device__ __forceinline__ int mk_id(int kind, int t, int k, int f) { return (kind << 24) | (t << 16) | (k << 8) | f; }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return uniform_f64(v);
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return uniform_f64(v);
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return uniform_f64(v);
+}
+__device__ __forceinline__ int first_lane(bool pred) {  // lowest lane with pred, -1 if none (uniform)
+  unsigned long long m = __ballot(pred);
+  return m ? (int)__builtin_ctzll(m) : -1;
+}
+__device__ __forceinline__ bool wave_any(bool pred) { return __ballot(pred) != 0ull; }
+
+// coefficient of jerk j_s in functional `kind` of the state at the start of segment tt, m = tt-1-s >= 0
+__device__ __forceinline__ double wcoef(int kind, int m, double h) {
+  const double dm = (double)m;
+  const double cP = h * h * h * (1.0 / 6.0 + 0.5 * dm + 0.5 * dm * dm);
+  const double cV = h * h * (0.5 + dm);
+  switch (kind) {
+    case W_P: return cP;
+    case W_CP1: return cP + cV * (h / 3.0);
+    case W_CP2: return cP + cV * (2.0 * h / 3.0) + h * (h * h / 6.0);
+    case W_V: return cV;
+    default: return h;
+  }
+}
+
+// ---- time allocation: getDTInitial (solverGurobi.cpp:659-759); same closed forms as the oracle ------------------
+__device__ inline double polish3(double c3, double c2, double c1, double c0, double t) {
+  for (int it = 0; it < 3; it++) {
+    double f = ((c3 * t + c2) * t + c1) * t + c0;
+    double df = (3 * c3 * t + 2 * c2) * t + c1;
+    if (df == 0 || !isfinite(df)) break;
+    double tn = t - f / df;
+    if (!isfinite(tn)) break;
+    t = tn;
+  }
+  return t;
+}
+__device__ inline double min_pos_add(double best, double v) {  // MinPositiveElement, solverGurobi_utils.hpp:19-32
+  return (v > 0 && (best == 0 || v < best)) ? v : best;
+}
+__device__ inline double min_pos_root_cubic(double c3, double c2, double c1, double c0) {
+  const double B = c2 / c3, C = c1 / c3, D = c0 / c3;
+  const double p = C - B * B / 3.0;
+  const double q = 2.0 * B * B * B / 27.0 - B * C / 3.0 + D;
+  const double disc = q * q / 4.0 + p * p * p / 27.0;
+  double best = 0;
+  if (disc > 0) {
+    const double sq = sqrt(disc);
+    const double u = cbrt(-q / 2.0 + sq), v = cbrt(-q / 2.0 - sq);
+    best = min_pos_add(best, polish3(c3, c2, c1, c0, u + v - B / 3.0));
+    if (0.5 * sqrt(3.0) * fabs(u - v) < 1e-12) best = min_pos_add(best, -(u + v) / 2.0 - B / 3.0);
+  } else if (p == 0) {
+    best = min_pos_add(best, -B / 3.0);
+  } else {
+    const double m = 2.0 * sqrt(-p / 3.0);
+    double arg = 3.0 * q / (p * m);
+    arg = fmin(1.0, fmax(-1.0, arg));
+    const double phi = acos(arg) / 3.0;
+    for (int j = 0; j < 3; j++)
+      best = min_pos_add(best, polish3(c3, c2, c1, c0, m * cos(phi - 2.0 * 3.14159265358979323846 * j / 3.0) - B / 3.0));
+  }
+  return best;
+}
+__device__ inline double min_pos_root_quad(double c2, double c1, double c0) {
+  const double disc = c1 * c1 - 4.0 * c2 * c0;
+  double best = 0;
+  if (disc < 0) {
+    if (sqrt(-disc) / fabs(2.0 * c2) < 1e-12) best = min_pos_add(best, -c1 / (2.0 * c2));
+    return best;
+  }
+  const double s = sqrt(disc);
+  const double qq = -0.5 * (c1 + (c1 >= 0 ? s : -s));
+  if (qq != 0) {
+    best = min_pos_add(best, qq / c2);
+    best = min_pos_add(best, c0 / qq);
+  }
+  return best;
+}
+__device__ inline double dt_initial(const fh_problem& pr) {
+  float mx = 0.f;
+  for (int i = 0; i < 3; i++) {
+    const double dx = pr.xf[i] - pr.x0[i];
+    const float tv = (float)(fabs(dx) / pr.v_max);                     // :672-674
+    const float jerk = (float)(copysign(1.0, dx) * pr.j_max);          // :679-681
+    const float a0 = (float)pr.x0[6 + i], v0 = (float)pr.x0[3 + i];    // :682-687
+    const float tj = (float)min_pos_root_cubic((double)jerk / 6.0, (double)a0 / 2.0, (double)v0, -dx);  // :691-713
+    const float acc = (float)(copysign(1.0, dx) * pr.a_max);           // :718-720
+    const float ta = (float)min_pos_root_quad(0.5 * (double)acc, (double)v0, -dx);                      // :724-746
+    mx = fmaxf(mx, fmaxf(tv, fmaxf(ta, tj)));
+  }
+  double dt0 = (double)(mx / (float)pr.n_seg);  // :751  (float / int)
+  if (dt0 > 10000) dt0 = 0;                     // :752-756
+  return dt0;
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+template <int NSEG>
+struct Solver {
+  static constexpr int NV = 3 * NSEG;
+  static constexpr int S = NV | 1;  // odd row stride: conflict-free column AND row sweeps with ds_read_b64
+  static constexpr int NT = NSEG + 1;
+
+  // ---- LDS carve (doubles first) ----
+  double *Q, *R;                                      // [NV][S]: Q1 (column c = active slot), R upper triangular
+  double *x, *z, *g, *d, *r, *u, *rinv, *bestx;       // [NV]
+  double *P0, *V0, *A0, *Pc, *Vc, *Ac;                // [NT*3] jerk-free / current states at segment starts
+  double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
+  double* wn;                                         // [W_KINDS][NT] row-norm factors sqrt(sum_m wcoef^2)
+  double* viol;                                       // [NSEG][FH_MAX_POLY]
+  double* fnorm;                                      // [n_faces] |a_f|
+  fh_face* faces;                                     // [n_faces]
+  unsigned long long* polyact;                        // [NSEG][4] active-row bit per face
+  int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_order, *face_off;
+
+  static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
+    return sizeof(double) * (2 * NV * S + 8 * NV + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + NSEG * FH_MAX_POLY + max_faces) +
+           sizeof(fh_face) * max_faces + sizeof(unsigned long long) * NSEG * 4 +
+           sizeof(int) * (2 * NV + 5 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 2) + 64;
+  }
+
+  // ---- wave-uniform scalars ----
+  int lane, N, n, q, P;
+  double h, tol, dep2;
+  double vmax, amax, jmax;
+  int force_final;
+  double xf9[9];
+
+  __device__ void carve(unsigned char* base, int max_faces) {
+    double* p = reinterpret_cast<double*>(base);
+    Q = p; p += NV * S;
+    R = p; p += NV * S;
+    x = p; p += NV;  z = p; p += NV;  g = p; p += NV;  d = p; p += NV;
+    r = p; p += NV;  u = p; p += NV;  rinv = p; p += NV;  bestx = p; p += NV;
+    P0 = p; p += NT * 3;  V0 = p; p += NT * 3;  A0 = p; p += NT * 3;
+    Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
+    CP = p; p += NSEG * 12;
+    wn = p; p += W_KINDS * NT;
+    viol = p; p += NSEG * FH_MAX_POLY;
+    fnorm = p; p += max_faces;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) p += 1;  // faces are read 16 B at a time
+    faces = reinterpret_cast<fh_face*>(p); p += 4 * max_faces;
+    polyact = reinterpret_cast<unsigned long long*>(p); p += NSEG * 4;
+    int* ip = reinterpret_cast<int*>(p);
+    act = ip; ip += NV;  boxact = ip; ip += NV;
+    assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
+    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_order = ip; ip += NSEG * FH_MAX_POLY;
+    face_off = ip; ip += FH_MAX_POLY + 1;
+  }
+
+  // ---- per trial: jerk-free states and row-norm table for step h ----
+  __device__ void setup_trial(const fh_problem& pr) {
+    if (lane < 3) {  // zero-jerk propagation of x0 (3 lanes, N serial steps)
+      double p = pr.x0[lane], v = pr.x0[3 + lane], a = pr.x0[6 + lane];
+      P0[lane] = p; V0[lane] = v; A0[lane] = a;
+      for (int t = 0; t < N; t++) {
+        p = p + v * h + 0.5 * a * h * h;
+        v = v + a * h;
+        P0[(t + 1) * 3 + lane] = p; V0[(t + 1) * 3 + lane] = v; A0[(t + 1) * 3 + lane] = a;
+      }
+    }
+    for (int idx = lane; idx < W_KINDS * NT; idx += 64) {
+      const int kind = idx / NT, tt = idx % NT;
+      double s = 0;
+      for (int m = 0; m < tt && tt <= N; m++) {
+        const double c = wcoef(kind, m, h);
+        s += c * c;
+      }
+      wn[idx] = sqrt(s);
+    }
+    FH_SYNC();
+  }
+
+  // ---- states at segment starts and Bezier control points of the current x (getCP0..3, :833-862) ----
+  __device__ void compute_states() {
+    if (lane < (N + 1) * 3) {
+      const int tt = lane / 3, i = lane - 3 * tt;
+      double p = P0[lane], v = V0[lane], a = A0[lane];
+      for (int s = 0; s < tt; s++) {
+        const double dm = (double)(tt - 1 - s);
+        const double xs = x[3 * s + i];
+        p += h * h * h * (1.0 / 6.0 + 0.5 * dm + 0.5 * dm * dm) * xs;
+        v += h * h * (0.5 + dm) * xs;
+        a += h * xs;
+      }
+      Pc[lane] = p; Vc[lane] = v; Ac[lane] = a;
+    }
+    FH_SYNC();
+    for (int idx = lane; idx < N * 12; idx += 64) {
+      const int t = idx / 12, rem = idx - 12 * t, k = rem / 3, i = rem - 3 * k;
+      const int o = (t + (k == 3 ? 1 : 0)) * 3 + i;
+      double c = Pc[o];
+      if (k == 1) c += Vc[o] * (h / 3.0);
+      if (k == 2) c += Vc[o] * (2.0 * h / 3.0) + Ac[o] * (h * h / 6.0);
+      CP[idx] = c;
+    }
+    FH_SYNC();
+  }
+
+  // ---- most violated inactive inequality row; violation relative to the row norm. id<0: none. ----
+  // sets const_bad if a jerk-independent row (segment 0, control points 0..2) is violated.
+  __device__ void scan(int& id_out, double& v_out, bool& const_bad) {
+    double bs = 0, bv = 0;
+    int bid = -1;
+    bool bad = false;
+    if (lane < n) {
+      const int t = lane / 3, i = lane - 3 * t;
+      const int ba = boxact[lane];
+      const double xv = x[lane];
+      double v = xv - jmax;
+      if (v > tol && !(ba & 1) && v > bs) { bs = v; bv = v; bid = mk_id(K_JBOX, t, i, 0); }
+      v = -xv - jmax;
+      if (v > tol && !(ba & 2) && v > bs) { bs = v; bv = v; bid = mk_id(K_JBOX, t, i, 1); }
+      if (t >= 1) {
+        const double V = Vc[lane], A = Ac[lane];
+        const double nV = wn[W_V * NT + t], nA = wn[W_A * NT + t];
+        v = V - vmax;
+        if (v > tol && !(ba & 4) && v > bs * nV) { bs = v / nV; bv = v; bid = mk_id(K_VBOX, t, i, 0); }
+        v = -V - vmax;
+        if (v > tol && !(ba & 8) && v > bs * nV) { bs = v / nV; bv = v; bid = mk_id(K_VBOX, t, i, 1); }
+        v = A - amax;
+        if (v > tol && !(ba & 16) && v > bs * nA) { bs = v / nA; bv = v; bid = mk_id(K_ABOX, t, i, 0); }
+        v = -A - amax;
+        if (v > tol && !(ba & 32) && v > bs * nA) { bs = v / nA; bv = v; bid = mk_id(K_ABOX, t, i, 1); }
+      }
+    }
+    const int k = lane & 3, fl = lane >> 2;
+    for (int t = 0; t < N; t++) {
+      const int p = assign[t];
+      if (p < 0) continue;
+      const int f0 = face_off[p], F = face_off[p + 1] - f0;
+      const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
+      const unsigned long long am = polyact[t * 4 + k];
+      const double w = wn[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
+      for (int fb = 0; fb < F; fb += 16) {
+        const int f = fb + fl;
+        if (f < F) {
+          const fh_face fc = faces[f0 + f];
+          const double v = fc.a[0] * c0 + fc.a[1] * c1 + fc.a[2] * c2 - fc.b;
+          if (v > tol) {
+            if (w == 0.0) bad = true;
+            else if (!((am >> f) & 1ull)) {
+              const double nr = fnorm[f0 + f] * w;
+              if (v > bs * nr) { bs = v / nr; bv = v; bid = mk_id(K_POLY, t, k, f); }
+            }
+          }
+        }
+      }
+    }
+    const_bad = wave_any(bad);
+    const double mx = wave_max(bs);
+    id_out = -1;
+    v_out = 0;
+    if (mx > 0) {
+      const int L = first_lane(bs == mx);
+      id_out = __builtin_amdgcn_readlane(bid, L);
+      v_out = readlane_f64(bv, L);
+    }
+  }
+
+  // ---- normal of row `id` in jerk space: g[v], v = 3 s + i.  returns |g|^2 ----
+  __device__ double build_g(int id) {
+    const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
+    double gv = 0;
+    if (lane < n) {
+      const int s = lane / 3, i = lane - 3 * s;
+      if (kind == K_JBOX) {
+        gv = (s == t && i == k) ? (f ? -1.0 : 1.0) : 0.0;
+      } else {
+        int wk, tt;
+        double gi;
+        if (kind == K_POLY) {
+          wk = (k == 3) ? W_P : k;
+          tt = t + (k == 3 ? 1 : 0);
+          gi = faces[face_off[assign[t]] + f].a[i];
+        } else if (kind == K_EQ) {  // f = axis*3 + which (0 pos, 1 vel, 2 accel), state at the end (tt = N)
+          const int axis = f / 3, which = f - 3 * axis;
+          wk = which == 0 ? W_P : (which == 1 ? W_V : W_A);
+          tt = N;
+          gi = (i == axis) ? 1.0 : 0.0;
+        } else {
+          wk = (kind == K_VBOX) ? W_V : W_A;
+          tt = t;
+          gi = (i == k) ? (f ? -1.0 : 1.0) : 0.0;
+        }
+        const int m = tt - 1 - s;
+        gv = (m >= 0) ? gi * wcoef(wk, m, h) : 0.0;
+      }
+      g[lane] = gv;
+    }
+    FH_SYNC();
+    return wave_sum(gv * gv);
+  }
+
+  // ---- z = (I - Q1 Q1^T) g with one re-orthogonalisation, d = Q1^T g (per-lane dc for lane<q). returns |z|^2 ----
+  __device__ double project(double& dc, double& zi) {
+    dc = 0;
+    if (lane < q)
+      for (int i = 0; i < n; i++) dc += Q[i * S + lane] * g[i];
+    if (lane < NV) d[lane] = dc;
+    FH_SYNC();
+    zi = 0;
+    if (lane < n) {
+      zi = g[lane];
+      for (int c = 0; c < q; c++) zi -= Q[lane * S + c] * d[c];
+      z[lane] = zi;
+    }
+    FH_SYNC();
+    double ec = 0;
+    if (lane < q) {
+      for (int i = 0; i < n; i++) ec += Q[i * S + lane] * z[i];
+      dc += ec;
+      r[lane] = ec;
+    }
+    FH_SYNC();
+    if (lane < n) {
+      for (int c = 0; c < q; c++) zi -= Q[lane * S + c] * r[c];
+      z[lane] = zi;
+    }
+    FH_SYNC();
+    return wave_sum(lane < n ? zi * zi : 0.0);
+  }
+
+  // ---- r = R^{-1} d, column-oriented; lane c returns r_c ----
+  __device__ double backsolve(double dc) {
+    double rc = 0;
+    const double ri = (lane < q) ? rinv[lane] : 0.0;
+    double dcur = dc;
+    for (int c = q - 1; c >= 0; c--) {
+      const double val = readlane_f64(dcur * ri, c);
+      if (lane == c) rc = val;
+      if (lane < c) dcur -= R[lane * S + c] * val;
+    }
+    return rc;
+  }
+
+  __device__ void set_active(int id, bool on) {
+    const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
+    if (kind == K_EQ) return;
+    if (lane == 0) {
+      if (kind == K_POLY) {
+        unsigned long long m = polyact[t * 4 + k];
+        m = on ? (m | (1ull << f)) : (m & ~(1ull << f));
+        polyact[t * 4 + k] = m;
+      } else {
+        const int bit = (kind == K_JBOX ? 1 : (kind == K_VBOX ? 4 : 16)) << f;
+        int b = boxact[3 * t + k];
+        b = on ? (b | bit) : (b & ~bit);
+        boxact[3 * t + k] = b;
+      }
+    }
+  }
+
+  __device__ void add_row(int id, double zi, double zz, double dc, double up) {
+    const double rho = sqrt(zz);
+    const double inv = 1.0 / rho;
+    if (lane < n) Q[lane * S + q] = zi * inv;
+    if (lane < q) R[lane * S + q] = dc;
+    if (lane == q) {
+      R[q * S + q] = rho;
+      rinv[q] = inv;
+      act[q] = id;
+      u[q] = up;
+    }
+    set_active(id, true);
+    q++;
+    FH_SYNC();
+  }
+
+  __device__ void drop_row(int kpos) {
+    set_active(act[kpos], false);
+    FH_SYNC();
+    // shift the bookkeeping and the columns of R left
+    int a_next = 0;
+    double u_next = 0;
+    if (lane >= kpos && lane < q - 1) { a_next = act[lane + 1]; u_next = u[lane + 1]; }
+    FH_SYNC();
+    if (lane >= kpos && lane < q - 1) { act[lane] = a_next; u[lane] = u_next; }
+    if (lane < q)
+      for (int c = kpos; c < q - 1; c++) R[lane * S + c] = R[lane * S + c + 1];
+    FH_SYNC();
+    for (int j = kpos; j < q - 1; j++) {  // Givens: zero R[j+1][j]
+      const double a = R[j * S + j], b = R[(j + 1) * S + j];
+      const double rr = sqrt(a * a + b * b);
+      if (rr != 0.0) {
+        const double cs = a / rr, sn = b / rr;
+        if (lane >= j && lane < q - 1) {
+          const double t1 = R[j * S + lane], t2 = R[(j + 1) * S + lane];
+          R[j * S + lane] = cs * t1 + sn * t2;
+          R[(j + 1) * S + lane] = -sn * t1 + cs * t2;
+        }
+        if (lane < n) {
+          const double t1 = Q[lane * S + j], t2 = Q[lane * S + j + 1];
+          Q[lane * S + j] = cs * t1 + sn * t2;
+          Q[lane * S + j + 1] = -sn * t1 + cs * t2;
+        }
+      }
+      FH_SYNC();
+    }
+    if (lane >= kpos && lane < q - 1) rinv[lane] = 1.0 / R[lane * S + lane];
+    q--;
+    FH_SYNC();
+  }
+
+  __device__ void reset_qp() {
+    q = 0;
+    if (lane < NV) { x[lane] = 0; boxact[lane] = 0; }
+    for (int i = lane; i < NSEG * 4; i += 64) polyact[i] = 0ull;
+    FH_SYNC();
+  }
+
+  // ---- dual active set from the current (dual feasible) state.  eq_next: next equality to add (9 = none left).
+  // returns 0 optimal, 1 infeasible, 2 bounded out by `ub`, 3 iteration limit ----
+  __device__ int qp_run(int& eq_next, double ub, int max_iters, int& iters, double& cost) {
+    int it = 0;
+    const int st = qp_loop(eq_next, ub, max_iters, it, cost);
+    iters += it;
+    return st;
+  }
+  __device__ int qp_loop(int& eq_next, double ub, int max_iters, int& it, double& cost) {
+    for (;;) {
+      compute_states();
+      int id;
+      double vp;
+      bool is_eq = false;
+      if (eq_next < 9) {
+        const int axis = eq_next / 3, which = eq_next - 3 * axis;
+        const int e = eq_next++;
+        if (which == 0 && !force_final) continue;
+        const double cur = which == 0 ? Pc[N * 3 + axis] : (which == 1 ? Vc[N * 3 + axis] : Ac[N * 3 + axis]);
+        vp = cur - xf9[which * 3 + axis];
+        id = mk_id(K_EQ, 0, 0, e);
+        is_eq = true;
+      } else {
+        const double xl = (lane < n) ? x[lane] : 0.0;
+        cost = wave_sum(xl * xl);
+        if (cost >= ub) return 2;
+        bool cbad;
+        scan(id, vp, cbad);
+        if (cbad) return 1;
+        if (id < 0) return 0;
+      }
+      const double gg = build_g(id);
+      double up = 0;
+      for (;;) {  // until row `id` is active
+        if (++it > max_iters) return 3;
+        double dc, zi;
+        const double zz = project(dc, zi);
+        const double rc = backsolve(dc);
+        const bool dependent = zz <= dep2 * gg;
+        if (is_eq) {
+          if (dependent) {
+            if (fabs(vp) > tol) return 1;
+            break;  // redundant equality
+          }
+          const double t = vp / zz;
+          if (lane < q) u[lane] -= t * rc;
+          if (lane < n) x[lane] -= t * zi;
+          add_row(id, zi, zz, dc, t);
+          break;
+        }
+        double ratio = INFINITY;
+        if (lane < q && (act[lane] >> 24) != K_EQ && rc > 0) ratio = u[lane] / rc;
+        const double t1 = wave_min(ratio);
+        const int kb = (t1 < INFINITY) ? first_lane(ratio == t1) : -1;
+        if (kb < 0 && dependent) return 1;
+        const double t2 = dependent ? INFINITY : vp / zz;
+        const double t = fmin(t1, t2);
+        if (lane < q) u[lane] -= t * rc;
+        up += t;
+        if (!dependent) {
+          if (lane < n) x[lane] -= t * zi;
+          vp -= t * zz;
+        }
+        if (t2 <= t1) {
+          add_row(id, zi, zz, dc, up);
+          break;
+        }
+        FH_SYNC();
+        drop_row(kb);
+      }
+    }
+  }
+
+  // ---- leaf test / branching choice for the node just solved. returns branch segment or -1 (leaf) ----
+  __device__ int analyze(const fh_problem& pr) {
+    if (P == 0) {
+      if (lane < N) fullassign[lane] = -1;
+      FH_SYNC();
+      return -1;
+    }
+    for (int pair = lane; pair < N * P; pair += 64) {
+      const int t = pair / P, p = pair - t * P;
+      double worst = -INFINITY;
+      if (assign[t] < 0) {
+        const int f0 = face_off[p], f1 = face_off[p + 1];
+        for (int k = 0; k < 4; k++) {
+          const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
+          for (int f = f0; f < f1; f++) {
+            const fh_face fc = faces[f];
+            worst = fmax(worst, fc.a[0] * c0 + fc.a[1] * c1 + fc.a[2] * c2 - fc.b);
+          }
+        }
+      }
+      viol[t * FH_MAX_POLY + p] = worst;
+    }
+    FH_SYNC();
+    double score = -INFINITY;
+    if (lane < N) {
+      int full = assign[lane];
+      if (full < 0) {
+        double mn = INFINITY;
+        for (int p = 0; p < P; p++) {
+          const double v = viol[lane * FH_MAX_POLY + p];
+          if (v < mn) { mn = v; full = p; }
+        }
+        score = mn;
+      }
+      fullassign[lane] = full;
+    }
+    const double bw = wave_max(score);
+    FH_SYNC();
+    if (!(bw > tol)) return -1;
+    return first_lane(score == bw);
+  }
+
+  // ---- MIQP for one dt: depth-first branch and bound.  returns FH_ST_* ----
+  __device__ int miqp(const fh_problem& pr, const fh_params& par, double& best_cost, int& nodes, int& iters) {
+    best_cost = INFINITY;
+    int depth = 0;
+    int status_limit = 0;
+    if (lane < NSEG) assign[lane] = -1;
+    // jerk-independent rows of the box: |v0| <= v_max, |a0| <= a_max (setMaxConstraints t = 0, :397-401)
+    bool x0bad = false;
+    for (int i = 0; i < 3; i++) x0bad |= (fabs(pr.x0[3 + i]) - vmax > tol) || (fabs(pr.x0[6 + i]) - amax > tol);
+    if (x0bad) return FH_ST_INFEASIBLE;
+    reset_qp();
+    int eq_next = 0;
+    bool have_node = true;  // a node is ready to be solved (assign[] set, QP state prepared)
+    int local_nodes = 0;
+    while (have_node) {
+      if (local_nodes >= par.max_nodes) { status_limit = FH_ST_NODE_LIMIT; break; }
+      local_nodes++;
+      double cost = 0;
+      const int st = qp_run(eq_next, best_cost, par.max_iters, iters, cost);
+      if (st == 3) { status_limit = FH_ST_ITER_LIMIT; break; }
+      bool descend = false;
+      if (st == 0) {
+        const int bseg = analyze(pr);
+        if (bseg < 0) {  // leaf: feasible for the MIQP
+          if (cost < best_cost) {
+            best_cost = cost;
+            if (lane < n) bestx[lane] = x[lane];
+            if (lane < N) bestassign[lane] = fullassign[lane];
+            FH_SYNC();
+          }
+        } else {  // branch on bseg, most promising polytope first (stable insertion sort)
+          if (lane == 0) {
+            int* ord = &stk_order[depth * FH_MAX_POLY];
+            for (int p = 0; p < P; p++) ord[p] = p;
+            for (int a = 1; a < P; a++)
+              for (int b = a; b > 0 && viol[bseg * FH_MAX_POLY + ord[b]] < viol[bseg * FH_MAX_POLY + ord[b - 1]]; b--) {
+                const int tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp;
+              }
+            stk_seg[depth] = bseg;
+            stk_next[depth] = 1;
+            assign[bseg] = ord[0];
+          }
+          depth++;
+          FH_SYNC();
+          descend = true;  // first child: warm start from the parent's factorisation (dual feasible)
+        }
+      }
+      if (descend) continue;
+      // backtrack to the next untried sibling
+      have_node = false;
+      while (depth > 0) {
+        const int d_ = depth - 1;
+        const int nx = stk_next[d_];
+        const int seg = stk_seg[d_];
+        if (nx < P) {
+          FH_SYNC();
+          if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
+          FH_SYNC();
+          reset_qp();
+          eq_next = 0;
+          have_node = true;
+          break;
+        }
+        FH_SYNC();
+        if (lane == 0) assign[seg] = -1;
+        depth--;
+        FH_SYNC();
+      }
+    }
+    nodes += local_nodes;
+    if (status_limit) return status_limit;
+    return (best_cost < INFINITY) ? FH_ST_OPTIMAL : FH_ST_INFEASIBLE;
+  }
+};
+
+__device__ inline bool bad_input(const fh_problem& pr, int nseg_cap, int face_cap) {
+  if (pr.n_seg < 1 || pr.n_seg > nseg_cap || pr.n_poly < 0 || pr.n_poly > FH_MAX_POLY) return true;
+  if (pr.face_off[0] != 0 || pr.face_begin < 0) return true;
+  for (int p = 0; p < pr.n_poly; p++) {
+    const int c = pr.face_off[p + 1] - pr.face_off[p];
+    if (c < 0 || c > FH_MAX_FACES_POLY) return true;
+  }
+  if (pr.n_poly && pr.face_off[pr.n_poly] > face_cap) return true;
+  if (!(pr.f_inc > 0) || !isfinite(pr.f_init) || !isfinite(pr.f_final)) return true;
+  if ((pr.f_final - pr.f_init) / pr.f_inc > (double)FH_MAX_TRIALS) return true;
+  if (!(pr.dc > 0) || !(pr.v_max > 0) || !(pr.a_max > 0) || !(pr.j_max > 0)) return true;
+  for (int i = 0; i < 9; i++)
+    if (!isfinite(pr.x0[i]) || !isfinite(pr.xf[i])) return true;
+  return false;
+}
+
+// One workgroup (= one wavefront) per problem.
+template <int NSEG>
+__global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ gfaces,
+                                                   int n_problems, int max_faces, fh_params par, fh_result* __restrict__ results) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  if (b >= n_problems) return;
+  const fh_problem& pr = problems[b];
+  fh_result& res = results[b];
+  const int lane = threadIdx.x;
+
+  Solver<NSEG> sv;
+  sv.carve(smem, max_faces);
+  sv.lane = lane;
+
+  if (bad_input(pr, NSEG, max_faces)) {
+    if (lane == 0) {
+      res.solved = 0; res.trials = 0; res.status = FH_ST_BAD_INPUT; res.nodes = 0; res.qp_iters = 0; res.reserved = 0;
+      res.factor = 0; res.dt = 0; res.cost = 0;
+    }
+    if (lane < FH_MAX_SEG) res.assign[lane] = -1;
+    return;
+  }
+
+  sv.N = pr.n_seg;
+  sv.n = 3 * pr.n_seg;
+  sv.P = pr.n_poly;
+  sv.tol = par.feas_tol;
+  sv.dep2 = par.dep_tol * par.dep_tol;
+  sv.vmax = pr.v_max; sv.amax = pr.a_max; sv.jmax = pr.j_max;
+  sv.force_final = pr.force_final_pos;
+  for (int i = 0; i < 9; i++) sv.xf9[i] = pr.xf[i];
+
+  // stage the corridor once: coalesced 32-B face rows HBM -> LDS, and |a_f|
+  const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
+  if (lane <= FH_MAX_POLY) sv.face_off[lane] = pr.face_off[lane];
+  for (int f = lane; f < nf; f += 64) {
+    const fh_face fc = gfaces[pr.face_begin + f];
+    sv.faces[f] = fc;
+    sv.fnorm[f] = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+  }
+  FH_SYNC();
+
+  const double dt0 = dt_initial(pr);
+  const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
+  int trials = 0, nodes = 0, iters = 0, status = FH_ST_INFEASIBLE;
+  bool solved = false;
+  double dt = 0, factor = 0, cost = 0;
+  for (double f = pr.f_init; f <= pr.f_final && !solved; f = f + pr.f_inc) {  // genNewTraj :445-446
+    trials++;
+    dt = f * base;
+    sv.h = dt;
+    sv.setup_trial(pr);
+    status = sv.miqp(pr, par, cost, nodes, iters);
+    if (status == FH_ST_OPTIMAL) {
+      solved = true;
+      factor = f;
+    }
+  }
+
+  if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
+    if (lane < sv.n) sv.x[lane] = sv.bestx[lane];
+    FH_SYNC();
+    sv.compute_states();
+    if (lane < sv.n) {
+      const int t = lane / 3, i = lane - 3 * t;
+      res.coeff[t][0 + i] = sv.bestx[lane] / 6.0;
+      res.coeff[t][3 + i] = sv.Ac[lane] / 2.0;
+      res.coeff[t][6 + i] = sv.Vc[lane];
+      res.coeff[t][9 + i] = sv.Pc[lane];
+    }
+  }
+  if (lane < FH_MAX_SEG) res.assign[lane] = (solved && lane < sv.N && sv.P > 0) ? (int8_t)sv.bestassign[lane] : (int8_t)-1;
+  if (lane == 0) {
+    res.solved = solved ? 1 : 0;
+    res.trials = trials;
+    res.status = status;
+    res.nodes = nodes;
+    res.qp_iters = iters;
+    res.reserved = 0;
+    res.factor = solved ? factor : 0.0;
+    res.dt = dt;
+    res.cost = solved ? cost : 0.0;
+  }
+}
+
+}  // namespace fh

@@ -125,9 +125,12 @@ int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces
                    fh_result* results);
 
 /* Same, with every pointer already resident in device memory (HBM). Asynchronous on the
- * context's stream; call fh_sync() before reading results. */
-int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n,
-                          fh_result* d_results);
+ * context's stream; call fh_sync() before reading results.  max_seg / max_faces are upper bounds on
+ * n_seg and on the per-problem face count of the batch (they select the kernel instantiation and its
+ * LDS carve; pass 0 for the library maxima FH_MAX_SEG / FH_MAX_FACES).  A problem exceeding them is
+ * reported with FH_ST_BAD_INPUT. */
+int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n, int max_seg,
+                          int max_faces, fh_result* d_results);
 
 /* resetX()+fillX() (solverGurobi.cpp:382-388, :122-168) for a batch: problem i writes
  * counts[i] = max(2,(int)(N*dt/DC)) states to states[i*max_samples ...]; if counts[i] > max_samples
@@ -138,12 +141,17 @@ int fh_sample_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_r
                            int max_samples, fh_state* d_states, int32_t* d_counts);
 
 /* Whole -> safe hand-off of Faster::replan (faster/src/faster.cpp:456-475, :506-524) for synthetic
- * pairs: for pair i take R = sample number (int)(r_frac*count_i) of the whole
- * trajectory (fillX semantics) as x0 of safe problem i (pos, vel, accel); everything else in
- * d_safe[i] is left as the caller prepared it. Unsolved whole problems mark the safe problem with
- * n_seg = 0 (skipped, result status FH_ST_BAD_INPUT). Device pointers, asynchronous. */
-int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, int n,
-                        double r_frac, fh_problem* d_safe);
+ * pairs, entirely on the device: for pair i take R = sample number
+ * (int)(r_frac*count_i) of the whole trajectory (fillX semantics) as x0 of safe problem i (pos, vel,
+ * accel).  The safe corridor is the run of up to max_safe_poly consecutive polytopes of the whole
+ * corridor starting at the first one that (shrunk by `shrink` metres) contains R; its faces are written
+ * to d_safe_faces at the SAME face_begin as the whole problem (d_safe_faces must be as large as
+ * d_faces).  Everything else in d_safe[i] (n_seg, bounds, dc, factor window, force_final_pos, xf) is left
+ * as the caller prepared it.  Unsolved whole problems mark the safe problem with n_seg = 0 (skipped:
+ * its result reports FH_ST_BAD_INPUT).  Device pointers, asynchronous on the context stream. */
+int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results,
+                        const fh_face* d_faces, int n, double r_frac, double shrink, int max_safe_poly,
+                        fh_problem* d_safe, fh_face* d_safe_faces);
 
 int fh_sync(fh_ctx* ctx);
 

@@ -639,13 +639,14 @@ static void coeff_from_x(const fh_problem* pr, double h, const double* x, double
 
 static int bad_input(const fh_problem* pr) {
   if (pr->n_seg < 1 || pr->n_seg > FH_MAX_SEG || pr->n_poly < 0 || pr->n_poly > FH_MAX_POLY) return 1;
-  if (pr->face_off[0] != 0) return 1;
+  if (pr->face_off[0] != 0 || pr->face_begin < 0) return 1;
   for (int p = 0; p < pr->n_poly; p++) {
     int c = pr->face_off[p + 1] - pr->face_off[p];
     if (c < 0 || c > FH_MAX_FACES_POLY) return 1;
   }
   if (pr->n_poly && pr->face_off[pr->n_poly] > FH_MAX_FACES) return 1;
   if (!(pr->f_inc > 0) || !isfinite(pr->f_init) || !isfinite(pr->f_final)) return 1;
+  if ((pr->f_final - pr->f_init) / pr->f_inc > 4096.0) return 1; /* FH_MAX_TRIALS */
   if (!(pr->dc > 0) || !(pr->v_max > 0) || !(pr->a_max > 0) || !(pr->j_max > 0)) return 1;
   for (int i = 0; i < 9; i++)
     if (!isfinite(pr->x0[i]) || !isfinite(pr->xf[i])) return 1;
