@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — whole+safe trajectory solves per second on MI355X (BASELINE.json metric, config C4).
+
+One "step" = one pass of the hot path over one batch of synthetic corridor problems:
+    whole-trajectory solve (genNewTraj, N=10, <=6 polytopes)  ->  device-side whole->safe hand-off
+    (R = mid sample of the whole trajectory, safe corridor = <=3 shrunk polytopes)  ->  safe-trajectory solve.
+Inputs are resident in HBM before the timed region.  Each rank owns its own batch (independent problems,
+weak scaling, no data-path collective); with N>1 ranks the per-pair result summaries are all-gathered over
+RCCL after each step (the "batch gather" of SURVEY.md §8(e)).
+
+Usage (driver contract):  python bench.py --gpus N --steps K --warmup W
+N>1 is launched by torch.distributed.run (one rank per GPU).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
+
+
+def algorithmic_bytes(problems, n_seg_out):
+    """compulsory reads (scalars 56 B + x0/xf 144 B + 32 B per face) and writes
+    (96 B per segment of coefficients + 32 B cost/dt/factor/flags + 1 B per segment assignment)."""
+    nf = problems["face_off"][np.arange(len(problems)), np.clip(problems["n_poly"], 0, 8)].astype(np.int64)
+    reads = 200 * len(problems) + 32 * int(nf.sum())
+    writes = len(problems) * (96 * n_seg_out + 32 + n_seg_out)
+    return reads + writes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=32768, help="whole+safe pairs per rank per step (C4: 32768)")
+    ap.add_argument("--n-seg", type=int, default=10)
+    ap.add_argument("--max-poly", type=int, default=6)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from faster_amd import abi, capi, corridor
+
+    B, N = args.pairs, args.n_seg
+    whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(2, args.max_poly + 1)))
+    safe_t = corridor.safe_templates(whole)
+    max_faces = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    d_whole, d_faces, d_safe = to_dev(whole), to_dev(faces), to_dev(safe_t)
+    d_sfaces = torch.zeros_like(d_faces)
+    d_wres = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+    d_sres = torch.zeros_like(d_wres)
+
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    res_words = abi.result_dtype.itemsize // 8
+    gather_out = torch.zeros((world, B, 2), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        ctx.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, d_wres.data_ptr())
+        ctx.pair_glue_device(d_whole.data_ptr(), d_wres.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, d_safe.data_ptr(),
+                             d_sfaces.data_ptr())
+        ctx.solve_batch_device(d_safe.data_ptr(), d_sfaces.data_ptr(), B, N, max_faces, d_sres.data_ptr())
+        if world > 1:  # batch gather of the per-pair summaries (safe cost, whole cost) over RCCL/xGMI
+            sw = d_sres.view(torch.float64).view(B, res_words)[:, 5]
+            ww = d_wres.view(torch.float64).view(B, res_words)[:, 5]
+            dist.all_gather_into_tensor(gather_out.view(world * B, 2), torch.stack([ww, sw], dim=1))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = ctx.timing_read()
+    wres = d_wres.cpu().numpy().view(abi.result_dtype)
+    sres = d_sres.cpu().numpy().view(abi.result_dtype)
+    safe_h = d_safe.cpu().numpy().view(abi.problem_dtype)
+    sfaces_h = d_sfaces.cpu().numpy().view(abi.face_dtype)
+
+    if rank == 0:
+        pairs_total = world * B * args.steps
+        value = pairs_total / elapsed
+        # roofline of the dominant kernel (solve_kernel<10>, two launches per step: whole, safe)
+        bytes_whole = algorithmic_bytes(whole, N)
+        active = safe_h["n_seg"] > 0
+        bytes_safe = algorithmic_bytes(safe_h[active], N) + 24 * int((~active).sum())
+        bytes_per_launch = 0.5 * (bytes_whole + bytes_safe)
+        avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9  # GB/s
+        out = {
+            "metric": "trajectory solves/sec (whole+safe pairs) at N=%d, deg=3" % N,
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "C4: %d whole+safe paired solves per GPU per step (N=%d segments, deg=3, <=%d polytopes whole / <=3 safe), "
+                            "synthetic corridors (faster_amd/corridor.py seed 3)" % (B, N, args.max_poly),
+                "pairs_per_gpu": B,
+                "parallelism": "batch-sharded x%d, RCCL all_gather of result summaries" % world if world > 1 else "single GPU",
+                "whole_solved_frac": float(wres["solved"].mean()),
+                "safe_solved_frac": float(sres["solved"].mean()),
+                "mean_bnb_nodes_whole": float(wres["nodes"].mean()),
+                "mean_bnb_nodes_safe": float(sres["nodes"].mean()),
+                "mean_qp_iters_per_pair": float(wres["qp_iters"].mean() + sres["qp_iters"].mean()),
+                "mean_trials_per_pair": float(wres["trials"].mean() + sres["trials"].mean()),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fh::solve_kernel<10>",
+                "achieved": achieved,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK / 1e9),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": avg_ms,
+                "launches_timed": int(len(kernel_ms)),
+                "note": "latency/FP64-ALU bound by construction (SURVEY.md 8(d)): ~4-7 KB compulsory HBM bytes per pair",
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(whole, faces, safe_h, sfaces_h, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(whole, faces, safe, sfaces, target_s):
+    """The CPU oracle (oracle/faster_oracle.c, kind "port": Gurobi is absent) timed on a bounded sample of the SAME
+    pairs, all host cores via OpenMP.  Reported baseline only."""
+    from oracle import oracle as orc
+
+    orc.build()
+    cores = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+
+    def run(k):
+        t = time.perf_counter()
+        orc.solve_batch(whole[:k], faces)
+        act = safe[:k][safe[:k]["n_seg"] > 0]
+        if len(act):
+            orc.solve_batch(act, sfaces)
+        return time.perf_counter() - t
+
+    pilot = min(256, len(whole))
+    tp = run(pilot)
+    k = int(min(len(whole), max(pilot, pilot * target_s / max(tp, 1e-6))))
+    tk = run(k)
+    return {"value": k / tk, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "first %d of the %d pairs of rank 0 (whole + safe solves), CPU restatement oracle/faster_oracle.c "
+                      "with OpenMP over problems; NOT Gurobi (absent)" % (k, len(whole)),
+            "seconds": tk}
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ SO_PATH = os.path.join(_HERE, "libfasterhip.so")
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
     "fh_solve_batch", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device",
-    "fh_sync", "fh_last_kernel_ms", "fh_version",
+    "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
 
 _LIB = None
@@ -58,6 +58,10 @@ def lib():
         L.fh_pair_glue_device.argtypes = [vp, vp, vp, vp, i32, f64, f64, i32, vp, vp]
         L.fh_sync.restype = i32
         L.fh_sync.argtypes = [vp]
+        L.fh_timing_reset.restype = i32
+        L.fh_timing_reset.argtypes = [vp]
+        L.fh_timing_read.restype = i32
+        L.fh_timing_read.argtypes = [vp, vp, i32]
         L.fh_last_kernel_ms.restype = f64
         L.fh_last_kernel_ms.argtypes = [vp]
         L.fh_version.restype = ctypes.c_char_p
@@ -102,6 +106,17 @@ class Context:
 
     def sync(self):
         self._check(lib().fh_sync(self._h), "fh_sync")
+
+    def timing_reset(self):
+        self._check(lib().fh_timing_reset(self._h), "fh_timing_reset")
+
+    def timing_read(self, cap=4096):
+        """Durations (ms) of the solve-kernel launches since timing_reset(), from HIP events on the stream."""
+        ms = np.zeros(cap, dtype=np.float64)
+        cnt = lib().fh_timing_read(self._h, abi.ptr(ms), cap)
+        if cnt < 0:
+            self._check(cnt, "fh_timing_read")
+        return ms[: min(cnt, cap)]
 
     def last_kernel_ms(self):
         return lib().fh_last_kernel_ms(self._h)

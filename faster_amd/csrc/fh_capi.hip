@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/fasterhip.h"
 #include "fh_sample.hip.hpp"
@@ -17,8 +18,8 @@ struct fh_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool have_timing = false;
+  std::vector<hipEvent_t> ev;  // pairs (start, stop), one pair per solve-kernel launch
+  size_t ev_used = 0;          // events in use since the last fh_timing_reset
   fh_params par;
   std::string err;
   // staging buffers of the host-pointer entry points (grown on demand, reused)
@@ -52,11 +53,21 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   const size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
   auto kern = fh::solve_kernel<NSEG>;
   FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  FH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->ev_used + 2 > ctx->ev.size()) {
+    if (ctx->ev.size() >= 8192) ctx->ev_used = 0;  // ring: keep the most recent launches only
+    else
+      for (int k = 0; k < 2; k++) {
+        hipEvent_t e;
+        FH_HIP(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+      }
+  }
+  hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
+  FH_HIP(hipEventRecord(e0, ctx->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, ctx->stream, d_problems, d_faces, n, max_faces, ctx->par, d_results);
   FH_HIP(hipGetLastError());
-  FH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-  ctx->have_timing = true;
+  FH_HIP(hipEventRecord(e1, ctx->stream));
+  ctx->ev_used += 2;
   return FH_OK;
 }
 
@@ -100,8 +111,6 @@ int fh_create(fh_ctx** out, int device) {
   FH_HIP(hipGetDevice(&ctx->device));
   FH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
-  FH_HIP(hipEventCreate(&ctx->ev0));
-  FH_HIP(hipEventCreate(&ctx->ev1));
   return FH_OK;
 }
 
@@ -110,8 +119,7 @@ void fh_destroy(fh_ctx* ctx) {
   if (ctx->device >= 0) {
     for (int i = 0; i < 6; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   }
   delete ctx;
@@ -240,11 +248,31 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
   return FH_OK;
 }
 
+int fh_timing_reset(fh_ctx* ctx) {
+  if (!ctx) return FH_ERR_ARG;
+  ctx->ev_used = 0;
+  return FH_OK;
+}
+
+int fh_timing_read(fh_ctx* ctx, double* ms, int cap) {
+  if (!ctx || cap < 0 || (cap > 0 && !ms)) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  const int count = (int)(ctx->ev_used / 2);
+  if (count == 0) return 0;
+  FH_HIP(hipEventSynchronize(ctx->ev[ctx->ev_used - 1]));
+  for (int i = 0; i < count && i < cap; i++) {
+    float t = 0.f;
+    FH_HIP(hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+    ms[i] = (double)t;
+  }
+  return count;
+}
+
 double fh_last_kernel_ms(fh_ctx* ctx) {
-  if (!ctx || ctx->device < 0 || !ctx->have_timing) return -1.0;
-  if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+  if (!ctx || ctx->device < 0 || ctx->ev_used < 2) return -1.0;
+  if (hipEventSynchronize(ctx->ev[ctx->ev_used - 1]) != hipSuccess) return -1.0;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, ctx->ev[ctx->ev_used - 2], ctx->ev[ctx->ev_used - 1]) != hipSuccess) return -1.0;
   return (double)ms;
 }
 

@@ -173,16 +173,17 @@ struct Solver {
   double* fnorm;                                      // [n_faces] |a_f|
   fh_face* faces;                                     // [n_faces]
   unsigned long long* polyact;                        // [NSEG][4] active-row bit per face
-  int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_order, *face_off;
+  int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_order, *face_off;
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
     return sizeof(double) * (2 * NV * S + 8 * NV + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + NSEG * FH_MAX_POLY + max_faces) +
            sizeof(fh_face) * max_faces + sizeof(unsigned long long) * NSEG * 4 +
-           sizeof(int) * (2 * NV + 5 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 2) + 64;
+           sizeof(int) * (2 * NV + 6 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 2) + 64;
   }
 
   // ---- wave-uniform scalars ----
   int lane, N, n, q, P;
+  unsigned allowed_first, allowed_last;  // polytopes not excluded for segment 0 / N-1 by jerk-independent rows
   double h, tol, dep2;
   double vmax, amax, jmax;
   int force_final;
@@ -206,7 +207,7 @@ struct Solver {
     int* ip = reinterpret_cast<int*>(p);
     act = ip; ip += NV;  boxact = ip; ip += NV;
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
-    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_order = ip; ip += NSEG * FH_MAX_POLY;
+    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_order = ip; ip += NSEG * FH_MAX_POLY;
     face_off = ip; ip += FH_MAX_POLY + 1;
   }
 
@@ -544,6 +545,45 @@ struct Solver {
     }
   }
 
+  __device__ __forceinline__ unsigned allowed_mask(int t) const {
+    unsigned m = P ? ((1u << P) - 1u) : 0u;
+    if (t == 0) m &= allowed_first;
+    if (t == N - 1) m &= allowed_last;
+    return m;
+  }
+
+  // ---- exact screening on jerk-independent indicator rows (same rule as the oracle's screen_constant_rows):
+  // control points 0..2 of segment 0 depend on x0 and h only; with the final position forced, control points
+  // 1..3 of the last segment depend on xf and h only.  One lane per polytope. ----
+  __device__ void screen_constant_rows(const fh_problem& pr) {
+    allowed_first = allowed_last = 0xffffffffu;
+    if (P == 0) return;
+    bool ok0 = false, okN = false;
+    if (lane < P) {
+      double w0 = -INFINITY, wN = -INFINITY;
+      const int f0 = face_off[lane], f1 = face_off[lane + 1];
+      for (int k = 0; k < 3; k++) {
+        double c0[3], cN[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const double p0 = pr.x0[i], v0 = pr.x0[3 + i], a0 = pr.x0[6 + i];
+          const double pf = xf9[i], vf = xf9[3 + i], af = xf9[6 + i];
+          c0[i] = k == 0 ? p0 : (k == 1 ? p0 + v0 * (h / 3.0) : p0 + v0 * (2.0 * h / 3.0) + a0 * (h * h / 6.0));
+          cN[i] = k == 0 ? pf : (k == 1 ? pf - vf * (h / 3.0) : pf - vf * (2.0 * h / 3.0) + af * (h * h / 6.0));
+        }
+        for (int f = f0; f < f1; f++) {
+          const fh_face fc = faces[f];
+          w0 = fmax(w0, fc.a[0] * c0[0] + fc.a[1] * c0[1] + fc.a[2] * c0[2] - fc.b);
+          wN = fmax(wN, fc.a[0] * cN[0] + fc.a[1] * cN[1] + fc.a[2] * cN[2] - fc.b);
+        }
+      }
+      ok0 = !(w0 > tol);
+      okN = !(wN > tol);
+    }
+    allowed_first = (unsigned)__ballot(ok0);
+    if (force_final) allowed_last = (unsigned)__ballot(okN);
+  }
+
   // ---- leaf test / branching choice for the node just solved. returns branch segment or -1 (leaf) ----
   __device__ int analyze(const fh_problem& pr) {
     if (P == 0) {
@@ -554,7 +594,8 @@ struct Solver {
     for (int pair = lane; pair < N * P; pair += 64) {
       const int t = pair / P, p = pair - t * P;
       double worst = -INFINITY;
-      if (assign[t] < 0) {
+      if (assign[t] < 0 && !((allowed_mask(t) >> p) & 1u)) worst = INFINITY;
+      else if (assign[t] < 0) {
         const int f0 = face_off[p], f1 = face_off[p + 1];
         for (int k = 0; k < 4; k++) {
           const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
@@ -596,6 +637,17 @@ struct Solver {
     bool x0bad = false;
     for (int i = 0; i < 3; i++) x0bad |= (fabs(pr.x0[3 + i]) - vmax > tol) || (fabs(pr.x0[6 + i]) - amax > tol);
     if (x0bad) return FH_ST_INFEASIBLE;
+    screen_constant_rows(pr);
+    if (P > 0) {
+      if (allowed_mask(0) == 0u || allowed_mask(N - 1) == 0u) return FH_ST_INFEASIBLE;
+      FH_SYNC();
+      if (lane == 0) {  // a segment with exactly one candidate polytope is not a decision
+        const unsigned m0 = allowed_mask(0), mN = allowed_mask(N - 1);
+        if ((m0 & (m0 - 1u)) == 0u) assign[0] = __builtin_ctz(m0);
+        if ((mN & (mN - 1u)) == 0u) assign[N - 1] = __builtin_ctz(mN);
+      }
+      FH_SYNC();
+    }
     reset_qp();
     int eq_next = 0;
     bool have_node = true;  // a node is ready to be solved (assign[] set, QP state prepared)
@@ -619,8 +671,12 @@ struct Solver {
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
           if (lane == 0) {
             int* ord = &stk_order[depth * FH_MAX_POLY];
-            for (int p = 0; p < P; p++) ord[p] = p;
-            for (int a = 1; a < P; a++)
+            const unsigned am = allowed_mask(bseg);
+            int cnt = 0;
+            for (int p = 0; p < P; p++)
+              if ((am >> p) & 1u) ord[cnt++] = p;
+            stk_cnt[depth] = cnt;
+            for (int a = 1; a < cnt; a++)
               for (int b = a; b > 0 && viol[bseg * FH_MAX_POLY + ord[b]] < viol[bseg * FH_MAX_POLY + ord[b - 1]]; b--) {
                 const int tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp;
               }
@@ -640,7 +696,7 @@ struct Solver {
         const int d_ = depth - 1;
         const int nx = stk_next[d_];
         const int seg = stk_seg[d_];
-        if (nx < P) {
+        if (nx < stk_cnt[d_]) {
           FH_SYNC();
           if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
           FH_SYNC();

@@ -155,8 +155,13 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
 
 int fh_sync(fh_ctx* ctx);
 
-/* Timing of the last fh_solve_batch_device launch on the context stream, measured with HIP
- * events recorded around the solve kernel (ms); <0 if unavailable. Synchronises. */
+/* Timing of the solve kernel, measured with HIP events recorded around every solve-kernel launch on
+ * the context stream (the same stream the kernel runs on).  fh_timing_reset() forgets recorded launches;
+ * fh_timing_read() synchronises with the last recorded launch and writes the duration (ms) of up to
+ * `cap` launches recorded since the reset, oldest first; returns the number recorded (may exceed cap)
+ * or <0 on error.  fh_last_kernel_ms() is the duration of the most recent launch (<0 if none). */
+int fh_timing_reset(fh_ctx* ctx);
+int fh_timing_read(fh_ctx* ctx, double* ms, int cap);
 double fh_last_kernel_ms(fh_ctx* ctx);
 
 /* library / build identification, e.g. "fasterhip 0.1 gfx950" */

@@ -519,7 +519,45 @@ typedef struct {
   double best_x[NV_MAX];
   int8_t best_assign[FH_MAX_SEG];
   int nodes, iters, limit;
+  unsigned allowed[FH_MAX_SEG]; /* bit p set: polytope p is not excluded for segment t by jerk-independent rows */
 } bnb_ctx;
+
+/* Exact screening on jerk-independent indicator rows.  Control points 0..2 of segment 0 are functions of x0
+ * and h only; with the final position forced, control points 1..3 of the last segment are functions of xf
+ * and h only (cp3 = pf, cp2 = pf - vf h/3, cp1 = pf - 2 vf h/3 + af h^2/6).  A polytope that does not hold them
+ * can never be chosen for that segment (b[t][p] = 1 would violate its indicator rows, :283-286). */
+static void screen_constant_rows(bnb_ctx* B) {
+  const orc_model* M = &B->M;
+  const fh_problem* pr = M->pr;
+  const double h = M->h, tol = M->par.feas_tol;
+  const int N = M->N;
+  for (int t = 0; t < N; t++) B->allowed[t] = pr->n_poly ? ((1u << pr->n_poly) - 1u) : 0u;
+  if (!pr->n_poly) return;
+  double cp[2][3][3];
+  for (int i = 0; i < 3; i++) {
+    const double p0 = pr->x0[i], v0 = pr->x0[3 + i], a0 = pr->x0[6 + i];
+    cp[0][0][i] = p0;
+    cp[0][1][i] = p0 + v0 * (h / 3.0);
+    cp[0][2][i] = p0 + v0 * (2.0 * h / 3.0) + a0 * (h * h / 6.0);
+    const double pf = pr->xf[i], vf = pr->xf[3 + i], af = pr->xf[6 + i];
+    cp[1][0][i] = pf;
+    cp[1][1][i] = pf - vf * (h / 3.0);
+    cp[1][2][i] = pf - vf * (2.0 * h / 3.0) + af * (h * h / 6.0);
+  }
+  for (int e = 0; e < (pr->force_final_pos ? 2 : 1); e++) {
+    const int t = e ? N - 1 : 0;
+    for (int p = 0; p < pr->n_poly; p++) {
+      double worst = -INFINITY;
+      for (int f = pr->face_off[p]; f < pr->face_off[p + 1]; f++)
+        for (int k = 0; k < 3; k++) {
+          const fh_face* F = &M->faces[f];
+          const double v = F->a[0] * cp[e][k][0] + F->a[1] * cp[e][k][1] + F->a[2] * cp[e][k][2] - F->b;
+          if (v > worst) worst = v;
+        }
+      if (worst > tol) B->allowed[t] &= ~(1u << p);
+    }
+  }
+}
 
 static void bnb_node(bnb_ctx* B, int8_t* assign) {
   const orc_model* M = &B->M;
@@ -553,7 +591,7 @@ static void bnb_node(bnb_ctx* B, int8_t* assign) {
     double mn = INFINITY;
     int arg = 0;
     for (int p = 0; p < pr->n_poly; p++) {
-      viol[p] = seg_poly_violation(M, P, V, A, t, p);
+      viol[p] = ((B->allowed[t] >> p) & 1u) ? seg_poly_violation(M, P, V, A, t, p) : INFINITY;
       if (viol[p] < mn) {
         mn = viol[p];
         arg = p;
@@ -584,6 +622,7 @@ static void bnb_node(bnb_ctx* B, int8_t* assign) {
       order[b - 1] = tmp;
     }
   for (int c = 0; c < pr->n_poly; c++) {
+    if (!((B->allowed[bseg] >> order[c]) & 1u)) continue;
     assign[bseg] = (int8_t)order[c];
     bnb_node(B, assign);
   }
@@ -608,7 +647,20 @@ static int miqp_bnb(const fh_problem* pr, const fh_face* faces, const fh_params*
   B.limit = 0;
   int8_t assign[FH_MAX_SEG];
   for (int t = 0; t < FH_MAX_SEG; t++) assign[t] = fixed_assign ? fixed_assign[t] : -1;
-  bnb_node(&B, assign);
+  screen_constant_rows(&B);
+  int screened_out = 0;
+  for (int t = 0; t < pr->n_seg && pr->n_poly; t++) {
+    if (assign[t] >= 0) {
+      if (assign[t] >= pr->n_poly || !((B.allowed[t] >> assign[t]) & 1u)) screened_out = 1;
+    } else if (B.allowed[t] == 0u) {
+      screened_out = 1;
+    } else if ((B.allowed[t] & (B.allowed[t] - 1u)) == 0u) { /* exactly one candidate: not a decision */
+      int p = 0;
+      while (!((B.allowed[t] >> p) & 1u)) p++;
+      assign[t] = (int8_t)p;
+    }
+  }
+  if (!screened_out) bnb_node(&B, assign);
   free(B.eq);
   free(B.in);
   *nodes += B.nodes;

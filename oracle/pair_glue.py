@@ -1,0 +1,52 @@
+"""Host restatement of fh_pair_glue_device (whole -> safe hand-off for synthetic pairs).  TEST INFRASTRUCTURE ONLY.
+
+Mirrors the data dependency of Faster::replan (faster/src/faster.cpp:456-475: R = X_whole[k]; :506-524: the safe
+solver starts from R) for the synthetic pairing of SURVEY.md §8(d) C4.  Uses oracle.sample (fillX semantics)."""
+import numpy as np
+
+from faster_amd import abi
+from . import oracle
+
+
+def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_poly=3):
+    safe = safe_templates.copy()
+    sfaces = np.zeros_like(faces)
+    for i in range(len(whole)):
+        pw, rw = whole[i], wres[i]
+        if not rw["solved"]:
+            safe["n_seg"][i] = 0
+            continue
+        X = oracle.sample(pw, rw)
+        size = X.shape[0]
+        k = min(max(int(r_frac * size), 0), size - 1)
+        R = X[k]
+        safe["x0"][i, 0:3], safe["x0"][i, 3:6], safe["x0"][i, 6:9] = R["pos"], R["vel"], R["accel"]
+        P = int(pw["n_poly"])
+        fb = int(pw["face_begin"])
+        start, best, found = 0, np.inf, False
+        for p in range(P):
+            f0, f1 = fb + pw["face_off"][p], fb + pw["face_off"][p + 1]
+            A, b = faces["a"][f0:f1], faces["b"][f0:f1]
+            nr = np.sqrt((A * A).sum(axis=1))
+            worst = np.max(A @ R["pos"] - (b - shrink * nr)) if f1 > f0 else -np.inf
+            if worst <= 0:
+                start, found = p, True
+                break
+            if worst < best:
+                best, start = worst, p
+        cnt = min(P - start, max_safe_poly) if P else 0
+        safe["n_poly"][i] = cnt
+        safe["face_begin"][i] = fb
+        o = 0
+        off = [0]
+        for p in range(cnt):
+            f0, f1 = fb + pw["face_off"][start + p], fb + pw["face_off"][start + p + 1]
+            m = f1 - f0
+            sfaces["a"][fb + o: fb + o + m] = faces["a"][f0:f1]
+            nr = np.sqrt((faces["a"][f0:f1] ** 2).sum(axis=1))
+            sfaces["b"][fb + o: fb + o + m] = faces["b"][f0:f1] - shrink * nr
+            o += m
+            off.append(o)
+        off += [o] * (abi.FH_MAX_POLY + 1 - len(off))
+        safe["face_off"][i] = off
+    return safe, sfaces

@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctx():
+    # PyTorch-ROCm bundles its own HIP runtime: when a process uses both, torch must be imported BEFORE
+    # libfasterhip.so is loaded so that both share one runtime.
+    import torch  # noqa: F401
+
     from faster_amd import capi
 
     c = capi.Context(0)
@@ -123,3 +127,57 @@ def test_sampling_parity(ctx, oracle):
             np.testing.assert_allclose(states[i, :m][fld], ref[:m][fld], rtol=0, atol=1e-11)
         if m:
             assert np.all(states[i, m - 1]["vel"] == 0) and np.all(states[i, m - 1]["jerk"] == 0)
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")
+
+
+def test_pair_pipeline_device_pointers(ctx, oracle):
+    """C4 pipeline with device-resident buffers: whole solve -> fh_pair_glue_device -> safe solve, against the
+    oracle driven through the host restatement of the hand-off (oracle/pair_glue.py)."""
+    import torch
+
+    from oracle import pair_glue
+
+    n, N = 384, 10
+    whole, faces, _ = corridor.whole_batch(n, seed=3, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    tmpl = corridor.safe_templates(whole)
+    max_faces = int(whole["face_off"][np.arange(n), whole["n_poly"]].max())
+    d_whole, d_faces, d_safe = _dev(whole), _dev(faces), _dev(tmpl)
+    d_sfaces = torch.zeros_like(d_faces)
+    d_wres = torch.zeros(n * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_sres = torch.zeros_like(d_wres)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.timing_reset()
+    ctx.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), n, N, max_faces, d_wres.data_ptr())
+    ctx.pair_glue_device(d_whole.data_ptr(), d_wres.data_ptr(), d_faces.data_ptr(), n, 0.5, 0.2, 3, d_safe.data_ptr(), d_sfaces.data_ptr())
+    ctx.solve_batch_device(d_safe.data_ptr(), d_sfaces.data_ptr(), n, N, max_faces, d_sres.data_ptr())
+    ctx.sync()
+    assert len(ctx.timing_read()) == 2 and ctx.last_kernel_ms() > 0
+    ctx.set_stream(0)
+    wres = d_wres.cpu().numpy().view(abi.result_dtype)
+    sres = d_sres.cpu().numpy().view(abi.result_dtype)
+    safe = d_safe.cpu().numpy().view(abi.problem_dtype)
+    sfaces = d_sfaces.cpu().numpy().view(abi.face_dtype)
+
+    wref = oracle.solve_batch(whole, faces)
+    compare(wres, wref)
+    # hand-off: same R, same corridor selection (inputs: the GPU's whole results, so that rounding cannot fork it)
+    safe_ref, sfaces_ref = pair_glue.glue(whole, wres, faces, tmpl, 0.5, 0.2, 3)
+    assert np.array_equal(safe["n_seg"], safe_ref["n_seg"])
+    assert np.array_equal(safe["n_poly"], safe_ref["n_poly"])
+    assert np.array_equal(safe["face_off"], safe_ref["face_off"])
+    np.testing.assert_allclose(safe["x0"], safe_ref["x0"], rtol=0, atol=1e-11)
+    live = safe["n_seg"] > 0
+    for i in np.nonzero(live)[0]:
+        f0 = safe["face_begin"][i]
+        f1 = f0 + safe["face_off"][i][safe["n_poly"][i]]
+        np.testing.assert_allclose(sfaces["a"][f0:f1], sfaces_ref["a"][f0:f1], rtol=0, atol=0)
+        np.testing.assert_allclose(sfaces["b"][f0:f1], sfaces_ref["b"][f0:f1], rtol=0, atol=1e-14)
+    sref = oracle.solve_batch(safe, sfaces)
+    compare(sres, sref)
+    check_assignment_valid(safe, sfaces, sres)
+    assert 0.3 < sres["solved"].mean() <= 1.0
