@@ -1,0 +1,49 @@
+"""Batch sharding across the GPUs of one node.
+
+Every genNewTraj() is independent, and a whole+safe pair never leaves its GPU, so the only communication is the
+gather of per-pair result summaries (RCCL all_gather over xGMI when the backend is "nccl"; gloo in CPU tests).
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous block partition: rank r owns [lo, hi) with ceil(n/world) items per rank (pairs are never split)."""
+    per = -(-n // world)
+    lo = min(rank * per, n)
+    hi = min(lo + per, n)
+    return lo, hi
+
+
+def shard_batch(problems, faces, rank, world):
+    """Slice a (problems, faces) batch for one rank, rebasing face_begin onto the rank-local face array."""
+    lo, hi = shard_range(len(problems), rank, world)
+    pr = problems[lo:hi].copy()
+    if hi == lo:
+        return pr, faces[:0].copy()
+    nf = pr["face_off"][np.arange(hi - lo), np.clip(pr["n_poly"], 0, pr["face_off"].shape[1] - 1)]
+    f_lo = int(pr["face_begin"].min())
+    f_hi = int((pr["face_begin"] + nf).max())
+    pr["face_begin"] -= f_lo
+    return pr, faces[f_lo:f_hi].copy()
+
+
+def summaries(results):
+    """[n, 4] float64: solved, factor, dt, cost — what rank 0 needs from every pair."""
+    out = np.zeros((len(results), 4), dtype=np.float64)
+    out[:, 0] = results["solved"]
+    out[:, 1] = results["factor"]
+    out[:, 2] = results["dt"]
+    out[:, 3] = results["cost"]
+    return out
+
+
+def all_gather_rows(dist, local, per_rank):
+    """all_gather of a [<=per_rank, k] tensor padded to per_rank rows; returns [world*per_rank, k]."""
+    import torch
+
+    world = dist.get_world_size()
+    pad = torch.zeros((per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.zeros((world * per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return out

@@ -1,0 +1,115 @@
+"""The C++ host class `SolverHip` (faster_amd/host/solver_hip.hpp) keeps the SolverGurobi surface
+(/root/reference/faster/include/solverGurobi.hpp:61-137) and is driven with the call sequence of
+Faster (faster/src/faster.cpp:52-71, :406-427, :521-537, :582-588) by tests/cpp/test_solver_hip.cpp."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from faster_amd import abi, corridor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_solver_hip")
+
+
+def build_driver():
+    from faster_amd import build as fb
+
+    fb.build_all()
+    src = os.path.join(ROOT, "tests", "cpp", "test_solver_hip.cpp")
+    deps = [src, fb.HOST_SO, os.path.join(ROOT, "faster_amd", "host", "solver_hip.hpp")]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "faster_amd", "host"),
+                               src, "-o", EXE, "-L", os.path.join(ROOT, "faster_amd"), "-lsolverhip", "-lfasterhip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
+    return EXE
+
+
+def parse(stdout):
+    """The class prints the reference's own console messages (e.g. StopExecution) on stdout: keep the JSON lines."""
+    return json.loads("\n".join(l for l in stdout.splitlines() if l[:1] in ('{', '}', '"')))
+
+
+def write_scenario(path, fx):
+    P = fx["polytopes"]
+    lines = ["10 6 0.01 5 3 5 1.0 1.0 20 20", " ".join(map(str, fx["x0"])), " ".join(map(str, fx["xf"][:3]))]
+
+    def polys(idx):
+        out = [str(len(idx))]
+        for p in idx:
+            out.append(str(len(P[p]["b"])))
+            for a, b in zip(P[p]["A"], P[p]["b"]):
+                out.append("%r %r %r %r" % (a[0], a[1], a[2], b))
+        return out
+
+    lines += polys([0, 1, 2])
+    lines.append("13 11.5 3")          # M: second vertex of decomp_test_node/data/path3d.txt
+    lines += polys([0])
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def test_host_class_compiles_and_links():
+    """CPU-side: the SolverGurobi-shaped class and its Faster-style driver compile and link against the C ABI."""
+    exe = build_driver()
+    assert os.path.exists(exe)
+    hdr = open(os.path.join(ROOT, "faster_amd", "host", "solver_hip.hpp")).read()
+    for name in ("setN", "setX0", "setXf", "resetX", "setBounds", "genNewTraj", "getDTInitial", "setDC", "setPolytopes", "fillX",
+                 "setForceFinalConstraint", "setWMax", "setMaxConstraints", "createVars", "setThreads", "setVerbose", "StopExecution",
+                 "ResetToNormalState", "setMode", "setFactorInitialAndFinalAndIncrement", "X_temp_", "dt_", "trials_", "temporal_",
+                 "runtime_ms_", "factor_that_worked_", "N_", "cb_"):
+        assert name in hdr, name
+
+
+def test_host_class_fails_loudly_without_gpu(tmp_path, fixture_corridor):
+    """No device => genNewTraj() returns false (never throws, never falls back to a CPU path)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = build_driver()
+    sc = tmp_path / "scenario.txt"
+    write_scenario(sc, fixture_corridor)
+    r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    out = parse(r.stdout)
+    assert out["whole"]["solved"] == 0 and out["safe"]["solved"] == 0
+    assert "no HIP device" in r.stderr or "device error" in r.stderr
+
+
+@pytest.mark.gpu
+def test_host_class_matches_oracle(tmp_path, oracle, fixture_corridor):
+    exe = build_driver()
+    sc = tmp_path / "scenario.txt"
+    write_scenario(sc, fixture_corridor)
+    r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = parse(r.stdout)
+    assert out["cancelled"] == {"ret": 0, "trials": 0, "flag_after": 0}
+    fx = fixture_corridor
+    # whole: SURVEY.md App. B anchor KA-1
+    pw, fw = corridor.fixture_problem(fx, 10, (5, 3, 5), True, [0, 1, 2], fx["x0"], fx["xf"])
+    rw = oracle.solve_batch(pw, fw)[0]
+    w = out["whole"]
+    assert w["solved"] == 1 and w["trials"] == rw["trials"] == 3 and w["factor"] == rw["factor"] == 3.0
+    assert w["dt"] == rw["dt"]
+    assert w["cost"] == pytest.approx(23.869158339522752, rel=1e-9)
+    Xw = oracle.sample(pw[0], rw)
+    assert w["n"] == Xw.shape[0]
+    np.testing.assert_allclose(w["first"][:3], Xw[0]["pos"], atol=1e-9)
+    np.testing.assert_allclose(w["last"][:3], Xw[-1]["pos"], atol=1e-7)
+    assert w["last"][3] == 0 and w["last"][5] == 0   # last sample: zero vel / jerk (solverGurobi.cpp:165-167)
+    # safe from R = X_whole[n/2]
+    R = Xw[Xw.shape[0] // 2]
+    np.testing.assert_allclose(out["R"], np.concatenate([R["pos"], R["vel"], R["accel"]]), atol=1e-7)
+    ps, fs = corridor.fixture_problem(fx, 6, (5, 3, 5), False, [0], out["R"], [13, 11.5, 3, 0, 0, 0, 0, 0, 0])
+    rs = oracle.solve_batch(ps, fs)[0]
+    s = out["safe"]
+    assert s["solved"] == rs["solved"] and s["trials"] == rs["trials"]
+    if rs["solved"]:
+        assert s["factor"] == rs["factor"] and s["cost"] == pytest.approx(rs["cost"], rel=1e-7, abs=1e-9)
+    # window update (faster.cpp:582-588): [max(3-20,1), 3+20] => same first feasible factor
+    assert out["window"] == [1.0, 23.0]
+    assert out["whole_again"]["solved"] == 1 and out["whole_again"]["factor"] == 3.0

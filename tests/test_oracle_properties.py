@@ -1,0 +1,149 @@
+"""Self-certification of the CPU oracle on synthetic corridors (the reference gives no expected outputs):
+exhaustive enumeration of all P^N assignments, an independent SciPy solve of the unreduced model, and invariances."""
+import numpy as np
+import pytest
+
+from faster_amd import abi, corridor
+
+
+def polys_of(pr, faces):
+    out = []
+    fb = int(pr["face_begin"])
+    for p in range(int(pr["n_poly"])):
+        f0, f1 = fb + pr["face_off"][p], fb + pr["face_off"][p + 1]
+        out.append((faces["a"][f0:f1].copy(), faces["b"][f0:f1].copy()))
+    return out
+
+
+def test_branch_and_bound_equals_exhaustive_enumeration(oracle):
+    """All P^N assignments (N=5, P<=3: up to 243 QPs per problem) vs. branch and bound, at the accepted dt and at the
+    last rejected dt (where every assignment must be infeasible)."""
+    pr, faces, _ = corridor.whole_batch(40, seed=101, n_seg=5, p_choices=(2, 3), speed=3.5, lateral=1.0)
+    res = oracle.solve_batch(pr, faces)
+    checked = 0
+    for i in range(len(pr)):
+        r = res[i]
+        if not r["solved"]:
+            continue
+        nfeas, bf = oracle.bruteforce_dt(pr[i], faces, r["dt"])
+        assert nfeas >= 1
+        assert bf["cost"] == pytest.approx(r["cost"], rel=1e-9, abs=1e-9)
+        np.testing.assert_allclose(bf["coeff"], r["coeff"], atol=1e-7)
+        if r["trials"] > 1:
+            dt_prev = (r["factor"] - pr[i]["f_inc"]) * (r["dt"] / r["factor"])
+            nprev, _ = oracle.bruteforce_dt(pr[i], faces, dt_prev)
+            assert nprev == 0
+        checked += 1
+    assert checked >= 20
+
+
+def test_safe_problems_equal_exhaustive_enumeration(oracle):
+    pr, faces, _ = corridor.safe_batch(30, seed=102, n_seg=5, p_choices=(2, 3), speed=3.0)
+    res = oracle.solve_batch(pr, faces)
+    assert res["solved"].mean() > 0.5
+    for i in np.nonzero(res["solved"])[0]:
+        nfeas, bf = oracle.bruteforce_dt(pr[i], faces, res[i]["dt"])
+        assert bf["cost"] == pytest.approx(res[i]["cost"], rel=1e-9, abs=1e-9)
+
+
+def test_scipy_unreduced_model_agrees_on_random_corridors(oracle):
+    """SLSQP on the 12N-coefficient model with the oracle's assignment must not find a better or different optimum."""
+    from oracle import py_model
+
+    pr, faces, _ = corridor.whole_batch(12, seed=103, n_seg=6, p_choices=(1, 2, 3))
+    res = oracle.solve_batch(pr, faces)
+    done = 0
+    for i in np.nonzero(res["solved"])[0][:8]:
+        p, r = pr[i], res[i]
+        N = int(p["n_seg"])
+        s = py_model.solve_fixed(N, float(r["dt"]), p["x0"], p["xf"], float(p["v_max"]), float(p["a_max"]), float(p["j_max"]),
+                                 bool(p["force_final_pos"]), polys_of(p, faces), [int(a) for a in r["assign"][:N]])
+        assert s is not None
+        assert s[0] == pytest.approx(r["cost"], rel=1e-7, abs=1e-8)
+        np.testing.assert_allclose(s[1], r["coeff"][:N], atol=5e-6)
+        done += 1
+    assert done >= 4
+
+
+def test_solution_satisfies_the_reference_model(oracle):
+    """Every reported trajectory satisfies the rows the reference adds (solverGurobi.cpp:332-407, :499-524, :237-289)."""
+    pr, faces, _ = corridor.whole_batch(64, seed=104, p_choices=(2, 3, 4, 5))
+    res = oracle.solve_batch(pr, faces)
+    for i in np.nonzero(res["solved"])[0]:
+        p, r = pr[i], res[i]
+        N, h = int(p["n_seg"]), float(r["dt"])
+        c = r["coeff"][:N]
+        a, b, cc, d = c[:, 0:3], c[:, 3:6], c[:, 6:9], c[:, 9:12]
+        pos_end = a * h**3 + b * h**2 + cc * h + d
+        vel_end = 3 * a * h**2 + 2 * b * h + cc
+        acc_end = 6 * a * h + 2 * b
+        np.testing.assert_allclose(d[0], p["x0"][0:3], atol=1e-12)
+        np.testing.assert_allclose(cc[0], p["x0"][3:6], atol=1e-12)
+        np.testing.assert_allclose(2 * b[0], p["x0"][6:9], atol=1e-12)
+        np.testing.assert_allclose(pos_end[:-1], d[1:], atol=1e-9)
+        np.testing.assert_allclose(vel_end[:-1], cc[1:], atol=1e-9)
+        np.testing.assert_allclose(acc_end[:-1], 2 * b[1:], atol=1e-9)
+        np.testing.assert_allclose(pos_end[-1], p["xf"][0:3], atol=1e-8)
+        np.testing.assert_allclose(vel_end[-1], 0, atol=1e-8)
+        np.testing.assert_allclose(acc_end[-1], 0, atol=1e-8)
+        assert np.all(np.abs(cc) <= p["v_max"] + 1e-8) and np.all(np.abs(2 * b) <= p["a_max"] + 1e-8)
+        assert np.all(np.abs(6 * a) <= p["j_max"] + 1e-8)
+        assert r["cost"] == pytest.approx(float(np.sum((6 * a) ** 2)), rel=1e-12)
+        fb = int(p["face_begin"])
+        for t in range(N):
+            q = int(r["assign"][t])
+            f0, f1 = fb + p["face_off"][q], fb + p["face_off"][q + 1]
+            for cp in (d[t], d[t] + cc[t] * h / 3, d[t] + 2 * cc[t] * h / 3 + b[t] * h * h / 3, pos_end[t]):
+                assert np.max(faces["a"][f0:f1] @ cp - faces["b"][f0:f1]) <= 1e-7
+
+
+def test_invariances(oracle):
+    """Translation of the whole scene, permutation and duplication of faces, and relabelling of polytopes leave
+    feasibility, factor and cost unchanged."""
+    pr, faces, _ = corridor.whole_batch(24, seed=105, p_choices=(2, 3))
+    base = oracle.solve_batch(pr, faces)
+    shift = np.array([3.25, -7.5, 0.0])
+    pr2, faces2 = pr.copy(), faces.copy()
+    pr2["x0"][:, 0:3] += shift
+    pr2["xf"][:, 0:3] += shift
+    faces2["b"] += faces2["a"] @ shift
+    r2 = oracle.solve_batch(pr2, faces2)
+    assert np.array_equal(r2["solved"], base["solved"]) and np.array_equal(r2["factor"], base["factor"])
+    np.testing.assert_allclose(r2["cost"], base["cost"], rtol=1e-7, atol=1e-9)
+    # reverse the face order inside every polytope and duplicate the first face
+    rng = np.random.default_rng(0)
+    batches = []
+    for i in range(len(pr)):
+        ps = polys_of(pr[i], faces)
+        new = []
+        for A, b in ps:
+            perm = rng.permutation(len(b))
+            new.append((np.vstack([A[perm], A[perm][:1]]), np.concatenate([b[perm], b[perm][:1]])))
+        new = new[::-1]  # relabel polytopes
+        f, off = abi.pack_faces(new)
+        q = pr[i: i + 1].copy()
+        q["face_begin"] = 0
+        q["face_off"][0, : len(off)] = off
+        q["face_off"][0, len(off):] = off[-1]
+        batches.append((q, f))
+    pr3, faces3 = corridor.concat(batches)
+    r3 = oracle.solve_batch(pr3, faces3)
+    assert np.array_equal(r3["solved"], base["solved"]) and np.array_equal(r3["factor"], base["factor"])
+    np.testing.assert_allclose(r3["cost"], base["cost"], rtol=1e-7, atol=1e-9)
+    # (the polytope index reported for a segment that fits several overlapping polytopes may legitimately differ)
+    np.testing.assert_allclose(r3["coeff"], base["coeff"], atol=1e-6)
+
+
+def test_cost_does_not_increase_with_more_time_in_free_space(oracle):
+    """Without a corridor the optimal jerk cost is non-increasing in dt (more time is never worse)."""
+    pr, faces, _ = corridor.whole_batch(8, seed=106)
+    pr = pr.copy()
+    pr["n_poly"] = 0
+    res = oracle.solve_batch(pr, faces)
+    for i in np.nonzero(res["solved"])[0]:
+        costs = []
+        for f in (1.0, 1.25, 1.5, 2.0):
+            st, r = oracle.miqp_dt(pr[i], faces, f * res[i]["dt"])
+            assert st == abi.FH_ST_OPTIMAL
+            costs.append(r["cost"])
+        assert all(a >= b - 1e-9 for a, b in zip(costs, costs[1:]))
