@@ -23,8 +23,9 @@ struct fh_ctx {
   fh_params par;
   std::string err;
   // staging buffers of the host-pointer entry points (grown on demand, reused)
-  void* d_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[6] = {0, 0, 0, 0, 0, 0};
+  void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int n_cu = 0;
 };
 
 #define FH_HIP(call)                                                                            \
@@ -52,6 +53,15 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
                         fh_result* d_results) {
   const size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
   auto kern = fh::solve_kernel<NSEG>;
+  // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU), never more than the batch
+  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  const int grid = std::min(n, ctx->n_cu * per_cu);
+  // slot 5: snapshot workspace (one slot per tree level per workgroup), slot 6: the work counter
+  int rc;
+  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_DOUBLES)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
+  FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 4, ctx->stream));
   FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ctx->ev_used + 2 > ctx->ev.size()) {
     if (ctx->ev.size() >= 8192) ctx->ev_used = 0;  // ring: keep the most recent launches only
@@ -64,7 +74,8 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   }
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(64), lds, ctx->stream, d_problems, d_faces, n, max_faces, ctx->par, d_results);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, n, max_faces, ctx->par,
+                     (double*)ctx->d_buf[5], (unsigned int*)ctx->d_buf[6], d_results);
   FH_HIP(hipGetLastError());
   FH_HIP(hipEventRecord(e1, ctx->stream));
   ctx->ev_used += 2;
@@ -109,6 +120,9 @@ int fh_create(fh_ctx** out, int device) {
   }
   *out = ctx;
   FH_HIP(hipGetDevice(&ctx->device));
+  hipDeviceProp_t prop;
+  FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   FH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
   return FH_OK;
@@ -117,7 +131,7 @@ int fh_create(fh_ctx** out, int device) {
 void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 8; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

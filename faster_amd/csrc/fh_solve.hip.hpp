@@ -160,25 +160,27 @@ __device__ inline double dt_initial(const fh_problem& pr) {
 template <int NSEG>
 struct Solver {
   static constexpr int NV = 3 * NSEG;
-  static constexpr int S = NV | 1;  // odd row stride: conflict-free column AND row sweeps with ds_read_b64
+  static constexpr int NVP = (NV + 7) & ~7;  // vectors / factor rows padded with zeros to a multiple of 8
+  static constexpr int S = NVP + 1;          // odd row stride: conflict-free column AND row sweeps with ds_read_b64
   static constexpr int NT = NSEG + 1;
 
   // ---- LDS carve (doubles first) ----
-  double *Q, *R;                                      // [NV][S]: Q1 (column c = active slot), R upper triangular
-  double *x, *z, *g, *d, *r, *u, *rinv, *bestx;       // [NV]
+  double *Q, *R;                                      // [NVP][S]: Q1 (column c = active slot), R upper triangular
+  double *x, *z, *g, *d, *r, *u, *rinv, *bestx;       // [NVP]
   double *P0, *V0, *A0, *Pc, *Vc, *Ac;                // [NT*3] jerk-free / current states at segment starts
   double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
   double* wn;                                         // [W_KINDS][NT] row-norm factors sqrt(sum_m wcoef^2)
   double* viol;                                       // [NSEG][FH_MAX_POLY]
+  double* xfl;                                        // [9] goal state (+3 pad)
   double* fnorm;                                      // [n_faces] |a_f|
   fh_face* faces;                                     // [n_faces]
   unsigned long long* polyact;                        // [NSEG][4] active-row bit per face
-  int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_order, *face_off;
+  int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_order, *face_off;
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (2 * NV * S + 8 * NV + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + NSEG * FH_MAX_POLY + max_faces) +
+    return sizeof(double) * (2 * NVP * S + 8 * NVP + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + NSEG * FH_MAX_POLY + 12 + max_faces) +
            sizeof(fh_face) * max_faces + sizeof(unsigned long long) * NSEG * 4 +
-           sizeof(int) * (2 * NV + 6 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 2) + 64;
+           sizeof(int) * (2 * NVP + 7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 2) + 64;
   }
 
   // ---- wave-uniform scalars ----
@@ -187,28 +189,59 @@ struct Solver {
   double h, tol, dep2;
   double vmax, amax, jmax;
   int force_final;
-  double xf9[9];
+
+  // The dual active-set state that a branch-and-bound node inherits is one contiguous LDS block, so that it can be
+  // snapshotted to / restored from the per-workgroup HBM workspace with linear 16-B-per-lane copies.
+  static constexpr int SNAP_DOUBLES = 2 * NVP * S + 3 * NVP + NSEG * 4 + NVP;  // Q, R, x, u, rinv, polyact, act+boxact
+  static_assert(SNAP_DOUBLES % 2 == 0, "snapshot is copied as double2");
 
   __device__ void carve(unsigned char* base, int max_faces) {
     double* p = reinterpret_cast<double*>(base);
-    Q = p; p += NV * S;
-    R = p; p += NV * S;
-    x = p; p += NV;  z = p; p += NV;  g = p; p += NV;  d = p; p += NV;
-    r = p; p += NV;  u = p; p += NV;  rinv = p; p += NV;  bestx = p; p += NV;
+    Q = p; p += NVP * S;
+    R = p; p += NVP * S;
+    x = p; p += NVP;  u = p; p += NVP;  rinv = p; p += NVP;
+    polyact = reinterpret_cast<unsigned long long*>(p); p += NSEG * 4;
+    act = reinterpret_cast<int*>(p); boxact = act + NVP; p += NVP;
+    // ---- end of the snapshot block ----
+    z = p; p += NVP;  g = p; p += NVP;  d = p; p += NVP;  r = p; p += NVP;  bestx = p; p += NVP;
     P0 = p; p += NT * 3;  V0 = p; p += NT * 3;  A0 = p; p += NT * 3;
     Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
     CP = p; p += NSEG * 12;
     wn = p; p += W_KINDS * NT;
     viol = p; p += NSEG * FH_MAX_POLY;
+    xfl = p; p += 12;
     fnorm = p; p += max_faces;
     if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) p += 1;  // faces are read 16 B at a time
     faces = reinterpret_cast<fh_face*>(p); p += 4 * max_faces;
-    polyact = reinterpret_cast<unsigned long long*>(p); p += NSEG * 4;
     int* ip = reinterpret_cast<int*>(p);
-    act = ip; ip += NV;  boxact = ip; ip += NV;
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
-    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_order = ip; ip += NSEG * FH_MAX_POLY;
+    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_q = ip; ip += NSEG;
+    stk_order = ip; ip += NSEG * FH_MAX_POLY;
     face_off = ip; ip += FH_MAX_POLY + 1;
+  }
+
+  // ---- node state snapshots (HBM workspace, one slot per tree level; L2-resident in practice) ----
+  __device__ void snapshot_save(double* __restrict__ ws_level) {
+    FH_SYNC();
+    const double2* src = reinterpret_cast<const double2*>(Q);
+    double2* dst = reinterpret_cast<double2*>(ws_level);
+    for (int i = lane; i < SNAP_DOUBLES / 2; i += 64) dst[i] = src[i];
+  }
+  __device__ void snapshot_restore(const double* __restrict__ ws_level) {
+    FH_SYNC();
+    double2* dst = reinterpret_cast<double2*>(Q);
+    const double2* src = reinterpret_cast<const double2*>(ws_level);
+    for (int i = lane; i < SNAP_DOUBLES / 2; i += 64) dst[i] = src[i];  // same lane <-> same words as the save
+    FH_SYNC();
+  }
+
+  // Invariant kept by reset_qp/add_row/drop_row: Q[i][c] == 0 for i >= n or c >= q, and g, d, z, x are zero
+  // beyond n (resp. q), so that the factor sweeps below can run in unpredicated blocks of 8.
+  __device__ void init_problem() {
+    for (int i = lane; i < NVP * S; i += 64) { Q[i] = 0.0; R[i] = 0.0; }
+    if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; r[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; boxact[lane] = 0; }
+    q = 0;
+    FH_SYNC();
   }
 
   // ---- per trial: jerk-free states and row-norm table for step h ----
@@ -239,11 +272,13 @@ struct Solver {
     if (lane < (N + 1) * 3) {
       const int tt = lane / 3, i = lane - 3 * tt;
       double p = P0[lane], v = V0[lane], a = A0[lane];
-      for (int s = 0; s < tt; s++) {
+      const double h2 = h * h, h3 = h2 * h;
+#pragma unroll
+      for (int s = 0; s < NSEG; s++) {  // all loads in flight at once; segments s >= tt contribute nothing
+        const double xs = (s < tt) ? x[3 * s + i] : 0.0;
         const double dm = (double)(tt - 1 - s);
-        const double xs = x[3 * s + i];
-        p += h * h * h * (1.0 / 6.0 + 0.5 * dm + 0.5 * dm * dm) * xs;
-        v += h * h * (0.5 + dm) * xs;
+        p += h3 * (1.0 / 6.0 + 0.5 * dm + 0.5 * dm * dm) * xs;
+        v += h2 * (0.5 + dm) * xs;
         a += h * xs;
       }
       Pc[lane] = p; Vc[lane] = v; Ac[lane] = a;
@@ -261,7 +296,9 @@ struct Solver {
   }
 
   // ---- most violated inactive inequality row; violation relative to the row norm. id<0: none. ----
-  // sets const_bad if a jerk-independent row (segment 0, control points 0..2) is violated.
+  // Box rows: lane = variable.  Corridor rows: lane = (segment, control point), sweeping the faces of the
+  // segment's polytope (4 lanes share each face read).  Sets const_bad if a jerk-independent row (segment 0,
+  // control points 0..2) is violated.
   __device__ void scan(int& id_out, double& v_out, bool& const_bad) {
     double bs = 0, bv = 0;
     int bid = -1;
@@ -287,17 +324,16 @@ struct Solver {
         if (v > tol && !(ba & 32) && v > bs * nA) { bs = v / nA; bv = v; bid = mk_id(K_ABOX, t, i, 1); }
       }
     }
-    const int k = lane & 3, fl = lane >> 2;
-    for (int t = 0; t < N; t++) {
+    if (lane < 4 * N) {
+      const int t = lane >> 2, k = lane & 3;
       const int p = assign[t];
-      if (p < 0) continue;
-      const int f0 = face_off[p], F = face_off[p + 1] - f0;
-      const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
-      const unsigned long long am = polyact[t * 4 + k];
-      const double w = wn[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
-      for (int fb = 0; fb < F; fb += 16) {
-        const int f = fb + fl;
-        if (f < F) {
+      if (p >= 0) {
+        const int f0 = face_off[p], F = face_off[p + 1] - f0;
+        const double c0 = CP[lane * 3 + 0], c1 = CP[lane * 3 + 1], c2 = CP[lane * 3 + 2];
+        const unsigned long long am = polyact[lane];
+        const double w = wn[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
+#pragma unroll 4
+        for (int f = 0; f < F; f++) {
           const fh_face fc = faces[f0 + f];
           const double v = fc.a[0] * c0 + fc.a[1] * c1 + fc.a[2] * c2 - fc.b;
           if (v > tol) {
@@ -349,50 +385,91 @@ struct Solver {
         const int m = tt - 1 - s;
         gv = (m >= 0) ? gi * wcoef(wk, m, h) : 0.0;
       }
-      g[lane] = gv;
     }
+    if (lane < NVP) g[lane] = gv;
     FH_SYNC();
     return wave_sum(gv * gv);
   }
 
-  // ---- z = (I - Q1 Q1^T) g with one re-orthogonalisation, d = Q1^T g (per-lane dc for lane<q). returns |z|^2 ----
-  __device__ double project(double& dc, double& zi) {
-    dc = 0;
-    if (lane < q)
-      for (int i = 0; i < n; i++) dc += Q[i * S + lane] * g[i];
-    if (lane < NV) d[lane] = dc;
-    FH_SYNC();
-    zi = 0;
-    if (lane < n) {
-      zi = g[lane];
-      for (int c = 0; c < q; c++) zi -= Q[lane * S + c] * d[c];
-      z[lane] = zi;
+  // column sweep: sum_i Q[i][col] * v[i] over the padded length n8 (two accumulators, 8 loads in flight)
+  __device__ __forceinline__ double col_dot(const double* __restrict__ M, int col, const double* __restrict__ v, int n8) const {
+    double a0 = 0, a1 = 0;
+    for (int i0 = 0; i0 < n8; i0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        a0 += M[(i0 + j) * S + col] * v[i0 + j];
+        a1 += M[(i0 + j + 1) * S + col] * v[i0 + j + 1];
+      }
     }
+    return a0 + a1;
+  }
+  // row sweep: sum_c Q[row][c] * v[c] over the padded length q8
+  __device__ __forceinline__ double row_dot(const double* __restrict__ M, int row, const double* __restrict__ v, int q8) const {
+    double a0 = 0, a1 = 0;
+    const double* Mr = M + row * S;
+    for (int c0 = 0; c0 < q8; c0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        a0 += Mr[c0 + j] * v[c0 + j];
+        a1 += Mr[c0 + j + 1] * v[c0 + j + 1];
+      }
+    }
+    return a0 + a1;
+  }
+
+  // ---- z = (I - Q1 Q1^T) g, d = Q1^T g (lane c holds d_c, lane i holds z_i). Re-orthogonalises when the first
+  // pass cancels more than half of |g|^2 (Daniel-Gragg-Kaufman-Stewart).  returns |z|^2 ----
+  __device__ double project(double gg, double& dc, double& zi) {
+    const int n8 = (n + 7) & ~7, q8 = (q + 7) & ~7;
+    const int ll = lane < NVP ? lane : NVP - 1;  // lanes beyond the padded size compute a harmless duplicate
+    dc = col_dot(Q, ll, g, n8);
+    if (lane < NVP) d[lane] = dc;
     FH_SYNC();
-    double ec = 0;
-    if (lane < q) {
-      for (int i = 0; i < n; i++) ec += Q[i * S + lane] * z[i];
+    zi = g[ll] - row_dot(Q, ll, d, q8);
+    if (lane >= NVP) zi = 0.0;
+    double zz = wave_sum(zi * zi);
+    if (zz < 0.5 * gg) {
+      if (lane < NVP) z[lane] = zi;
+      FH_SYNC();
+      const double ec = col_dot(Q, ll, z, n8);
       dc += ec;
-      r[lane] = ec;
+      if (lane < NVP) r[lane] = ec;
+      FH_SYNC();
+      zi -= row_dot(Q, ll, r, q8);
+      if (lane >= NVP) zi = 0.0;
+      zz = wave_sum(zi * zi);
     }
-    FH_SYNC();
-    if (lane < n) {
-      for (int c = 0; c < q; c++) zi -= Q[lane * S + c] * r[c];
-      z[lane] = zi;
-    }
-    FH_SYNC();
-    return wave_sum(lane < n ? zi * zi : 0.0);
+    return zz;
   }
 
   // ---- r = R^{-1} d, column-oriented; lane c returns r_c ----
   __device__ double backsolve(double dc) {
     double rc = 0;
+    const int ll = lane < NVP ? lane : NVP - 1;
     const double ri = (lane < q) ? rinv[lane] : 0.0;
     double dcur = dc;
-    for (int c = q - 1; c >= 0; c--) {
+    const double* Rr = R + ll * S;
+    int c = q - 1;
+    for (; c >= 3; c -= 4) {  // the four R loads do not depend on the recurrence: issue them first
+      const double r0 = Rr[c], r1 = Rr[c - 1], r2 = Rr[c - 2], r3 = Rr[c - 3];
+      double val = readlane_f64(dcur * ri, c);
+      if (lane == c) rc = val;
+      if (lane < c) dcur -= r0 * val;
+      val = readlane_f64(dcur * ri, c - 1);
+      if (lane == c - 1) rc = val;
+      if (lane < c - 1) dcur -= r1 * val;
+      val = readlane_f64(dcur * ri, c - 2);
+      if (lane == c - 2) rc = val;
+      if (lane < c - 2) dcur -= r2 * val;
+      val = readlane_f64(dcur * ri, c - 3);
+      if (lane == c - 3) rc = val;
+      if (lane < c - 3) dcur -= r3 * val;
+    }
+    for (; c >= 0; c--) {
+      const double r0 = Rr[c];
       const double val = readlane_f64(dcur * ri, c);
       if (lane == c) rc = val;
-      if (lane < c) dcur -= R[lane * S + c] * val;
+      if (lane < c) dcur -= r0 * val;
     }
     return rc;
   }
@@ -461,13 +538,18 @@ struct Solver {
       FH_SYNC();
     }
     if (lane >= kpos && lane < q - 1) rinv[lane] = 1.0 / R[lane * S + lane];
+    if (lane < NVP) Q[lane * S + q - 1] = 0.0;  // keep the zero padding beyond the active columns
     q--;
     FH_SYNC();
   }
 
   __device__ void reset_qp() {
+    if (lane < NVP) {
+      for (int c = 0; c < q; c++) Q[lane * S + c] = 0.0;  // columns >= q are zero already
+      x[lane] = 0;
+      boxact[lane] = 0;
+    }
     q = 0;
-    if (lane < NV) { x[lane] = 0; boxact[lane] = 0; }
     for (int i = lane; i < NSEG * 4; i += 64) polyact[i] = 0ull;
     FH_SYNC();
   }
@@ -491,7 +573,7 @@ struct Solver {
         const int e = eq_next++;
         if (which == 0 && !force_final) continue;
         const double cur = which == 0 ? Pc[N * 3 + axis] : (which == 1 ? Vc[N * 3 + axis] : Ac[N * 3 + axis]);
-        vp = cur - xf9[which * 3 + axis];
+        vp = cur - xfl[which * 3 + axis];
         id = mk_id(K_EQ, 0, 0, e);
         is_eq = true;
       } else {
@@ -508,7 +590,7 @@ struct Solver {
       for (;;) {  // until row `id` is active
         if (++it > max_iters) return 3;
         double dc, zi;
-        const double zz = project(dc, zi);
+        const double zz = project(gg, dc, zi);
         const double rc = backsolve(dc);
         const bool dependent = zz <= dep2 * gg;
         if (is_eq) {
@@ -567,7 +649,7 @@ struct Solver {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
           const double p0 = pr.x0[i], v0 = pr.x0[3 + i], a0 = pr.x0[6 + i];
-          const double pf = xf9[i], vf = xf9[3 + i], af = xf9[6 + i];
+          const double pf = xfl[i], vf = xfl[3 + i], af = xfl[6 + i];
           c0[i] = k == 0 ? p0 : (k == 1 ? p0 + v0 * (h / 3.0) : p0 + v0 * (2.0 * h / 3.0) + a0 * (h * h / 6.0));
           cN[i] = k == 0 ? pf : (k == 1 ? pf - vf * (h / 3.0) : pf - vf * (2.0 * h / 3.0) + af * (h * h / 6.0));
         }
@@ -628,7 +710,7 @@ struct Solver {
   }
 
   // ---- MIQP for one dt: depth-first branch and bound.  returns FH_ST_* ----
-  __device__ int miqp(const fh_problem& pr, const fh_params& par, double& best_cost, int& nodes, int& iters) {
+  __device__ int miqp(const fh_problem& pr, const fh_params& par, double* __restrict__ ws, double& best_cost, int& nodes, int& iters) {
     best_cost = INFINITY;
     int depth = 0;
     int status_limit = 0;
@@ -669,6 +751,7 @@ struct Solver {
             FH_SYNC();
           }
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
+          snapshot_save(ws + (size_t)depth * SNAP_DOUBLES);  // the children inherit this node's factorisation
           if (lane == 0) {
             int* ord = &stk_order[depth * FH_MAX_POLY];
             const unsigned am = allowed_mask(bseg);
@@ -681,12 +764,13 @@ struct Solver {
                 const int tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp;
               }
             stk_seg[depth] = bseg;
+            stk_q[depth] = q;
             stk_next[depth] = 1;
             assign[bseg] = ord[0];
           }
           depth++;
           FH_SYNC();
-          descend = true;  // first child: warm start from the parent's factorisation (dual feasible)
+          descend = true;  // first child: continue from the parent's factorisation (dual feasible when rows are added)
         }
       }
       if (descend) continue;
@@ -699,9 +783,9 @@ struct Solver {
         if (nx < stk_cnt[d_]) {
           FH_SYNC();
           if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
-          FH_SYNC();
-          reset_qp();
-          eq_next = 0;
+          snapshot_restore(ws + (size_t)d_ * SNAP_DOUBLES);  // sibling: restart from the parent's optimum, not from scratch
+          q = stk_q[d_];
+          eq_next = 9;
           have_node = true;
           break;
         }
@@ -733,21 +817,13 @@ __device__ inline bool bad_input(const fh_problem& pr, int nseg_cap, int face_ca
   return false;
 }
 
-// One workgroup (= one wavefront) per problem.
+// Persistent workgroups (one wavefront each): every workgroup pulls the next problem from a device-scope counter
+// until the batch is exhausted, so problems of very different difficulty balance across the 256 CUs and the
+// snapshot workspace is sized by the resident grid, not by the batch.
 template <int NSEG>
-__global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ gfaces,
-                                                   int n_problems, int max_faces, fh_params par, fh_result* __restrict__ results) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int b = blockIdx.x;
-  if (b >= n_problems) return;
-  const fh_problem& pr = problems[b];
-  fh_result& res = results[b];
-  const int lane = threadIdx.x;
-
-  Solver<NSEG> sv;
-  sv.carve(smem, max_faces);
-  sv.lane = lane;
-
+__device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face* __restrict__ gfaces, int max_faces,
+                          const fh_params& par, double* __restrict__ ws, fh_result& res) {
+  const int lane = sv.lane;
   if (bad_input(pr, NSEG, max_faces)) {
     if (lane == 0) {
       res.solved = 0; res.trials = 0; res.status = FH_ST_BAD_INPUT; res.nodes = 0; res.qp_iters = 0; res.reserved = 0;
@@ -764,7 +840,9 @@ __global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict_
   sv.dep2 = par.dep_tol * par.dep_tol;
   sv.vmax = pr.v_max; sv.amax = pr.a_max; sv.jmax = pr.j_max;
   sv.force_final = pr.force_final_pos;
-  for (int i = 0; i < 9; i++) sv.xf9[i] = pr.xf[i];
+  FH_SYNC();  // the previous problem of this workgroup is completely done with LDS
+  if (lane < 9) sv.xfl[lane] = pr.xf[lane];
+  sv.init_problem();
 
   // stage the corridor once: coalesced 32-B face rows HBM -> LDS, and |a_f|
   const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
@@ -786,7 +864,7 @@ __global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict_
     dt = f * base;
     sv.h = dt;
     sv.setup_trial(pr);
-    status = sv.miqp(pr, par, cost, nodes, iters);
+    status = sv.miqp(pr, par, ws, cost, nodes, iters);
     if (status == FH_ST_OPTIMAL) {
       solved = true;
       factor = f;
@@ -794,7 +872,8 @@ __global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict_
   }
 
   if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
-    if (lane < sv.n) sv.x[lane] = sv.bestx[lane];
+    FH_SYNC();
+    if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx[lane] : 0.0;
     FH_SYNC();
     sv.compute_states();
     if (lane < sv.n) {
@@ -816,6 +895,25 @@ __global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict_
     res.factor = solved ? factor : 0.0;
     res.dt = dt;
     res.cost = solved ? cost : 0.0;
+  }
+}
+
+template <int NSEG>
+__global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ gfaces,
+                                                   int n_problems, int max_faces, fh_params par, double* __restrict__ workspace,
+                                                   unsigned int* __restrict__ next_problem, fh_result* __restrict__ results) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Solver<NSEG> sv;
+  sv.carve(smem, max_faces);
+  sv.lane = threadIdx.x;
+  sv.q = 0;
+  double* ws = workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_DOUBLES;
+  for (;;) {
+    unsigned int b = 0;
+    if (threadIdx.x == 0) b = atomicAdd(next_problem, 1u);
+    b = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+    if (b >= (unsigned int)n_problems) break;
+    solve_one<NSEG>(sv, problems[b], gfaces, max_faces, par, ws, results[b]);
   }
 }
 
