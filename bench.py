@@ -35,6 +35,22 @@ def algorithmic_bytes(problems, n_seg_out):
     return reads + writes
 
 
+def measured_traffic():
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
+    in separate runs by scripts/profile_round.sh, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes)."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+        try:
+            t = json.load(open(f)).get("_hbm_traffic_per_launch_bytes")
+        except Exception:
+            t = None
+        if t:
+            best = (t["total"], os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +203,8 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
-                "traffic": None,
+                "traffic": (measured_traffic() or (None, None))[0],
+                "traffic_source": (measured_traffic() or (None, None))[1],
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": int(len(kernel_ms)),

@@ -170,7 +170,6 @@ int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_fa
   if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
   if (max_faces <= 0 || max_faces > FH_MAX_FACES) max_faces = FH_MAX_FACES;
   max_faces = (max_faces + 7) & ~7;
-  FH_HIP(hipMemsetAsync(d_results, 0, sizeof(fh_result) * (size_t)n, ctx->stream));
   if (max_seg <= 6) return launch_solve<6>(ctx, d_problems, d_faces, n, max_faces, d_results);
   if (max_seg <= 10) return launch_solve<10>(ctx, d_problems, d_faces, n, max_faces, d_results);
   return launch_solve<FH_MAX_SEG>(ctx, d_problems, d_faces, n, max_faces, d_results);
@@ -256,7 +255,7 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
-  hipLaunchKernelGGL(fh::pair_glue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_whole,
+  hipLaunchKernelGGL(fh::pair_glue_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole,
                      d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces);
   FH_HIP(hipGetLastError());
   return FH_OK;

@@ -10,7 +10,7 @@
 //                  for synthetic pairs: R = sample (int)(r_frac*count) of the whole
 //                  trajectory becomes x0 of the safe problem; the safe corridor is the run of up to
 //                  `max_safe_poly` consecutive polytopes starting at the first one that contains R, each shrunk
-//                  by `shrink` metres (emulating the unknown-space inflation).  One thread per pair.
+//                  by `shrink` metres (emulating the unknown-space inflation).  One wavefront per pair.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -83,16 +83,19 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
   }
 }
 
-__global__ void pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
-                                 const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink, int max_safe_poly,
-                                 fh_problem* __restrict__ safe, fh_face* __restrict__ sfaces) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per pair: the scalar sample clock runs once (wave-uniform), the polytope tests and the face copy are
+// lane-parallel over faces with coalesced 32-B rows.
+__global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
+                                                       const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink,
+                                                       int max_safe_poly, fh_problem* __restrict__ safe, fh_face* __restrict__ sfaces) {
+  const int b = blockIdx.x;
   if (b >= n) return;
+  const int lane = threadIdx.x;
   const fh_problem& pw = whole[b];
   const fh_result& rw = wres[b];
   fh_problem& ps = safe[b];
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
-    ps.n_seg = 0;
+    if (lane == 0) ps.n_seg = 0;
     return;
   }
   const int N = pw.n_seg;
@@ -103,50 +106,54 @@ __global__ void pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_
   if (k < 0) k = 0;
   double t = 0;
   int interval = 0;
-  for (int i = 0; i <= k; i++) {
+  for (int i = 0; i <= k; i++) {  // the reference's clock (solverGurobi.cpp:131-135), wave-uniform
     t = t + DC;
     if (t > dt * (interval + 1)) interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
   }
   fh_state R;
   eval_state(rw.coeff[interval], t - interval * dt, k == size - 1, R);
-  for (int a = 0; a < 3; a++) {
-    ps.x0[a] = R.pos[a];
-    ps.x0[3 + a] = R.vel[a];
-    ps.x0[6 + a] = R.accel[a];
+  if (lane < 3) {
+    ps.x0[lane] = R.pos[lane];
+    ps.x0[3 + lane] = R.vel[lane];
+    ps.x0[6 + lane] = R.accel[lane];
   }
   // first polytope (shrunk) that contains R, else the least violated one
   const int P = pw.n_poly;
+  const int fb = pw.face_begin;
   int start = 0;
   double best = INFINITY;
   bool found = false;
   for (int p = 0; p < P && !found; p++) {
     double worst = -INFINITY;
-    for (int f = pw.face_off[p]; f < pw.face_off[p + 1]; f++) {
-      const fh_face fc = wfaces[pw.face_begin + f];
+    for (int f = pw.face_off[p] + lane; f < pw.face_off[p + 1]; f += 64) {
+      const fh_face fc = wfaces[fb + f];
       const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
       worst = fmax(worst, fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - shrink * nr));
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
     if (worst <= 0) { start = p; found = true; }
     else if (worst < best) { best = worst; start = p; }
   }
   int cnt = P - start;
   if (cnt > max_safe_poly) cnt = max_safe_poly;
   if (P == 0) cnt = 0;
-  ps.n_poly = cnt;
-  ps.face_begin = pw.face_begin;
-  int o = 0;
-  ps.face_off[0] = 0;
-  for (int p = 0; p < cnt; p++) {
-    for (int f = pw.face_off[start + p]; f < pw.face_off[start + p + 1]; f++) {
-      fh_face fc = wfaces[pw.face_begin + f];
-      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      fc.b -= shrink * nr;
-      sfaces[pw.face_begin + o] = fc;
-      o++;
-    }
-    ps.face_off[p + 1] = o;
+  const int src0 = P ? pw.face_off[start] : 0;
+  const int total = P ? pw.face_off[start + cnt] - src0 : 0;
+  for (int f = lane; f < total; f += 64) {
+    fh_face fc = wfaces[fb + src0 + f];
+    const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+    fc.b -= shrink * nr;
+    sfaces[fb + f] = fc;
   }
-  for (int p = cnt; p < FH_MAX_POLY; p++) ps.face_off[p + 1] = o;
+  if (lane <= FH_MAX_POLY) {
+    const int p = lane < cnt ? lane : cnt;
+    ps.face_off[lane] = pw.face_off[start + p] - src0;
+  }
+  if (lane == 0) {
+    ps.n_poly = cnt;
+    ps.face_begin = fb;
+  }
 }
 
 }  // namespace fh

@@ -556,27 +556,134 @@ struct Solver {
 
   // ---- dual active set from the current (dual feasible) state.  eq_next: next equality to add (9 = none left).
   // returns 0 optimal, 1 infeasible, 2 bounded out by `ub`, 3 iteration limit ----
-  __device__ int qp_run(int& eq_next, double ub, int max_iters, int& iters, double& cost) {
+  // ---- final-state equalities (setConstraintsXf :332-357), built directly instead of by 6-9 active-set iterations.
+  // Their normals are the same three jerk->state functionals w_P, w_V, w_A (N-vectors, m = N-1-s) on every axis, and
+  // the axes have disjoint supports, so the thin QR of the 6/9 rows is a 3-vector Gram-Schmidt (lane = segment)
+  // replicated per axis, and the minimum-norm point is three triangular 3x3 solves.  Rows are taken in the oracle's
+  // order (per axis: [pos], vel, accel); a dependent row (N < 3) is skipped if consistent, else the node is infeasible.
+  // Leaves q = number of accepted rows, x = minimum-norm point.  Returns false if inconsistent. ----
+  __device__ bool init_equalities() {
+    const int nrow = force_final ? 3 : 2;
+    const int koff = 3 - nrow;  // row j uses functional kind j + koff: 0 pos, 1 vel, 2 accel
+    double* eqq = viol;          // [3][NT] orthonormal N-vectors, indexed by segment s
+    double* eqy = viol + 3 * NT; // [3][3]  coefficients y_j per axis
+    const bool on = lane < N;
+    const int m = N - 1 - lane;
+    double F[3], Qv[3] = {0.0, 0.0, 0.0};
+    bool acc[3] = {false, false, false};
+    double rd[3] = {1.0, 1.0, 1.0}, ro[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int kind = j + koff;
+      F[j] = (on && j < nrow) ? wcoef(kind == 0 ? W_P : (kind == 1 ? W_V : W_A), m, h) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (j < nrow) {
+        double zj = F[j];
+        double dd[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+          for (int jp = 0; jp < 3; jp++)
+            if (jp < j && acc[jp]) {
+              const double e = wave_sum(Qv[jp] * zj);
+              zj -= e * Qv[jp];
+              dd[jp] += e;
+            }
+        const double zz = wave_sum(zj * zj), ff = wave_sum(F[j] * F[j]);
+#pragma unroll
+        for (int jp = 0; jp < 3; jp++) ro[jp][j] = dd[jp];
+        if (zz > dep2 * ff) {
+          acc[j] = true;
+          rd[j] = sqrt(zz);
+          Qv[j] = zj / rd[j];
+        }
+      }
+    }
+    FH_SYNC();
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) eqq[j * NT + lane] = Qv[j];
+    }
+    // per axis: forward substitution R^T y = rhs, consistency of skipped rows
+    bool bad = false;
+    if (lane < 3) {
+      double y[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        if (j < nrow) {
+          const int kind = j + koff;
+          const double base = kind == 0 ? P0[N * 3 + lane] : (kind == 1 ? V0[N * 3 + lane] : A0[N * 3 + lane]);
+          double rhs = xfl[kind * 3 + lane] - base;
+#pragma unroll
+          for (int jp = 0; jp < 3; jp++)
+            if (jp < j && acc[jp]) rhs -= ro[jp][j] * y[jp];
+          if (acc[j]) y[j] = rhs / rd[j];
+          else if (fabs(rhs) > tol) bad = true;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) eqy[j * 3 + lane] = y[j];
+    }
+    if (wave_any(bad)) return false;
+    FH_SYNC();
+    int cnt = 0, rank[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { rank[j] = cnt; cnt += acc[j] ? 1 : 0; }
+    if (lane < n) {  // x and the Q1 columns of this lane's axis
+      const int s = lane / 3, i = lane - 3 * s;
+      double xv = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (acc[j]) {
+          const double qv = eqq[j * NT + s];
+          xv += qv * eqy[j * 3 + i];
+          Q[lane * S + i * cnt + rank[j]] = qv;
+        }
+      x[lane] = xv;
+    }
+    if (lane < 3 * cnt) {  // column `lane` of R (block diagonal per axis), bookkeeping
+      const int i = lane / cnt, rk = lane - i * cnt;
+      int j = 0;
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++)
+        if (acc[jj] && rank[jj] == rk) j = jj;
+      for (int c2 = 0; c2 < lane; c2++) {
+        double v = 0.0;
+        const int i2 = c2 / cnt, rk2 = c2 - i2 * cnt;
+        if (i2 == i) {
+#pragma unroll
+          for (int jj = 0; jj < 3; jj++)
+            if (acc[jj] && rank[jj] == rk2) v = (j == 0) ? ro[jj][0] : (j == 1 ? ro[jj][1] : ro[jj][2]);
+        }
+        R[c2 * S + lane] = v;
+      }
+      const double dg = j == 0 ? rd[0] : (j == 1 ? rd[1] : rd[2]);
+      R[lane * S + lane] = dg;
+      rinv[lane] = 1.0 / dg;
+      act[lane] = mk_id(K_EQ, 0, 0, i * 3 + j + koff);
+      u[lane] = 0.0;
+    }
+    q = 3 * cnt;
+    FH_SYNC();
+    return true;
+  }
+
+  // ---- dual active set from the current (dual feasible) state.
+  // returns 0 optimal, 1 infeasible, 2 bounded out by `ub`, 3 iteration limit ----
+  __device__ int qp_run(double ub, int max_iters, int& iters, double& cost) {
     int it = 0;
-    const int st = qp_loop(eq_next, ub, max_iters, it, cost);
+    const int st = qp_loop(ub, max_iters, it, cost);
     iters += it;
     return st;
   }
-  __device__ int qp_loop(int& eq_next, double ub, int max_iters, int& it, double& cost) {
+  __device__ int qp_loop(double ub, int max_iters, int& it, double& cost) {
     for (;;) {
       compute_states();
       int id;
       double vp;
-      bool is_eq = false;
-      if (eq_next < 9) {
-        const int axis = eq_next / 3, which = eq_next - 3 * axis;
-        const int e = eq_next++;
-        if (which == 0 && !force_final) continue;
-        const double cur = which == 0 ? Pc[N * 3 + axis] : (which == 1 ? Vc[N * 3 + axis] : Ac[N * 3 + axis]);
-        vp = cur - xfl[which * 3 + axis];
-        id = mk_id(K_EQ, 0, 0, e);
-        is_eq = true;
-      } else {
+      {
         const double xl = (lane < n) ? x[lane] : 0.0;
         cost = wave_sum(xl * xl);
         if (cost >= ub) return 2;
@@ -593,17 +700,6 @@ struct Solver {
         const double zz = project(gg, dc, zi);
         const double rc = backsolve(dc);
         const bool dependent = zz <= dep2 * gg;
-        if (is_eq) {
-          if (dependent) {
-            if (fabs(vp) > tol) return 1;
-            break;  // redundant equality
-          }
-          const double t = vp / zz;
-          if (lane < q) u[lane] -= t * rc;
-          if (lane < n) x[lane] -= t * zi;
-          add_row(id, zi, zz, dc, t);
-          break;
-        }
         double ratio = INFINITY;
         if (lane < q && (act[lane] >> 24) != K_EQ && rc > 0) ratio = u[lane] / rc;
         const double t1 = wave_min(ratio);
@@ -731,14 +827,14 @@ struct Solver {
       FH_SYNC();
     }
     reset_qp();
-    int eq_next = 0;
+    if (!init_equalities()) return FH_ST_INFEASIBLE;
     bool have_node = true;  // a node is ready to be solved (assign[] set, QP state prepared)
     int local_nodes = 0;
     while (have_node) {
       if (local_nodes >= par.max_nodes) { status_limit = FH_ST_NODE_LIMIT; break; }
       local_nodes++;
       double cost = 0;
-      const int st = qp_run(eq_next, best_cost, par.max_iters, iters, cost);
+      const int st = qp_run(best_cost, par.max_iters, iters, cost);
       if (st == 3) { status_limit = FH_ST_ITER_LIMIT; break; }
       bool descend = false;
       if (st == 0) {
@@ -785,7 +881,6 @@ struct Solver {
           if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
           snapshot_restore(ws + (size_t)d_ * SNAP_DOUBLES);  // sibling: restart from the parent's optimum, not from scratch
           q = stk_q[d_];
-          eq_next = 9;
           have_node = true;
           break;
         }
@@ -830,6 +925,7 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
       res.factor = 0; res.dt = 0; res.cost = 0;
     }
     if (lane < FH_MAX_SEG) res.assign[lane] = -1;
+    for (int i = lane; i < FH_MAX_SEG * 12; i += 64) (&res.coeff[0][0])[i] = 0.0;
     return;
   }
 
@@ -876,13 +972,16 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
     if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx[lane] : 0.0;
     FH_SYNC();
     sv.compute_states();
-    if (lane < sv.n) {
-      const int t = lane / 3, i = lane - 3 * t;
-      res.coeff[t][0 + i] = sv.bestx[lane] / 6.0;
-      res.coeff[t][3 + i] = sv.Ac[lane] / 2.0;
-      res.coeff[t][6 + i] = sv.Vc[lane];
-      res.coeff[t][9 + i] = sv.Pc[lane];
+  }
+  // every word of the result is written by the kernel (no memset of the result buffer is needed)
+  for (int idx = lane; idx < FH_MAX_SEG * 12; idx += 64) {
+    const int t = idx / 12, rem = idx - 12 * t, kind = rem / 3, i = rem - 3 * kind;
+    double v = 0.0;
+    if (solved && t < sv.N) {
+      const int o = 3 * t + i;
+      v = kind == 0 ? sv.bestx[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
     }
+    res.coeff[t][rem] = v;
   }
   if (lane < FH_MAX_SEG) res.assign[lane] = (solved && lane < sv.N && sv.P > 0) ? (int8_t)sv.bestassign[lane] : (int8_t)-1;
   if (lane == 0) {
