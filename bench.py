@@ -54,17 +54,19 @@ def measured_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pairs", type=int, default=32768, help="whole+safe pairs per rank per step (C4: 32768)")
     ap.add_argument("--n-seg", type=int, default=10)
     ap.add_argument("--max-poly", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     args = ap.parse_args()
 
+    # more hardware queues than the HIP default (4) so that the in-flight pipelines really run concurrently
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))

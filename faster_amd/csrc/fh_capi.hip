@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -51,7 +52,8 @@ static int ensure(fh_ctx* ctx, int slot, size_t bytes) {
 template <int NSEG>
 static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n, int max_faces,
                         fh_result* d_results) {
-  const size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
+  size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
+  if (const char* pad = getenv("FH_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   auto kern = fh::solve_kernel<NSEG>;
   // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU), never more than the batch
   int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
@@ -59,7 +61,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   const int grid = std::min(n, ctx->n_cu * per_cu);
   // slot 5: snapshot workspace (one slot per tree level per workgroup), slot 6: the work counter
   int rc;
-  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_DOUBLES)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_PADDED)) != FH_OK) return rc;
   if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
   FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 4, ctx->stream));
   FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -30,6 +30,15 @@
 namespace fh {
 
 #define FH_SYNC() __syncthreads()
+// -DFH_PROFILE: per-phase cycle counters (s_memtime) accumulated per problem and written into the unused last
+// coefficient row of the result (diagnostic builds only; scripts/phase_profile.py).
+#ifdef FH_PROFILE
+#define FH_T0() const unsigned long long t0__ = __builtin_readcyclecounter()
+#define FH_T1(slot) do { prof[slot] += __builtin_readcyclecounter() - t0__; cnt[slot] += 1; } while (0)
+#else
+#define FH_T0()
+#define FH_T1(slot)
+#endif
 #define FH_MAX_TRIALS 4096
 
 enum { K_EQ = 0, K_JBOX = 1, K_VBOX = 2, K_ABOX = 3, K_POLY = 4 };
@@ -51,20 +60,41 @@ __device__ __forceinline__ double uniform_f64(double v) {
 }
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Wave64 reductions on the DPP network (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 / row_bcast:31
+// across rows; the total lands in lane 63) instead of ds_bpermute round trips through the LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double identity, double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(identity), lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return uniform_f64(v);
+  v += dpp_f64<0x111, 0xf>(0.0, v);
+  v += dpp_f64<0x112, 0xf>(0.0, v);
+  v += dpp_f64<0x114, 0xf>(0.0, v);
+  v += dpp_f64<0x118, 0xf>(0.0, v);
+  v += dpp_f64<0x142, 0xa>(0.0, v);
+  v += dpp_f64<0x143, 0xc>(0.0, v);
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return uniform_f64(v);
+  v = fmax(v, dpp_f64<0x111, 0xf>(-INFINITY, v));
+  v = fmax(v, dpp_f64<0x112, 0xf>(-INFINITY, v));
+  v = fmax(v, dpp_f64<0x114, 0xf>(-INFINITY, v));
+  v = fmax(v, dpp_f64<0x118, 0xf>(-INFINITY, v));
+  v = fmax(v, dpp_f64<0x142, 0xa>(-INFINITY, v));
+  v = fmax(v, dpp_f64<0x143, 0xc>(-INFINITY, v));
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return uniform_f64(v);
+  v = fmin(v, dpp_f64<0x111, 0xf>(INFINITY, v));
+  v = fmin(v, dpp_f64<0x112, 0xf>(INFINITY, v));
+  v = fmin(v, dpp_f64<0x114, 0xf>(INFINITY, v));
+  v = fmin(v, dpp_f64<0x118, 0xf>(INFINITY, v));
+  v = fmin(v, dpp_f64<0x142, 0xa>(INFINITY, v));
+  v = fmin(v, dpp_f64<0x143, 0xc>(INFINITY, v));
+  return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int first_lane(bool pred) {  // lowest lane with pred, -1 if none (uniform)
   unsigned long long m = __ballot(pred);
@@ -170,21 +200,29 @@ struct Solver {
   double *P0, *V0, *A0, *Pc, *Vc, *Ac;                // [NT*3] jerk-free / current states at segment starts
   double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
   double* wn;                                         // [W_KINDS][NT] row-norm factors sqrt(sum_m wcoef^2)
+  double* wni;                                        // [W_KINDS][NT] their inverses (0 where the factor is 0)
   double* viol;                                       // [NSEG][FH_MAX_POLY]
   double* xfl;                                        // [9] goal state (+3 pad)
-  double* fnorm;                                      // [n_faces] |a_f|
-  fh_face* faces;                                     // [n_faces]
+  double* tolf;                                       // [n_faces] feas_tol / |a_f|
+  fh_face* faces;                                     // [n_faces] NORMALISED rows: a/|a| and bt = -(b + feas_tol)/|a|, so that
+                                                      //           a.cp + bt > 0  <=>  the original row is violated by more than feas_tol
   unsigned long long* polyact;                        // [NSEG][4] active-row bit per face
   int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_order, *face_off;
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (2 * NVP * S + 8 * NVP + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + NSEG * FH_MAX_POLY + 12 + max_faces) +
-           sizeof(fh_face) * max_faces + sizeof(unsigned long long) * NSEG * 4 +
-           sizeof(int) * (2 * NVP + 7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 2) + 64;
+    return sizeof(double) * (2 * NVP * S + 3 * NVP + NSEG * 4 + NVP + 5 * NVP + 6 * NT * 3 + NSEG * 12 + 2 * W_KINDS * NT +
+                             NSEG * FH_MAX_POLY + 12) +
+           sizeof(int) * (7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 1 + 3) + (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
   }
 
   // ---- wave-uniform scalars ----
   int lane, N, n, q, P;
+  int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
+  unsigned poly_ok;  // polytopes without a violated zero-normal face (such a polytope can never hold a segment)
+#ifdef FH_PROFILE
+  unsigned long long prof[14];
+  unsigned int cnt[14];
+#endif
   unsigned allowed_first, allowed_last;  // polytopes not excluded for segment 0 / N-1 by jerk-independent rows
   double h, tol, dep2;
   double vmax, amax, jmax;
@@ -195,6 +233,8 @@ struct Solver {
   static constexpr int SNAP_DOUBLES = 2 * NVP * S + 3 * NVP + NSEG * 4 + NVP;  // Q, R, x, u, rinv, polyact, act+boxact
   static_assert(SNAP_DOUBLES % 2 == 0, "snapshot is copied as double2");
 
+  // Fixed-size arrays first (compile-time LDS offsets that fold into the ds_read/ds_write immediates and cost no
+  // SGPRs), the two arrays sized by the batch's face bound last.
   __device__ void carve(unsigned char* base, int max_faces) {
     double* p = reinterpret_cast<double*>(base);
     Q = p; p += NVP * S;
@@ -208,30 +248,45 @@ struct Solver {
     Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
     CP = p; p += NSEG * 12;
     wn = p; p += W_KINDS * NT;
+    wni = p; p += W_KINDS * NT;
     viol = p; p += NSEG * FH_MAX_POLY;
     xfl = p; p += 12;
-    fnorm = p; p += max_faces;
-    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) p += 1;  // faces are read 16 B at a time
-    faces = reinterpret_cast<fh_face*>(p); p += 4 * max_faces;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
     stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_q = ip; ip += NSEG;
     stk_order = ip; ip += NSEG * FH_MAX_POLY;
     face_off = ip; ip += FH_MAX_POLY + 1;
+    ip += (4 - ((7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 1) & 3)) & 3;  // back to 16-B alignment
+    faces = reinterpret_cast<fh_face*>(ip);  // [max_faces] 32-B rows, read 16 B at a time
+    tolf = reinterpret_cast<double*>(faces + max_faces);
   }
 
   // ---- node state snapshots (HBM workspace, one slot per tree level; L2-resident in practice) ----
+  // Copies run in full 64-lane steps of 16 B (no per-step predicates): the tail of the last step spills into the
+  // scratch vectors that follow the block in LDS (z, g, ...), which is harmless in both directions.
+  static constexpr int SNAP_STEPS = (SNAP_DOUBLES / 2 + 63) / 64;
+  static constexpr int SNAP_PADDED = SNAP_STEPS * 128;  // doubles per workspace slot
+  static_assert(SNAP_PADDED - SNAP_DOUBLES <= 4 * NVP, "snapshot tail must stay inside the scratch vectors z, g, d, r");
   __device__ void snapshot_save(double* __restrict__ ws_level) {
     FH_SYNC();
-    const double2* src = reinterpret_cast<const double2*>(Q);
-    double2* dst = reinterpret_cast<double2*>(ws_level);
-    for (int i = lane; i < SNAP_DOUBLES / 2; i += 64) dst[i] = src[i];
+    const double2* src = reinterpret_cast<const double2*>(Q) + lane;
+    double2* dst = reinterpret_cast<double2*>(ws_level) + lane;
+#pragma unroll
+    for (int k = 0; k < SNAP_STEPS; k++) dst[k * 64] = src[k * 64];
   }
   __device__ void snapshot_restore(const double* __restrict__ ws_level) {
     FH_SYNC();
-    double2* dst = reinterpret_cast<double2*>(Q);
-    const double2* src = reinterpret_cast<const double2*>(ws_level);
-    for (int i = lane; i < SNAP_DOUBLES / 2; i += 64) dst[i] = src[i];  // same lane <-> same words as the save
+    double2* dst = reinterpret_cast<double2*>(Q) + lane;
+    const double2* src = reinterpret_cast<const double2*>(ws_level) + lane;
+    constexpr int CH = 6;  // loads in flight per chunk (bounded register footprint)
+    for (int k0 = 0; k0 < SNAP_STEPS; k0 += CH) {
+      double2 tmp[CH];
+#pragma unroll
+      for (int j = 0; j < CH; j++) tmp[j] = src[(k0 + j < SNAP_STEPS ? k0 + j : SNAP_STEPS - 1) * 64];
+#pragma unroll
+      for (int j = 0; j < CH; j++)
+        if (k0 + j < SNAP_STEPS) dst[(k0 + j) * 64] = tmp[j];  // same lane <-> same words as the save
+    }
     FH_SYNC();
   }
 
@@ -262,7 +317,9 @@ struct Solver {
         const double c = wcoef(kind, m, h);
         s += c * c;
       }
-      wn[idx] = sqrt(s);
+      const double w = sqrt(s);
+      wn[idx] = w;
+      wni[idx] = w > 0.0 ? 1.0 / w : 0.0;
     }
     FH_SYNC();
   }
@@ -284,13 +341,13 @@ struct Solver {
       Pc[lane] = p; Vc[lane] = v; Ac[lane] = a;
     }
     FH_SYNC();
-    for (int idx = lane; idx < N * 12; idx += 64) {
-      const int t = idx / 12, rem = idx - 12 * t, k = rem / 3, i = rem - 3 * k;
-      const int o = (t + (k == 3 ? 1 : 0)) * 3 + i;
-      double c = Pc[o];
-      if (k == 1) c += Vc[o] * (h / 3.0);
-      if (k == 2) c += Vc[o] * (2.0 * h / 3.0) + Ac[o] * (h * h / 6.0);
-      CP[idx] = c;
+    if (lane < 4 * N) {  // lane = (segment, control point): three axes each, no integer divisions
+      const int t = lane >> 2, k = lane & 3;
+      const int o = (t + (k == 3 ? 1 : 0)) * 3;
+      const double wv = k == 1 ? h / 3.0 : (k == 2 ? 2.0 * h / 3.0 : 0.0);
+      const double wa = k == 2 ? h * h / 6.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) CP[lane * 3 + i] = Pc[o + i] + wv * Vc[o + i] + wa * Ac[o + i];
     }
     FH_SYNC();
   }
@@ -307,42 +364,49 @@ struct Solver {
       const int t = lane / 3, i = lane - 3 * t;
       const int ba = boxact[lane];
       const double xv = x[lane];
-      double v = xv - jmax;
-      if (v > tol && !(ba & 1) && v > bs) { bs = v; bv = v; bid = mk_id(K_JBOX, t, i, 0); }
-      v = -xv - jmax;
-      if (v > tol && !(ba & 2) && v > bs) { bs = v; bv = v; bid = mk_id(K_JBOX, t, i, 1); }
-      if (t >= 1) {
-        const double V = Vc[lane], A = Ac[lane];
-        const double nV = wn[W_V * NT + t], nA = wn[W_A * NT + t];
-        v = V - vmax;
-        if (v > tol && !(ba & 4) && v > bs * nV) { bs = v / nV; bv = v; bid = mk_id(K_VBOX, t, i, 0); }
-        v = -V - vmax;
-        if (v > tol && !(ba & 8) && v > bs * nV) { bs = v / nV; bv = v; bid = mk_id(K_VBOX, t, i, 1); }
-        v = A - amax;
-        if (v > tol && !(ba & 16) && v > bs * nA) { bs = v / nA; bv = v; bid = mk_id(K_ABOX, t, i, 0); }
-        v = -A - amax;
-        if (v > tol && !(ba & 32) && v > bs * nA) { bs = v / nA; bv = v; bid = mk_id(K_ABOX, t, i, 1); }
+      const double V = Vc[lane], A = Ac[lane];
+      const double iV = t >= 1 ? wni[W_V * NT + t] : 0.0, iA = t >= 1 ? wni[W_A * NT + t] : 0.0;  // t = 0 rows are constants
+      const double cand[6] = {xv - jmax, -xv - jmax, V - vmax, -V - vmax, A - amax, -A - amax};
+      const double inv[6] = {1.0, 1.0, iV, iV, iA, iA};
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const double sc = cand[c] * inv[c];
+        const bool take = cand[c] > tol && !((ba >> c) & 1) && sc > bs;
+        bs = take ? sc : bs;
+        bv = take ? cand[c] : bv;
+        bid = take ? mk_id(c < 2 ? K_JBOX : (c < 4 ? K_VBOX : K_ABOX), t, i, c & 1) : bid;
       }
     }
-    if (lane < 4 * N) {
-      const int t = lane >> 2, k = lane & 3;
-      const int p = assign[t];
-      if (p >= 0) {
-        const int f0 = face_off[p], F = face_off[p + 1] - f0;
-        const double c0 = CP[lane * 3 + 0], c1 = CP[lane * 3 + 1], c2 = CP[lane * 3 + 2];
-        const unsigned long long am = polyact[lane];
-        const double w = wn[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
-#pragma unroll 4
-        for (int f = 0; f < F; f++) {
-          const fh_face fc = faces[f0 + f];
-          const double v = fc.a[0] * c0 + fc.a[1] * c1 + fc.a[2] * c2 - fc.b;
-          if (v > tol) {
-            if (w == 0.0) bad = true;
-            else if (!((am >> f) & 1ull)) {
-              const double nr = fnorm[f0 + f] * w;
-              if (v > bs * nr) { bs = v / nr; bv = v; bid = mk_id(K_POLY, t, k, f); }
-            }
-          }
+    {  // corridor rows: wave-uniform trip count (max faces per polytope) so that the face loads of 4 rows are in flight.
+       // All rows of a lane share the weight factor, so the lane maximises the normalised violation and scales once.
+      const bool live = lane < 4 * N;
+      const int t = live ? (lane >> 2) : 0, k = lane & 3;
+      const int p = live ? assign[t] : -1;
+      const int f0 = p >= 0 ? face_off[p] : 0;
+      const int F = p >= 0 ? face_off[p + 1] - f0 : 0;
+      const int cl = live ? lane : 0;
+      const double c0 = CP[cl * 3 + 0], c1 = CP[cl * 3 + 1], c2 = CP[cl * 3 + 2];
+      const unsigned long long am = polyact[cl];
+      const double wi = wni[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
+      int bf = -1;
+      double bvt = 0;
+      for (int fb = 0; fb < maxF; fb += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int f = fb + j;
+          const fh_face fc = faces[f0 + (f < F ? f : 0)];
+          const double vt = fma(fc.a[0], c0, fma(fc.a[1], c1, fma(fc.a[2], c2, fc.b)));
+          const bool inactive = !((f < 32 ? (unsigned)am : (unsigned)(am >> 32)) >> (f & 31) & 1u);
+          const bool take = (f < F) && inactive && vt > bvt;
+          bvt = take ? vt : bvt;
+          bf = take ? f : bf;
+        }
+      }
+      if (bf >= 0) {
+        if (wi == 0.0) bad = true;  // jerk-independent row (segment 0, control points 0..2) violated
+        else {
+          const double sc = bvt * wi;
+          if (sc > bs) { bs = sc; bv = bvt + tolf[f0 + bf]; bid = mk_id(K_POLY, t, k, bf); }
         }
       }
     }
@@ -523,7 +587,8 @@ struct Solver {
       const double a = R[j * S + j], b = R[(j + 1) * S + j];
       const double rr = sqrt(a * a + b * b);
       if (rr != 0.0) {
-        const double cs = a / rr, sn = b / rr;
+        const double irr = 1.0 / rr;
+        const double cs = a * irr, sn = b * irr;
         if (lane >= j && lane < q - 1) {
           const double t1 = R[j * S + lane], t2 = R[(j + 1) * S + lane];
           R[j * S + lane] = cs * t1 + sn * t2;
@@ -680,25 +745,29 @@ struct Solver {
   }
   __device__ int qp_loop(double ub, int max_iters, int& it, double& cost) {
     for (;;) {
-      compute_states();
+      { FH_T0(); compute_states(); FH_T1(2); }
       int id;
       double vp;
       {
+        FH_T0();
         const double xl = (lane < n) ? x[lane] : 0.0;
         cost = wave_sum(xl * xl);
         if (cost >= ub) return 2;
         bool cbad;
         scan(id, vp, cbad);
+        FH_T1(3);
         if (cbad) return 1;
         if (id < 0) return 0;
       }
-      const double gg = build_g(id);
+      double gg;
+      { FH_T0(); gg = build_g(id); FH_T1(4); }
       double up = 0;
       for (;;) {  // until row `id` is active
         if (++it > max_iters) return 3;
-        double dc, zi;
-        const double zz = project(gg, dc, zi);
-        const double rc = backsolve(dc);
+        double dc, zi, zz, rc;
+        { FH_T0(); zz = project(gg, dc, zi); FH_T1(5); }
+        FH_T0();
+        rc = backsolve(dc);
         const bool dependent = zz <= dep2 * gg;
         double ratio = INFINITY;
         if (lane < q && (act[lane] >> 24) != K_EQ && rc > 0) ratio = u[lane] / rc;
@@ -713,18 +782,21 @@ struct Solver {
           if (lane < n) x[lane] -= t * zi;
           vp -= t * zz;
         }
+        FH_T1(6);
         if (t2 <= t1) {
+          FH_T0();
           add_row(id, zi, zz, dc, up);
+          FH_T1(7);
           break;
         }
         FH_SYNC();
-        drop_row(kb);
+        { FH_T0(); drop_row(kb); FH_T1(8); }
       }
     }
   }
 
   __device__ __forceinline__ unsigned allowed_mask(int t) const {
-    unsigned m = P ? ((1u << P) - 1u) : 0u;
+    unsigned m = P ? (((1u << P) - 1u) & poly_ok) : 0u;
     if (t == 0) m &= allowed_first;
     if (t == N - 1) m &= allowed_last;
     return m;
@@ -749,14 +821,15 @@ struct Solver {
           c0[i] = k == 0 ? p0 : (k == 1 ? p0 + v0 * (h / 3.0) : p0 + v0 * (2.0 * h / 3.0) + a0 * (h * h / 6.0));
           cN[i] = k == 0 ? pf : (k == 1 ? pf - vf * (h / 3.0) : pf - vf * (2.0 * h / 3.0) + af * (h * h / 6.0));
         }
+#pragma unroll 4
         for (int f = f0; f < f1; f++) {
           const fh_face fc = faces[f];
-          w0 = fmax(w0, fc.a[0] * c0[0] + fc.a[1] * c0[1] + fc.a[2] * c0[2] - fc.b);
-          wN = fmax(wN, fc.a[0] * cN[0] + fc.a[1] * cN[1] + fc.a[2] * cN[2] - fc.b);
+          w0 = fmax(w0, fma(fc.a[0], c0[0], fma(fc.a[1], c0[1], fma(fc.a[2], c0[2], fc.b))));
+          wN = fmax(wN, fma(fc.a[0], cN[0], fma(fc.a[1], cN[1], fma(fc.a[2], cN[2], fc.b))));
         }
       }
-      ok0 = !(w0 > tol);
-      okN = !(wN > tol);
+      ok0 = !(w0 > 0.0);
+      okN = !(wN > 0.0);
     }
     allowed_first = (unsigned)__ballot(ok0);
     if (force_final) allowed_last = (unsigned)__ballot(okN);
@@ -769,21 +842,27 @@ struct Solver {
       FH_SYNC();
       return -1;
     }
-    for (int pair = lane; pair < N * P; pair += 64) {
-      const int t = pair / P, p = pair - t * P;
+    for (int pair0 = 0; pair0 < N * P; pair0 += 64) {
+      const int pair = pair0 + lane;
+      const bool live = pair < N * P;
+      const int t = live ? pair / P : 0, p = live ? pair - t * P : 0;
+      const bool need = live && assign[t] < 0 && ((allowed_mask(t) >> p) & 1u);
+      const int f0 = face_off[p], F = need ? face_off[p + 1] - f0 : 0;
       double worst = -INFINITY;
-      if (assign[t] < 0 && !((allowed_mask(t) >> p) & 1u)) worst = INFINITY;
-      else if (assign[t] < 0) {
-        const int f0 = face_off[p], f1 = face_off[p + 1];
-        for (int k = 0; k < 4; k++) {
-          const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
-          for (int f = f0; f < f1; f++) {
-            const fh_face fc = faces[f];
-            worst = fmax(worst, fc.a[0] * c0 + fc.a[1] * c1 + fc.a[2] * c2 - fc.b);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
+        for (int fb = 0; fb < maxF; fb += 4) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int f = fb + j;
+            const fh_face fc = faces[f0 + (f < F ? f : 0)];
+            const double v = fma(fc.a[0], c0, fma(fc.a[1], c1, fma(fc.a[2], c2, fc.b)));
+            worst = (f < F) ? fmax(worst, v) : worst;
           }
         }
       }
-      viol[t * FH_MAX_POLY + p] = worst;
+      if (live) viol[t * FH_MAX_POLY + p] = (assign[t] < 0 && !need) ? INFINITY : worst;
     }
     FH_SYNC();
     double score = -INFINITY;
@@ -801,7 +880,7 @@ struct Solver {
     }
     const double bw = wave_max(score);
     FH_SYNC();
-    if (!(bw > tol)) return -1;
+    if (!(bw > 0.0)) return -1;  // (normalised rows carry the tolerance)
     return first_lane(score == bw);
   }
 
@@ -815,7 +894,11 @@ struct Solver {
     bool x0bad = false;
     for (int i = 0; i < 3; i++) x0bad |= (fabs(pr.x0[3 + i]) - vmax > tol) || (fabs(pr.x0[6 + i]) - amax > tol);
     if (x0bad) return FH_ST_INFEASIBLE;
-    screen_constant_rows(pr);
+    {
+      FH_T0();
+      screen_constant_rows(pr);
+      FH_T1(1);
+    }
     if (P > 0) {
       if (allowed_mask(0) == 0u || allowed_mask(N - 1) == 0u) return FH_ST_INFEASIBLE;
       FH_SYNC();
@@ -826,8 +909,13 @@ struct Solver {
       }
       FH_SYNC();
     }
-    reset_qp();
-    if (!init_equalities()) return FH_ST_INFEASIBLE;
+    {
+      FH_T0();
+      reset_qp();
+      const bool eq_ok = init_equalities();
+      FH_T1(1);
+      if (!eq_ok) return FH_ST_INFEASIBLE;
+    }
     bool have_node = true;  // a node is ready to be solved (assign[] set, QP state prepared)
     int local_nodes = 0;
     while (have_node) {
@@ -838,7 +926,8 @@ struct Solver {
       if (st == 3) { status_limit = FH_ST_ITER_LIMIT; break; }
       bool descend = false;
       if (st == 0) {
-        const int bseg = analyze(pr);
+        int bseg;
+        { FH_T0(); bseg = analyze(pr); FH_T1(9); }
         if (bseg < 0) {  // leaf: feasible for the MIQP
           if (cost < best_cost) {
             best_cost = cost;
@@ -847,7 +936,7 @@ struct Solver {
             FH_SYNC();
           }
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
-          snapshot_save(ws + (size_t)depth * SNAP_DOUBLES);  // the children inherit this node's factorisation
+          { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED); FH_T1(10); }  // the children inherit this node's factorisation
           if (lane == 0) {
             int* ord = &stk_order[depth * FH_MAX_POLY];
             const unsigned am = allowed_mask(bseg);
@@ -879,7 +968,7 @@ struct Solver {
         if (nx < stk_cnt[d_]) {
           FH_SYNC();
           if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
-          snapshot_restore(ws + (size_t)d_ * SNAP_DOUBLES);  // sibling: restart from the parent's optimum, not from scratch
+          { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED); FH_T1(11); }  // sibling: restart from the parent's optimum, not from scratch
           q = stk_q[d_];
           have_node = true;
           break;
@@ -919,6 +1008,10 @@ template <int NSEG>
 __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face* __restrict__ gfaces, int max_faces,
                           const fh_params& par, double* __restrict__ ws, fh_result& res) {
   const int lane = sv.lane;
+#ifdef FH_PROFILE
+  for (int i = 0; i < 14; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
+  const unsigned long long tstart__ = __builtin_readcyclecounter();
+#endif
   if (bad_input(pr, NSEG, max_faces)) {
     if (lane == 0) {
       res.solved = 0; res.trials = 0; res.status = FH_ST_BAD_INPUT; res.nodes = 0; res.qp_iters = 0; res.reserved = 0;
@@ -943,15 +1036,43 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
   // stage the corridor once: coalesced 32-B face rows HBM -> LDS, and |a_f|
   const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
   if (lane <= FH_MAX_POLY) sv.face_off[lane] = pr.face_off[lane];
-  for (int f = lane; f < nf; f += 64) {
-    const fh_face fc = gfaces[pr.face_begin + f];
-    sv.faces[f] = fc;
-    sv.fnorm[f] = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+  {
+    int mf = 0;
+    for (int p = 0; p < pr.n_poly; p++) mf = max(mf, pr.face_off[p + 1] - pr.face_off[p]);
+    sv.maxF = mf;
   }
+  unsigned badpoly = 0u;
+  for (int f0_ = 0; f0_ < nf; f0_ += 64) {
+    const int f = f0_ + lane;
+    bool degenerate_violated = false;
+    int pf = 0;
+    if (f < nf) {
+      fh_face fc = gfaces[pr.face_begin + f];
+      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+      if (nr > 0.0) {
+        const double inv = 1.0 / nr;
+        fc.a[0] *= inv; fc.a[1] *= inv; fc.a[2] *= inv;
+        fc.b = -(fc.b + par.feas_tol) * inv;
+        sv.tolf[f] = par.feas_tol * inv;
+      } else {  // 0 <= b: never binding if b >= -tol, else no point satisfies it
+        degenerate_violated = -fc.b > par.feas_tol;
+        fc.b = -1.0;
+        sv.tolf[f] = 0.0;
+        for (int p = 0; p < pr.n_poly; p++) pf = (f >= pr.face_off[p]) ? p : pf;
+      }
+      sv.faces[f] = fc;
+    }
+    for (int p = 0; p < pr.n_poly; p++)
+      if (wave_any(degenerate_violated && pf == p)) badpoly |= 1u << p;
+  }
+  sv.poly_ok = ~badpoly;
   FH_SYNC();
 
   const double dt0 = dt_initial(pr);
   const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
+#ifdef FH_PROFILE
+  sv.prof[0] = __builtin_readcyclecounter() - tstart__;
+#endif
   int trials = 0, nodes = 0, iters = 0, status = FH_ST_INFEASIBLE;
   bool solved = false;
   double dt = 0, factor = 0, cost = 0;
@@ -959,7 +1080,11 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
     trials++;
     dt = f * base;
     sv.h = dt;
-    sv.setup_trial(pr);
+    { FH_T0(); sv.setup_trial(pr); 
+#ifdef FH_PROFILE
+      sv.prof[1] += __builtin_readcyclecounter() - t0__; sv.cnt[1] += 1;
+#endif
+    }
     status = sv.miqp(pr, par, ws, cost, nodes, iters);
     if (status == FH_ST_OPTIMAL) {
       solved = true;
@@ -983,6 +1108,18 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
     }
     res.coeff[t][rem] = v;
   }
+#ifdef FH_PROFILE
+  sv.prof[12] = __builtin_readcyclecounter() - tstart__;
+  sv.prof[1] += 0;
+  if (lane < 12 && sv.N < FH_MAX_SEG) {
+    unsigned long long pv = 0;
+    for (int i = 0; i < 12; i++) pv = (i == lane) ? sv.prof[i] : pv;
+    res.coeff[FH_MAX_SEG - 1][lane] = (double)pv;
+    unsigned int cv = 0;
+    for (int i = 0; i < 12; i++) cv = (i == lane) ? sv.cnt[i] : cv;
+    res.coeff[FH_MAX_SEG - 2][lane] = (double)cv;
+  }
+#endif
   if (lane < FH_MAX_SEG) res.assign[lane] = (solved && lane < sv.N && sv.P > 0) ? (int8_t)sv.bestassign[lane] : (int8_t)-1;
   if (lane == 0) {
     res.solved = solved ? 1 : 0;
@@ -998,7 +1135,7 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
 }
 
 template <int NSEG>
-__global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ gfaces,
+__global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ gfaces,
                                                    int n_problems, int max_faces, fh_params par, double* __restrict__ workspace,
                                                    unsigned int* __restrict__ next_problem, fh_result* __restrict__ results) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1006,7 +1143,7 @@ __global__ void __launch_bounds__(64) solve_kernel(const fh_problem* __restrict_
   sv.carve(smem, max_faces);
   sv.lane = threadIdx.x;
   sv.q = 0;
-  double* ws = workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_DOUBLES;
+  double* ws = workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   for (;;) {
     unsigned int b = 0;
     if (threadIdx.x == 0) b = atomicAdd(next_problem, 1u);
