@@ -27,6 +27,8 @@ struct fh_ctx {
   void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
+  unsigned long long ticket_base = 0;  // tickets handed out by all previous solve launches of this context
+  size_t lds_attr[3] = {0, 0, 0};      // largest dynamic-LDS size already set per kernel instantiation
 };
 
 #define FH_HIP(call)                                                                            \
@@ -62,8 +64,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // slot 5: snapshot workspace (one slot per tree level per workgroup), slot 6: the work counter
   int rc;
   if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_PADDED)) != FH_OK) return rc;
-  if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
-  FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 4, ctx->stream));
+  if (!ctx->d_buf[6]) {  // the ticket counter: zeroed once, never reset (see solve_kernel)
+    if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
+    FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 256, ctx->stream));
+    ctx->ticket_base = 0;
+  }
   FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if (ctx->ev_used + 2 > ctx->ev.size()) {
     if (ctx->ev.size() >= 8192) ctx->ev_used = 0;  // ring: keep the most recent launches only
@@ -77,7 +82,8 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, n, max_faces, ctx->par,
-                     (double*)ctx->d_buf[5], (unsigned int*)ctx->d_buf[6], d_results);
+                     (double*)ctx->d_buf[5], (unsigned long long*)ctx->d_buf[6], ctx->ticket_base, d_results);
+  ctx->ticket_base += (unsigned long long)n + (unsigned long long)grid;
   FH_HIP(hipGetLastError());
   FH_HIP(hipEventRecord(e1, ctx->stream));
   ctx->ev_used += 2;

@@ -1137,7 +1137,8 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
 template <int NSEG>
 __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ gfaces,
                                                    int n_problems, int max_faces, fh_params par, double* __restrict__ workspace,
-                                                   unsigned int* __restrict__ next_problem, fh_result* __restrict__ results) {
+                                                   unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
+                                                   fh_result* __restrict__ results) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Solver<NSEG> sv;
   sv.carve(smem, max_faces);
@@ -1145,8 +1146,10 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
   sv.q = 0;
   double* ws = workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   for (;;) {
+    // tickets only ever grow: this launch owns [ticket_base, ticket_base + n_problems); every workgroup draws exactly one
+    // ticket beyond that range when it leaves, so the host knows the next launch's base without resetting anything
     unsigned int b = 0;
-    if (threadIdx.x == 0) b = atomicAdd(next_problem, 1u);
+    if (threadIdx.x == 0) b = (unsigned int)min(atomicAdd(ticket, 1ull) - ticket_base, (unsigned long long)n_problems);
     b = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
     if (b >= (unsigned int)n_problems) break;
     solve_one<NSEG>(sv, problems[b], gfaces, max_faces, par, ws, results[b]);

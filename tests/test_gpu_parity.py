@@ -181,3 +181,136 @@ def test_pair_pipeline_device_pointers(ctx, oracle):
     compare(sres, sref)
     check_assignment_valid(safe, sfaces, sres)
     assert 0.3 < sres["solved"].mean() <= 1.0
+
+
+def test_maximum_sizes(ctx, oracle):
+    """N = FH_MAX_SEG = 16 segments, P = FH_MAX_POLY = 8 polytopes (the NSEG=16 kernel instantiation)."""
+    pr, faces, _ = corridor.whole_batch(48, seed=41, n_seg=abi.FH_MAX_SEG, p_choices=(abi.FH_MAX_POLY,))
+    got = ctx.solve_batch(pr, faces)
+    ref = oracle.solve_batch(pr, faces)
+    ok = compare(got, ref)
+    assert ok.sum() >= 24
+    check_assignment_valid(pr, faces, got)
+
+
+def test_mixed_sizes_in_one_batch(ctx, oracle):
+    """Ragged batch: different N, P, face counts and whole/safe problems in one launch."""
+    parts = [corridor.whole_batch(40, seed=51, n_seg=4, p_choices=(1, 2))[:2],
+             corridor.safe_batch(40, seed=52, n_seg=7, p_choices=(1, 2, 3))[:2],
+             corridor.whole_batch(40, seed=53, n_seg=10, p_choices=(5, 6))[:2],
+             corridor.whole_batch(20, seed=54, n_seg=13, p_choices=(3, 7))[:2]]
+    pr, faces = corridor.concat(parts)
+    perm = np.random.default_rng(5).permutation(len(pr))
+    pr = pr[perm]
+    got = ctx.solve_batch(pr, faces)
+    ref = oracle.solve_batch(pr, faces)
+    compare(got, ref)
+
+
+def test_many_faces_and_degenerate_rows(ctx, oracle):
+    """Polytopes padded with redundant faces up to FH_MAX_FACES_POLY, duplicated faces, and zero-normal rows
+    (0 <= b: harmless when b >= 0, excludes the polytope when b < 0)."""
+    pr, faces, _ = corridor.whole_batch(24, seed=61, n_seg=8, p_choices=(2, 3))
+    rng = np.random.default_rng(61)
+    batches = []
+    for i in range(len(pr)):
+        fb = int(pr["face_begin"][i])
+        polys = []
+        for p in range(int(pr["n_poly"][i])):
+            f0, f1 = fb + pr["face_off"][i][p], fb + pr["face_off"][i][p + 1]
+            A, b = faces["a"][f0:f1].copy(), faces["b"][f0:f1].copy()
+            extra = abi.FH_MAX_FACES_POLY - len(b) if (i % 3 == 0 and p == 0) else 3
+            idx = rng.integers(0, len(b), size=extra)
+            A2 = np.vstack([A, A[idx] * rng.uniform(0.5, 2.0, size=(extra, 1))])      # scaled copies: same half-spaces
+            b2 = np.concatenate([b, b[idx] * (np.linalg.norm(A2[len(b):], axis=1) / np.linalg.norm(A[idx], axis=1)) + rng.uniform(0, 0.5, size=extra)])
+            if i % 4 == 1:                      # harmless zero-normal row
+                A2 = np.vstack([A2, np.zeros((1, 3))]); b2 = np.append(b2, 0.25)
+            if i % 8 == 2 and p == 1:           # infeasible zero-normal row: polytope p can never be used
+                A2 = np.vstack([A2, np.zeros((1, 3))]); b2 = np.append(b2, -0.25)
+            polys.append((A2, b2))
+        f, off = abi.pack_faces(polys)
+        q = pr[i: i + 1].copy()
+        q["face_begin"] = 0
+        q["face_off"][0, : len(off)] = off
+        q["face_off"][0, len(off):] = off[-1]
+        batches.append((q, f))
+    pr2, faces2 = corridor.concat(batches)
+    got = ctx.solve_batch(pr2, faces2)
+    ref = oracle.solve_batch(pr2, faces2)
+    compare(got, ref)
+
+
+def test_limits_and_params(oracle):
+    """fh_set_params: node / iteration caps are reported, never hang; a looser feas_tol is honoured."""
+    import torch  # noqa: F401
+    from faster_amd import capi
+
+    c = capi.Context(0)
+    pr, faces, _ = corridor.whole_batch(64, seed=71, p_choices=(5, 6))
+    par = abi.default_params()
+    par["max_nodes"] = 2
+    c.set_params(par)
+    got = c.solve_batch(pr, faces)
+    ref = oracle.solve_batch(pr, faces, params=par)
+    assert set(np.unique(got["status"])) <= {abi.FH_ST_OPTIMAL, abi.FH_ST_NODE_LIMIT, abi.FH_ST_INFEASIBLE}
+    assert (got["status"] == abi.FH_ST_NODE_LIMIT).any()
+    assert np.all(got["solved"][got["status"] == abi.FH_ST_NODE_LIMIT] == 0)
+    assert (ref["status"] == abi.FH_ST_NODE_LIMIT).any()
+    par = abi.default_params()
+    par["max_iters"] = 3
+    c.set_params(par)
+    got = c.solve_batch(pr, faces)
+    assert (got["status"] == abi.FH_ST_ITER_LIMIT).any() and np.all(got["solved"][got["status"] == abi.FH_ST_ITER_LIMIT] == 0)
+    par = abi.default_params()
+    par["feas_tol"] = 1e-6      # Gurobi's FeasibilityTol
+    c.set_params(par)
+    got = c.solve_batch(pr, faces)
+    ref = oracle.solve_batch(pr, faces, params=par)
+    compare(got, ref, cost_rtol=1e-5, coeff_atol=1e-4)
+    with pytest.raises(capi.FasterHipError):
+        bad = abi.default_params()
+        bad["feas_tol"] = 0.0
+        c.set_params(bad)
+    c.close()
+
+
+def test_two_contexts_two_streams(oracle):
+    """Handles are independent: two contexts on two HIP streams solving different batches concurrently."""
+    import torch
+    from faster_amd import capi
+
+    c1, c2 = capi.Context(0), capi.Context(0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    c1.set_stream(s1.cuda_stream)
+    c2.set_stream(s2.cuda_stream)
+    b1 = corridor.whole_batch(512, seed=81)[:2]
+    b2 = corridor.safe_batch(512, seed=82, n_seg=10, p_choices=(1, 2, 3))[:2]
+    outs = []
+    for rep in range(3):  # repeated launches on the same contexts (the work counter is never reset)
+        d = []
+        for c, (pr, faces) in ((c1, b1), (c2, b2)):
+            n = len(pr)
+            mf = int(pr["face_off"][np.arange(n), pr["n_poly"]].max())
+            dp, df = _dev(pr), _dev(faces)
+            dr = torch.zeros(n * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+            c.solve_batch_device(dp.data_ptr(), df.data_ptr(), n, int(pr["n_seg"].max()), mf, dr.data_ptr())
+            d.append((dp, df, dr))
+        c1.sync(); c2.sync()
+        outs = [x[2].cpu().numpy().view(abi.result_dtype) for x in d]
+    compare(outs[0], oracle.solve_batch(*b1))
+    compare(outs[1], oracle.solve_batch(*b2))
+    c1.close(); c2.close()
+
+
+def test_sample_capacity_and_unsolved(ctx, oracle):
+    """fh_sample_batch: counts report the full size even when max_samples truncates; unsolved problems give 0."""
+    pr, faces, _ = corridor.whole_batch(16, seed=91)
+    pr = pr.copy()
+    pr["x0"][0, 3] = 9.0   # infeasible start
+    res = ctx.solve_batch(pr, faces)
+    states, counts = ctx.sample_batch(pr, res, 10)
+    assert counts[0] == 0 and res["solved"][0] == 0
+    for i in range(1, len(pr)):
+        full = oracle.sample(pr[i], res[i])
+        assert counts[i] == full.shape[0] > 10
+        np.testing.assert_allclose(states[i]["pos"], full[:10]["pos"], atol=1e-11)
