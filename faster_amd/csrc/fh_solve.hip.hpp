@@ -193,13 +193,14 @@ struct Solver {
   static constexpr int NVP = (NV + 7) & ~7;  // vectors / factor rows padded with zeros to a multiple of 8
   static constexpr int S = NVP + 1;          // odd row stride: conflict-free column AND row sweeps with ds_read_b64
   static constexpr int NT = NSEG + 1;
+  static constexpr int RPSZ = NVP * (NVP + 1) / 2;  // R is packed upper triangular, column major: R(r, c) = R[c(c+1)/2 + r]
+  static __device__ __forceinline__ int rp(int r_, int c_) { return (c_ * (c_ + 1)) / 2 + r_; }
 
   // ---- LDS carve (doubles first) ----
-  double *Q, *R;                                      // [NVP][S]: Q1 (column c = active slot), R upper triangular
+  double *Q, *R;                                      // Q1 [NVP][S] (column c = active slot); R packed upper triangular [RPSZ]
   double *x, *z, *g, *d, *r, *u, *rinv, *bestx;       // [NVP]
   double *P0, *V0, *A0, *Pc, *Vc, *Ac;                // [NT*3] jerk-free / current states at segment starts
   double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
-  double* wn;                                         // [W_KINDS][NT] row-norm factors sqrt(sum_m wcoef^2)
   double* wni;                                        // [W_KINDS][NT] their inverses (0 where the factor is 0)
   double* viol;                                       // [NSEG][FH_MAX_POLY]
   double* xfl;                                        // [9] goal state (+3 pad)
@@ -210,8 +211,7 @@ struct Solver {
   int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_order, *face_off;
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (2 * NVP * S + 3 * NVP + NSEG * 4 + NVP + 5 * NVP + 6 * NT * 3 + NSEG * 12 + 2 * W_KINDS * NT +
-                             NSEG * FH_MAX_POLY + 12) +
+    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NSEG * 4 + NVP + 5 * NVP + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + 12) +
            sizeof(int) * (7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 1 + 3) + (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
   }
 
@@ -230,7 +230,7 @@ struct Solver {
 
   // The dual active-set state that a branch-and-bound node inherits is one contiguous LDS block, so that it can be
   // snapshotted to / restored from the per-workgroup HBM workspace with linear 16-B-per-lane copies.
-  static constexpr int SNAP_DOUBLES = 2 * NVP * S + 3 * NVP + NSEG * 4 + NVP;  // Q, R, x, u, rinv, polyact, act+boxact
+  static constexpr int SNAP_DOUBLES = NVP * S + RPSZ + 3 * NVP + NSEG * 4 + NVP;  // Q, R, x, u, rinv, polyact, act+boxact
   static_assert(SNAP_DOUBLES % 2 == 0, "snapshot is copied as double2");
 
   // Fixed-size arrays first (compile-time LDS offsets that fold into the ds_read/ds_write immediates and cost no
@@ -238,7 +238,7 @@ struct Solver {
   __device__ void carve(unsigned char* base, int max_faces) {
     double* p = reinterpret_cast<double*>(base);
     Q = p; p += NVP * S;
-    R = p; p += NVP * S;
+    R = p; p += RPSZ;
     x = p; p += NVP;  u = p; p += NVP;  rinv = p; p += NVP;
     polyact = reinterpret_cast<unsigned long long*>(p); p += NSEG * 4;
     act = reinterpret_cast<int*>(p); boxact = act + NVP; p += NVP;
@@ -247,9 +247,9 @@ struct Solver {
     P0 = p; p += NT * 3;  V0 = p; p += NT * 3;  A0 = p; p += NT * 3;
     Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
     CP = p; p += NSEG * 12;
-    wn = p; p += W_KINDS * NT;
     wni = p; p += W_KINDS * NT;
-    viol = p; p += NSEG * FH_MAX_POLY;
+    viol = z;  // [NSEG][FH_MAX_POLY] aliases z,g,d,r: only live between two active-set runs (analyze, init_equalities)
+    static_assert(NSEG * FH_MAX_POLY <= 4 * NVP && 3 * NT + 9 <= 4 * NVP, "viol / equality scratch must fit in z,g,d,r");
     xfl = p; p += 12;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
@@ -293,7 +293,8 @@ struct Solver {
   // Invariant kept by reset_qp/add_row/drop_row: Q[i][c] == 0 for i >= n or c >= q, and g, d, z, x are zero
   // beyond n (resp. q), so that the factor sweeps below can run in unpredicated blocks of 8.
   __device__ void init_problem() {
-    for (int i = lane; i < NVP * S; i += 64) { Q[i] = 0.0; R[i] = 0.0; }
+    for (int i = lane; i < NVP * S; i += 64) Q[i] = 0.0;
+    for (int i = lane; i < RPSZ; i += 64) R[i] = 0.0;
     if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; r[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; boxact[lane] = 0; }
     q = 0;
     FH_SYNC();
@@ -318,7 +319,6 @@ struct Solver {
         s += c * c;
       }
       const double w = sqrt(s);
-      wn[idx] = w;
       wni[idx] = w > 0.0 ? 1.0 / w : 0.0;
     }
     FH_SYNC();
@@ -512,10 +512,10 @@ struct Solver {
     const int ll = lane < NVP ? lane : NVP - 1;
     const double ri = (lane < q) ? rinv[lane] : 0.0;
     double dcur = dc;
-    const double* Rr = R + ll * S;
     int c = q - 1;
     for (; c >= 3; c -= 4) {  // the four R loads do not depend on the recurrence: issue them first
-      const double r0 = Rr[c], r1 = Rr[c - 1], r2 = Rr[c - 2], r3 = Rr[c - 3];
+      const double r0 = R[rp(min(ll, c), c)], r1 = R[rp(min(ll, c - 1), c - 1)], r2 = R[rp(min(ll, c - 2), c - 2)],
+                   r3 = R[rp(min(ll, c - 3), c - 3)];
       double val = readlane_f64(dcur * ri, c);
       if (lane == c) rc = val;
       if (lane < c) dcur -= r0 * val;
@@ -530,7 +530,7 @@ struct Solver {
       if (lane < c - 3) dcur -= r3 * val;
     }
     for (; c >= 0; c--) {
-      const double r0 = Rr[c];
+      const double r0 = R[rp(min(ll, c), c)];
       const double val = readlane_f64(dcur * ri, c);
       if (lane == c) rc = val;
       if (lane < c) dcur -= r0 * val;
@@ -559,9 +559,9 @@ struct Solver {
     const double rho = sqrt(zz);
     const double inv = 1.0 / rho;
     if (lane < n) Q[lane * S + q] = zi * inv;
-    if (lane < q) R[lane * S + q] = dc;
+    if (lane < q) R[rp(lane, q)] = dc;
     if (lane == q) {
-      R[q * S + q] = rho;
+      R[rp(q, q)] = rho;
       rinv[q] = inv;
       act[q] = id;
       u[q] = up;
@@ -580,19 +580,19 @@ struct Solver {
     if (lane >= kpos && lane < q - 1) { a_next = act[lane + 1]; u_next = u[lane + 1]; }
     FH_SYNC();
     if (lane >= kpos && lane < q - 1) { act[lane] = a_next; u[lane] = u_next; }
-    if (lane < q)
-      for (int c = kpos; c < q - 1; c++) R[lane * S + c] = R[lane * S + c + 1];
     FH_SYNC();
-    for (int j = kpos; j < q - 1; j++) {  // Givens: zero R[j+1][j]
-      const double a = R[j * S + j], b = R[(j + 1) * S + j];
+    // Givens rotations applied in place to the OLD columns k+1..q-1 (old column c+1 becomes new column c), then the
+    // columns are compacted one slot to the left.
+    for (int j = kpos; j < q - 1; j++) {  // zero element (j+1) of old column j+1 against element j
+      const double a = R[rp(j, j + 1)], b = R[rp(j + 1, j + 1)];
       const double rr = sqrt(a * a + b * b);
       if (rr != 0.0) {
         const double irr = 1.0 / rr;
         const double cs = a * irr, sn = b * irr;
         if (lane >= j && lane < q - 1) {
-          const double t1 = R[j * S + lane], t2 = R[(j + 1) * S + lane];
-          R[j * S + lane] = cs * t1 + sn * t2;
-          R[(j + 1) * S + lane] = -sn * t1 + cs * t2;
+          const double t1 = R[rp(j, lane + 1)], t2 = R[rp(j + 1, lane + 1)];
+          R[rp(j, lane + 1)] = cs * t1 + sn * t2;
+          R[rp(j + 1, lane + 1)] = -sn * t1 + cs * t2;
         }
         if (lane < n) {
           const double t1 = Q[lane * S + j], t2 = Q[lane * S + j + 1];
@@ -602,7 +602,14 @@ struct Solver {
       }
       FH_SYNC();
     }
-    if (lane >= kpos && lane < q - 1) rinv[lane] = 1.0 / R[lane * S + lane];
+    for (int c = kpos; c < q - 1; c++) {  // new column c <- old column c+1 (rows 0..c)
+      double v = 0.0;
+      if (lane <= c) v = R[rp(lane, c + 1)];
+      FH_SYNC();
+      if (lane <= c) R[rp(lane, c)] = v;
+      FH_SYNC();
+    }
+    if (lane >= kpos && lane < q - 1) rinv[lane] = 1.0 / R[rp(lane, lane)];
     if (lane < NVP) Q[lane * S + q - 1] = 0.0;  // keep the zero padding beyond the active columns
     q--;
     FH_SYNC();
@@ -722,10 +729,10 @@ struct Solver {
           for (int jj = 0; jj < 3; jj++)
             if (acc[jj] && rank[jj] == rk2) v = (j == 0) ? ro[jj][0] : (j == 1 ? ro[jj][1] : ro[jj][2]);
         }
-        R[c2 * S + lane] = v;
+        R[rp(c2, lane)] = v;
       }
       const double dg = j == 0 ? rd[0] : (j == 1 ? rd[1] : rd[2]);
-      R[lane * S + lane] = dg;
+      R[rp(lane, lane)] = dg;
       rinv[lane] = 1.0 / dg;
       act[lane] = mk_id(K_EQ, 0, 0, i * 3 + j + koff);
       u[lane] = 0.0;
