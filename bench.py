@@ -85,7 +85,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    from faster_amd import abi, capi, corridor
+    from faster_amd import abi, capi, corridor, shard
 
     B, N = args.pairs, args.n_seg
     whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(2, args.max_poly + 1)))
@@ -130,9 +130,7 @@ def main():
         c.solve_batch_device(pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), B, N, max_faces, pp.d_sres.data_ptr())
         if world > 1:  # batch gather of the per-pair summaries (whole cost, safe cost) over RCCL/xGMI
             with torch.cuda.stream(pp.stream):
-                sw = pp.d_sres.view(torch.float64).view(B, res_words)[:, 5]
-                ww = pp.d_wres.view(torch.float64).view(B, res_words)[:, 5]
-                dist.all_gather_into_tensor(pp.gather.view(world * B, 2), torch.stack([ww, sw], dim=1))
+                shard.gather_step_summaries(dist, pp.d_wres, pp.d_sres, B, pp.gather.view(world * B, 2))
 
     def fence():
         torch.cuda.synchronize()

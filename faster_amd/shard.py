@@ -47,3 +47,19 @@ def all_gather_rows(dist, local, per_rank):
     out = torch.zeros((world * per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad)
     return out
+
+
+def gather_step_summaries(dist, whole_results, safe_results, n, out):
+    """The per-step "batch gather" of bench.py: every rank contributes (whole cost, safe cost) of its n pairs; `out` is
+    [world*n, 2].  whole_results / safe_results are uint8 tensors holding n `fh_result` records (device tensors with the
+    nccl backend = RCCL over xGMI; CPU tensors with gloo in the tests).  Runs on the current stream."""
+    import torch
+
+    from . import abi
+
+    words = abi.result_dtype.itemsize // 8
+    cost_word = abi.result_dtype.fields["cost"][1] // 8
+    ww = whole_results.view(torch.float64).view(n, words)[:, cost_word]
+    sw = safe_results.view(torch.float64).view(n, words)[:, cost_word]
+    dist.all_gather_into_tensor(out, torch.stack([ww, sw], dim=1))
+    return out

@@ -27,6 +27,19 @@ res = oracle.solve_batch(lpr, lfaces, threads=2)
 per = -(-len(pr) // world)
 g = shard.all_gather_rows(dist, torch.from_numpy(shard.summaries(res)), per)
 dist.barrier()
+# the per-step gather of bench.py (same function, CPU tensors + gloo here, device tensors + RCCL on the GPUs)
+from faster_amd import abi
+wt = torch.from_numpy(res.view(np.uint8).reshape(-1).copy())
+out = torch.zeros((world * len(res), 2), dtype=torch.float64)
+if len(set(dist_sizes := [shard.shard_range(len(pr), r, world)[1] - shard.shard_range(len(pr), r, world)[0] for r in range(world)])) == 1:
+    shard.gather_step_summaries(dist, wt, wt, len(res), out)
+else:  # uneven shards: pad to the common size as bench.py's equal per-rank batches never need to
+    pad = np.zeros(per, dtype=abi.result_dtype); pad[: len(res)] = res
+    wt = torch.from_numpy(pad.view(np.uint8).reshape(-1).copy())
+    out = torch.zeros((world * per, 2), dtype=torch.float64)
+    shard.gather_step_summaries(dist, wt, wt, per, out)
+    mine = out[rank * per: rank * per + len(res)].numpy()
+    assert np.array_equal(mine[:, 0], res["cost"]) and np.array_equal(mine[:, 1], res["cost"])
 if rank == 0:
     full = oracle.solve_batch(pr, faces, threads=2)
     got = np.concatenate([g[r * per: r * per + (shard.shard_range(len(pr), r, world)[1] - shard.shard_range(len(pr), r, world)[0])].numpy() for r in range(world)])
