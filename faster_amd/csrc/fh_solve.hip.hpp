@@ -197,7 +197,7 @@ struct Solver {
   static __device__ __forceinline__ int rp(int r_, int c_) { return (c_ * (c_ + 1)) / 2 + r_; }
 
   // ---- LDS carve (doubles first) ----
-  double *Q, *R;                                      // Q1 [NVP][S] (column c = active slot); R packed upper triangular [RPSZ]
+  double *Q, *R;                                      // Q1 column major [NVP cols][S] (column c = active slot); R packed upper triangular [RPSZ]
   double *x, *z, *g, *d, *r, *u, *rinv, *bestx;       // [NVP]
   double *P0, *V0, *A0, *Pc, *Vc, *Ac;                // [NT*3] jerk-free / current states at segment starts
   double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
@@ -230,8 +230,6 @@ struct Solver {
 
   // The dual active-set state that a branch-and-bound node inherits is one contiguous LDS block, so that it can be
   // snapshotted to / restored from the per-workgroup HBM workspace with linear 16-B-per-lane copies.
-  static constexpr int SNAP_DOUBLES = NVP * S + RPSZ + 3 * NVP + NSEG * 4 + NVP;  // Q, R, x, u, rinv, polyact, act+boxact
-  static_assert(SNAP_DOUBLES % 2 == 0, "snapshot is copied as double2");
 
   // Fixed-size arrays first (compile-time LDS offsets that fold into the ds_read/ds_write immediates and cost no
   // SGPRs), the two arrays sized by the batch's face bound last.
@@ -262,31 +260,53 @@ struct Solver {
   }
 
   // ---- node state snapshots (HBM workspace, one slot per tree level; L2-resident in practice) ----
-  // Copies run in full 64-lane steps of 16 B (no per-step predicates): the tail of the last step spills into the
-  // scratch vectors that follow the block in LDS (z, g, ...), which is harmless in both directions.
-  static constexpr int SNAP_STEPS = (SNAP_DOUBLES / 2 + 63) / 64;
-  static constexpr int SNAP_PADDED = SNAP_STEPS * 128;  // doubles per workspace slot
-  static_assert(SNAP_PADDED - SNAP_DOUBLES <= 4 * NVP, "snapshot tail must stay inside the scratch vectors z, g, d, r");
+  // A snapshot holds only what is live: the first q columns of Q1 (contiguous: column major), the first q columns of the
+  // packed R, and the fixed tail (x, u, 1/diag, active masks).  Workspace slot: [tail | Q | R], each padded for the
+  // 16-B-per-lane copy granularity.
+  static constexpr int SNAP_TAIL = 3 * NVP + NSEG * 4 + NVP;
+  static constexpr int SNAP_QOFF = (SNAP_TAIL + 127) & ~127;
+  static constexpr int SNAP_ROFF = SNAP_QOFF + ((NVP * S + 127) & ~127) + 128;
+  static constexpr int SNAP_PADDED = SNAP_ROFF + ((RPSZ + 127) & ~127) + 128;  // doubles per workspace slot
+  __device__ __forceinline__ void copy_out(double* __restrict__ dst, const double* src, int count) const {
+    const int n2 = (count + 1) >> 1;
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    for (int i = lane; i < n2; i += 64) d2[i] = s2[i];
+  }
+  __device__ __forceinline__ void copy_in(double* dst, const double* __restrict__ src, int count) const {
+    const int n2 = (count + 1) >> 1;
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    for (int i0 = 0; i0 < n2; i0 += 256) {  // four 1-KiB loads in flight before the first LDS store
+      double2 t[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int i = i0 + j * 64 + lane;
+        t[j] = s2[i < n2 ? i : 0];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int i = i0 + j * 64 + lane;
+        if (i < n2) d2[i] = t[j];  // same lane <-> same words as the save
+      }
+    }
+  }
   __device__ void snapshot_save(double* __restrict__ ws_level) {
     FH_SYNC();
-    const double2* src = reinterpret_cast<const double2*>(Q) + lane;
-    double2* dst = reinterpret_cast<double2*>(ws_level) + lane;
-#pragma unroll
-    for (int k = 0; k < SNAP_STEPS; k++) dst[k * 64] = src[k * 64];
+    copy_out(ws_level, x, SNAP_TAIL);
+    copy_out(ws_level + SNAP_QOFF, Q, q * S);
+    copy_out(ws_level + SNAP_ROFF, R, (q * (q + 1)) / 2);
   }
-  __device__ void snapshot_restore(const double* __restrict__ ws_level) {
+  // q_saved: number of active rows in the snapshot; the current q may be larger (columns to clear) or smaller
+  __device__ void snapshot_restore(const double* __restrict__ ws_level, int q_saved) {
     FH_SYNC();
-    double2* dst = reinterpret_cast<double2*>(Q) + lane;
-    const double2* src = reinterpret_cast<const double2*>(ws_level) + lane;
-    constexpr int CH = 6;  // loads in flight per chunk (bounded register footprint)
-    for (int k0 = 0; k0 < SNAP_STEPS; k0 += CH) {
-      double2 tmp[CH];
-#pragma unroll
-      for (int j = 0; j < CH; j++) tmp[j] = src[(k0 + j < SNAP_STEPS ? k0 + j : SNAP_STEPS - 1) * 64];
-#pragma unroll
-      for (int j = 0; j < CH; j++)
-        if (k0 + j < SNAP_STEPS) dst[(k0 + j) * 64] = tmp[j];  // same lane <-> same words as the save
-    }
+    if (lane < NVP)
+      for (int c = q_saved; c < q; c++) Q[c * S + lane] = 0.0;  // keep the zero padding beyond the active columns
+    FH_SYNC();
+    copy_in(Q, ws_level + SNAP_QOFF, q_saved * S);
+    copy_in(R, ws_level + SNAP_ROFF, (q_saved * (q_saved + 1)) / 2);
+    copy_in(x, ws_level, SNAP_TAIL);
+    q = q_saved;
     FH_SYNC();
   }
 
@@ -455,7 +475,8 @@ struct Solver {
     return wave_sum(gv * gv);
   }
 
-  // column sweep: sum_i Q[i][col] * v[i] over the padded length n8 (two accumulators, 8 loads in flight)
+  // Q1 is stored COLUMN major, Q(i, c) = Q[c * S + i] (the live columns are a contiguous prefix: cheap node snapshots).
+  // strided sweep: sum_k M[k * S + col] * v[k] over the padded length n8 (two accumulators, 8 loads in flight)
   __device__ __forceinline__ double col_dot(const double* __restrict__ M, int col, const double* __restrict__ v, int n8) const {
     double a0 = 0, a1 = 0;
     for (int i0 = 0; i0 < n8; i0 += 8) {
@@ -467,7 +488,7 @@ struct Solver {
     }
     return a0 + a1;
   }
-  // row sweep: sum_c Q[row][c] * v[c] over the padded length q8
+  // contiguous sweep: sum_k M[row * S + k] * v[k] over the padded length q8
   __device__ __forceinline__ double row_dot(const double* __restrict__ M, int row, const double* __restrict__ v, int q8) const {
     double a0 = 0, a1 = 0;
     const double* Mr = M + row * S;
@@ -486,20 +507,20 @@ struct Solver {
   __device__ double project(double gg, double& dc, double& zi) {
     const int n8 = (n + 7) & ~7, q8 = (q + 7) & ~7;
     const int ll = lane < NVP ? lane : NVP - 1;  // lanes beyond the padded size compute a harmless duplicate
-    dc = col_dot(Q, ll, g, n8);
+    dc = row_dot(Q, ll, g, n8);
     if (lane < NVP) d[lane] = dc;
     FH_SYNC();
-    zi = g[ll] - row_dot(Q, ll, d, q8);
+    zi = g[ll] - col_dot(Q, ll, d, q8);
     if (lane >= NVP) zi = 0.0;
     double zz = wave_sum(zi * zi);
     if (zz < 0.5 * gg) {
       if (lane < NVP) z[lane] = zi;
       FH_SYNC();
-      const double ec = col_dot(Q, ll, z, n8);
+      const double ec = row_dot(Q, ll, z, n8);
       dc += ec;
       if (lane < NVP) r[lane] = ec;
       FH_SYNC();
-      zi -= row_dot(Q, ll, r, q8);
+      zi -= col_dot(Q, ll, r, q8);
       if (lane >= NVP) zi = 0.0;
       zz = wave_sum(zi * zi);
     }
@@ -558,7 +579,7 @@ struct Solver {
   __device__ void add_row(int id, double zi, double zz, double dc, double up) {
     const double rho = sqrt(zz);
     const double inv = 1.0 / rho;
-    if (lane < n) Q[lane * S + q] = zi * inv;
+    if (lane < n) Q[q * S + lane] = zi * inv;
     if (lane < q) R[rp(lane, q)] = dc;
     if (lane == q) {
       R[rp(q, q)] = rho;
@@ -595,9 +616,9 @@ struct Solver {
           R[rp(j + 1, lane + 1)] = -sn * t1 + cs * t2;
         }
         if (lane < n) {
-          const double t1 = Q[lane * S + j], t2 = Q[lane * S + j + 1];
-          Q[lane * S + j] = cs * t1 + sn * t2;
-          Q[lane * S + j + 1] = -sn * t1 + cs * t2;
+          const double t1 = Q[j * S + lane], t2 = Q[(j + 1) * S + lane];
+          Q[j * S + lane] = cs * t1 + sn * t2;
+          Q[(j + 1) * S + lane] = -sn * t1 + cs * t2;
         }
       }
       FH_SYNC();
@@ -610,14 +631,14 @@ struct Solver {
       FH_SYNC();
     }
     if (lane >= kpos && lane < q - 1) rinv[lane] = 1.0 / R[rp(lane, lane)];
-    if (lane < NVP) Q[lane * S + q - 1] = 0.0;  // keep the zero padding beyond the active columns
+    if (lane < NVP) Q[(q - 1) * S + lane] = 0.0;  // keep the zero padding beyond the active columns
     q--;
     FH_SYNC();
   }
 
   __device__ void reset_qp() {
     if (lane < NVP) {
-      for (int c = 0; c < q; c++) Q[lane * S + c] = 0.0;  // columns >= q are zero already
+      for (int c = 0; c < q; c++) Q[c * S + lane] = 0.0;  // columns >= q are zero already
       x[lane] = 0;
       boxact[lane] = 0;
     }
@@ -711,7 +732,7 @@ struct Solver {
         if (acc[j]) {
           const double qv = eqq[j * NT + s];
           xv += qv * eqy[j * 3 + i];
-          Q[lane * S + i * cnt + rank[j]] = qv;
+          Q[(i * cnt + rank[j]) * S + lane] = qv;
         }
       x[lane] = xv;
     }
@@ -975,8 +996,7 @@ struct Solver {
         if (nx < stk_cnt[d_]) {
           FH_SYNC();
           if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
-          { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED); FH_T1(11); }  // sibling: restart from the parent's optimum, not from scratch
-          q = stk_q[d_];
+          { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED, stk_q[d_]); FH_T1(11); }  // sibling: restart from the parent's optimum, not from scratch
           have_node = true;
           break;
         }
