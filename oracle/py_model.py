@@ -142,3 +142,42 @@ def enumerate_miqp(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, candidat
         if s[0] < best:
             best, barg = s[0], tuple(a)
     return best, barg, nfeas
+
+
+def milp_feasible(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, big_m=1.0e3, time_limit=60.0):
+    """Feasibility of the reference's mixed-integer constraint set at one dt, decided by an independent third-party
+    branch-and-cut code (HiGHS through scipy.optimize.milp): 12N coefficients + one binary per (segment, polytope),
+    sum_p b[t][p] == 1, and the indicator rows of setPolytopesConstraints (:283-286) written with a big-M.
+    Returns True / False (None if HiGHS hits its limits).  Objective: none (feasibility only)."""
+    from scipy.optimize import Bounds, LinearConstraint, milp
+
+    P = len(polys)
+    nc = 12 * N
+    nv = nc + N * P
+    Aeq, beq, Ain, bin_ = build(N, dt, x0, xf, vmax, amax, jmax, force_final, [], None)
+    rows, lo, hi = [], [], []
+    for a, b in zip(Aeq, beq):
+        rows.append(np.concatenate([a, np.zeros(N * P)])); lo.append(b); hi.append(b)
+    for a, b in zip(Ain, bin_):
+        rows.append(np.concatenate([a, np.zeros(N * P)])); lo.append(-np.inf); hi.append(b)
+    for t in range(N):
+        r = np.zeros(nv)
+        r[nc + t * P: nc + (t + 1) * P] = 1.0
+        rows.append(r); lo.append(1.0); hi.append(1.0)
+        for p, (A, b) in enumerate(polys):
+            for f in range(len(b)):
+                for k in range(4):
+                    r = np.zeros(nv)
+                    r[:nc] = sum(A[f][i] * _cp(t, k, i, N, dt) for i in range(3))
+                    r[nc + t * P + p] = big_m          # a.cp <= b + M (1 - b_tp)
+                    rows.append(r); lo.append(-np.inf); hi.append(b[f] + big_m)
+    cons = LinearConstraint(np.array(rows), np.array(lo), np.array(hi))
+    integrality = np.concatenate([np.zeros(nc), np.ones(N * P)])
+    bounds = Bounds(np.concatenate([np.full(nc, -1e4), np.zeros(N * P)]), np.concatenate([np.full(nc, 1e4), np.ones(N * P)]))
+    res = milp(c=np.zeros(nv), constraints=cons, integrality=integrality, bounds=bounds,
+               options={"time_limit": time_limit, "presolve": True})
+    if res.status == 0:
+        return True
+    if res.status == 2:
+        return False
+    return None

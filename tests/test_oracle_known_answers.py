@@ -97,3 +97,16 @@ def test_sampling_matches_fillx_semantics(oracle, fixture_corridor, known_answer
     np.testing.assert_allclose(X[0]["pos"], co[0:3] * tau**3 + co[3:6] * tau**2 + co[6:9] * tau + co[9:12], rtol=0, atol=1e-14)
     assert np.all(X[-1]["vel"] == 0) and np.all(X[-1]["accel"] == 0) and np.all(X[-1]["jerk"] == 0)
     assert np.all(X[-2]["jerk"] == 6 * r["coeff"][c["N"] - 1][0:3])
+
+
+def test_fixture_first_feasible_factor_against_highs(oracle, fixture_corridor, known_answers):
+    """KA-1 on the reference's corridor: HiGHS (scipy.optimize.milp, big-M indicators on the unreduced variables) finds the
+    constraint set infeasible at factors 1 and 2 and feasible at factor 3 — the `trials_`/`factor_that_worked_` the oracle reports."""
+    from oracle import py_model
+
+    c = known_answers["cases"]["KA-1"]
+    polys = [(np.array(fixture_corridor["polytopes"][p]["A"]), np.array(fixture_corridor["polytopes"][p]["b"])) for p in c["polys"]]
+    dti = c["dt_init"]
+    args = (c["x0"], c["xf"], *c["vaj"], True, polys)
+    assert py_model.milp_feasible(c["N"], 2 * dti, *args) is False
+    assert py_model.milp_feasible(c["N"], 3 * dti, *args) is True

@@ -147,3 +147,23 @@ def test_cost_does_not_increase_with_more_time_in_free_space(oracle):
             assert st == abi.FH_ST_OPTIMAL
             costs.append(r["cost"])
         assert all(a >= b - 1e-9 for a, b in zip(costs, costs[1:]))
+
+
+def test_first_feasible_factor_against_highs(oracle):
+    """Feasibility flag / factor_that_worked_ pinned by a third-party mixed-integer code (HiGHS via scipy.optimize.milp) on
+    the reference's own variables with big-M indicator rows: feasible at the accepted factor, infeasible one step earlier."""
+    from oracle import py_model
+
+    pr, faces, _ = corridor.whole_batch(10, seed=107, n_seg=5, p_choices=(2, 3), speed=3.0, lateral=0.8)
+    res = oracle.solve_batch(pr, faces)
+    checked = 0
+    for i in np.nonzero(res["solved"])[0][:6]:
+        p, r = pr[i], res[i]
+        args = (int(p["n_seg"]),)
+        common = (p["x0"], p["xf"], float(p["v_max"]), float(p["a_max"]), float(p["j_max"]), bool(p["force_final_pos"]), polys_of(p, faces))
+        assert py_model.milp_feasible(args[0], float(r["dt"]), *common) is True
+        if r["trials"] > 1:
+            dt_prev = (r["factor"] - p["f_inc"]) * (r["dt"] / r["factor"])
+            assert py_model.milp_feasible(args[0], float(dt_prev), *common) is False
+        checked += 1
+    assert checked >= 3
