@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=32768, help="whole+safe pairs per rank per step (C4: 32768)")
     ap.add_argument("--n-seg", type=int, default=10)
     ap.add_argument("--max-poly", type=int, default=6)
+    ap.add_argument("--min-poly", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=6,
@@ -88,7 +89,7 @@ def main():
     from faster_amd import abi, capi, corridor, shard
 
     B, N = args.pairs, args.n_seg
-    whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(2, args.max_poly + 1)))
+    whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
     safe_t = corridor.safe_templates(whole)
     max_faces = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
 

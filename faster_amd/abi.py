@@ -21,7 +21,8 @@ problem_dtype = np.dtype(
         ("force_final_pos", "<i4"),
         ("face_begin", "<i4"),
         ("face_off", "<i4", (FH_MAX_POLY + 1,)),
-        ("reserved", "<i4", (3,)),
+        ("pin", "<u4", (2,)),
+        ("reserved", "<i4"),
         ("dc", "<f8"),
         ("v_max", "<f8"),
         ("a_max", "<f8"),
@@ -101,3 +102,13 @@ def pack_faces(polys):
         faces[i]["a"] = a
         faces[i]["b"] = bb
     return faces, off
+
+
+def set_pins(problem, assign):
+    """Fix the binaries of one problem record: assign[t] = polytope index or -1 (free)."""
+    w = 0
+    for t, a in enumerate(assign):
+        if a is not None and a >= 0:
+            w |= (int(a) + 1) << (4 * t)
+    problem["pin"][0] = w & 0xFFFFFFFF
+    problem["pin"][1] = (w >> 32) & 0xFFFFFFFF

@@ -929,11 +929,22 @@ struct Solver {
     }
     if (P > 0) {
       if (allowed_mask(0) == 0u || allowed_mask(N - 1) == 0u) return FH_ST_INFEASIBLE;
+      // fixed binaries (fh_problem.pin): pinned to an excluded polytope => no assignment is feasible
+      const unsigned long long pins = (unsigned long long)pr.pin[0] | ((unsigned long long)pr.pin[1] << 32);
+      bool pin_bad = false;
+      for (int t = 0; t < N; t++) {
+        const int v = (int)((pins >> (4 * t)) & 15ull);
+        if (v && !((allowed_mask(t) >> (v - 1)) & 1u)) pin_bad = true;
+      }
+      if (pin_bad) return FH_ST_INFEASIBLE;
       FH_SYNC();
-      if (lane == 0) {  // a segment with exactly one candidate polytope is not a decision
-        const unsigned m0 = allowed_mask(0), mN = allowed_mask(N - 1);
-        if ((m0 & (m0 - 1u)) == 0u) assign[0] = __builtin_ctz(m0);
-        if ((mN & (mN - 1u)) == 0u) assign[N - 1] = __builtin_ctz(mN);
+      if (lane < N) {
+        const int v = (int)((pins >> (4 * lane)) & 15ull);
+        if (v) assign[lane] = v - 1;
+        else if (lane == 0 || lane == N - 1) {  // a segment with exactly one candidate polytope is not a decision
+          const unsigned m = allowed_mask(lane);
+          if ((m & (m - 1u)) == 0u) assign[lane] = __builtin_ctz(m);
+        }
       }
       FH_SYNC();
     }
@@ -1025,6 +1036,11 @@ __device__ inline bool bad_input(const fh_problem& pr, int nseg_cap, int face_ca
   if (!(pr.dc > 0) || !(pr.v_max > 0) || !(pr.a_max > 0) || !(pr.j_max > 0)) return true;
   for (int i = 0; i < 9; i++)
     if (!isfinite(pr.x0[i]) || !isfinite(pr.xf[i])) return true;
+  const unsigned long long pins = (unsigned long long)pr.pin[0] | ((unsigned long long)pr.pin[1] << 32);
+  for (int t = 0; t < FH_MAX_SEG; t++) {
+    const int v = (int)((pins >> (4 * t)) & 15ull);
+    if (v && (t >= pr.n_seg || v > pr.n_poly)) return true;
+  }
   return false;
 }
 

@@ -56,7 +56,10 @@ typedef struct fh_problem {
   int32_t force_final_pos; /* forceFinalConstraint_: 1 whole trajectory, 0 safe trajectory      */
   int32_t face_begin;      /* index of this problem's first face in the batch face array        */
   int32_t face_off[FH_MAX_POLY + 1]; /* polytope p owns faces [face_begin+face_off[p], face_begin+face_off[p+1]) */
-  int32_t reserved[3];
+  uint32_t pin[2];         /* optional fixed binaries (BASELINE config 1 "fixed binaries (pure QP)"; the reference has no such
+                              API — its b[t][p] are private): nibble t of the 64-bit word pin[0] | pin[1]<<32 is 0 to leave
+                              segment t free, or p+1 to force b[t][p] = 1.  All zero = the reference's MIQP.            */
+  int32_t reserved;
   double dc;               /* DC                                                               */
   double v_max, a_max, j_max;
   double f_init, f_final, f_inc; /* factor window; the loop accumulates `f += f_inc` in double   */

@@ -702,6 +702,13 @@ static int bad_input(const fh_problem* pr) {
   if (!(pr->dc > 0) || !(pr->v_max > 0) || !(pr->a_max > 0) || !(pr->j_max > 0)) return 1;
   for (int i = 0; i < 9; i++)
     if (!isfinite(pr->x0[i]) || !isfinite(pr->xf[i])) return 1;
+  {
+    const unsigned long long pins = (unsigned long long)pr->pin[0] | ((unsigned long long)pr->pin[1] << 32);
+    for (int t = 0; t < FH_MAX_SEG; t++) {
+      const int v = (int)((pins >> (4 * t)) & 15ull);
+      if (v && (t >= pr->n_seg || v > pr->n_poly)) return 1;
+    }
+  }
   return 0;
 }
 
@@ -734,7 +741,14 @@ void orc_solve_fixed(const fh_problem* pr, const fh_face* faces, const fh_params
 }
 
 void orc_solve(const fh_problem* pr, const fh_face* faces, const fh_params* par, fh_result* res) {
-  orc_solve_fixed(pr, faces, par, NULL, res);
+  const unsigned long long pins = (unsigned long long)pr->pin[0] | ((unsigned long long)pr->pin[1] << 32);
+  if (!pins) {
+    orc_solve_fixed(pr, faces, par, NULL, res);
+    return;
+  }
+  int8_t fixed[FH_MAX_SEG];
+  for (int t = 0; t < FH_MAX_SEG; t++) fixed[t] = (int8_t)((int)((pins >> (4 * t)) & 15ull) - 1);
+  orc_solve_fixed(pr, faces, par, fixed, res);
 }
 
 void orc_solve_batch(const fh_problem* pr, const fh_face* faces, const fh_params* par, int n, fh_result* res) {

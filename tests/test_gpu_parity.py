@@ -314,3 +314,43 @@ def test_sample_capacity_and_unsolved(ctx, oracle):
         full = oracle.sample(pr[i], res[i])
         assert counts[i] == full.shape[0] > 10
         np.testing.assert_allclose(states[i]["pos"], full[:10]["pos"], atol=1e-11)
+
+
+def test_fixed_binaries_config_c1(ctx, oracle, fixture_corridor, known_answers):
+    """BASELINE config 1 "N=6, 3-polytope corridor, fixed binaries (pure QP)" and the pinned runners-up of KA-1:
+    fh_problem.pin fixes b[t][p]; costs are the survey's independent values (tests/golden/known_answers.json)."""
+    c = known_answers["cases"]["KA-1"]
+    batches, expect = [], []
+    for cost, assign in [(c["cost"], c["assign"])] + [tuple(x) for x in c["runners_up"]]:
+        pr, faces = corridor.fixture_problem(fixture_corridor, c["N"], c["vaj"], 1, c["polys"], c["x0"], c["xf"], f_init=3.0, f_final=3.0)
+        abi.set_pins(pr[0], assign)
+        batches.append((pr, faces))
+        expect.append(cost)
+    c2 = known_answers["cases"]["KA-2"]   # C1 proper: N=6, 3 polytopes, monotone pattern fixed
+    pr, faces = corridor.fixture_problem(fixture_corridor, 6, c2["vaj"], 1, c2["polys"], c2["x0"], c2["xf"])
+    abi.set_pins(pr[0], c2["assign"])
+    batches.append((pr, faces))
+    pr, faces = corridor.fixture_problem(fixture_corridor, 6, c2["vaj"], 1, c2["polys"], c2["x0"], c2["xf"])
+    abi.set_pins(pr[0], [0, 0, 1, 1, 2, 2])   # a pattern that is infeasible for every factor in the window? compare with the oracle
+    batches.append((pr, faces))
+    prs, fcs = corridor.concat(batches)
+    got = ctx.solve_batch(prs, fcs)
+    ref = oracle.solve_batch(prs, fcs)
+    compare(got, ref)
+    for i, cost in enumerate(expect):
+        assert got["solved"][i] == 1 and got["cost"][i] == pytest.approx(cost, rel=2e-8)
+        assert list(got["assign"][i][:10]) == list(([c["assign"]] + [x[1] for x in c["runners_up"]])[i])
+    assert got["solved"][len(expect)] == 1 and got["factor"][len(expect)] == 3.0
+    assert list(got["assign"][len(expect)][:6]) == c2["assign"]
+    # random pins on synthetic corridors, including pins that exclude every assignment
+    pr, faces, _ = corridor.whole_batch(128, seed=111, n_seg=8, p_choices=(2, 3, 4))
+    rng = np.random.default_rng(111)
+    for i in range(len(pr)):
+        a = [int(rng.integers(0, pr["n_poly"][i])) if rng.random() < 0.3 else -1 for _ in range(8)]
+        abi.set_pins(pr[i], a)
+    pr["pin"][5, 0] = 0x9           # polytope index 8 >= n_poly: bad input
+    got = ctx.solve_batch(pr, faces)
+    ref = oracle.solve_batch(pr, faces)
+    compare(got, ref)
+    assert got["status"][5] == abi.FH_ST_BAD_INPUT
+    assert 0 < got["solved"].mean() < 1
