@@ -57,13 +57,14 @@ result_dtype = np.dtype(
 
 state_dtype = np.dtype([("pos", "<f8", (3,)), ("vel", "<f8", (3,)), ("accel", "<f8", (3,)), ("jerk", "<f8", (3,))], align=True)
 
-params_dtype = np.dtype([("feas_tol", "<f8"), ("dep_tol", "<f8"), ("max_nodes", "<i4"), ("max_iters", "<i4")], align=True)
+params_dtype = np.dtype([("feas_tol", "<f8"), ("dep_tol", "<f8"), ("max_nodes", "<i4"), ("max_iters", "<i4"), ("max_work", "<i4"),
+                         ("reserved", "<i4")], align=True)
 
 assert problem_dtype.itemsize == 264, problem_dtype.itemsize
 assert face_dtype.itemsize == 32
 assert result_dtype.itemsize == 1600, result_dtype.itemsize
 assert state_dtype.itemsize == 96
-assert params_dtype.itemsize == 24
+assert params_dtype.itemsize == 32
 
 
 def default_params():
@@ -72,6 +73,7 @@ def default_params():
     p["dep_tol"] = 1e-10
     p["max_nodes"] = 100000
     p["max_iters"] = 2000
+    p["max_work"] = 0
     return p
 
 

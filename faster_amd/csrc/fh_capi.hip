@@ -100,6 +100,8 @@ void fh_default_params(fh_params* p) {
   p->dep_tol = 1e-10;
   p->max_nodes = 100000;
   p->max_iters = 2000;
+  p->max_work = 0;
+  p->reserved = 0;
 }
 
 int fh_create(fh_ctx** out, int device) {
@@ -151,7 +153,7 @@ const char* fh_last_error(const fh_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 
 int fh_set_params(fh_ctx* ctx, const fh_params* p) {
   if (!ctx || !p) return FH_ERR_ARG;
-  if (!(p->feas_tol > 0) || !(p->dep_tol > 0) || p->max_nodes < 1 || p->max_iters < 1) return FH_ERR_ARG;
+  if (!(p->feas_tol > 0) || !(p->dep_tol > 0) || p->max_nodes < 1 || p->max_iters < 1 || p->max_work < 0) return FH_ERR_ARG;
   ctx->par = *p;
   return FH_OK;
 }

@@ -959,6 +959,7 @@ struct Solver {
     int local_nodes = 0;
     while (have_node) {
       if (local_nodes >= par.max_nodes) { status_limit = FH_ST_NODE_LIMIT; break; }
+      if (par.max_work > 0 && iters >= par.max_work) { status_limit = FH_ST_ITER_LIMIT; break; }
       local_nodes++;
       double cost = 0;
       const int st = qp_run(best_cost, par.max_iters, iters, cost);
@@ -1119,7 +1120,8 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
   int trials = 0, nodes = 0, iters = 0, status = FH_ST_INFEASIBLE;
   bool solved = false;
   double dt = 0, factor = 0, cost = 0;
-  for (double f = pr.f_init; f <= pr.f_final && !solved; f = f + pr.f_inc) {  // genNewTraj :445-446
+  for (double f = pr.f_init; f <= pr.f_final && !solved && !(par.max_work > 0 && status == FH_ST_ITER_LIMIT);
+       f = f + pr.f_inc) {  // genNewTraj :445-446
     trials++;
     dt = f * base;
     sv.h = dt;

@@ -99,6 +99,10 @@ typedef struct fh_params {
   double dep_tol;     /* |z|/|g| below this => candidate row linearly dependent (1e-10)      */
   int32_t max_nodes;  /* per trial branch-and-bound node cap          (default 100000)       */
   int32_t max_iters;  /* per QP active-set iteration cap              (default 2000)         */
+  int32_t max_work;   /* per PROBLEM cap on active-set iterations over all trials and nodes; 0 = unlimited (default).
+                         The reference sets no Gurobi TimeLimit; a real-time caller can bound the worst case here:
+                         a problem that exceeds it ends with FH_ST_ITER_LIMIT, solved = 0.                          */
+  int32_t reserved;
 } fh_params;
 
 /* One sample of fillX(): pos, vel, accel, jerk (faster_types.hpp:79-165 `state`, yaw/dyaw unused

@@ -518,7 +518,7 @@ typedef struct {
   double best_cost;
   double best_x[NV_MAX];
   int8_t best_assign[FH_MAX_SEG];
-  int nodes, iters, limit;
+  int nodes, iters, limit, iters_before;
   unsigned allowed[FH_MAX_SEG]; /* bit p set: polytope p is not excluded for segment t by jerk-independent rows */
 } bnb_ctx;
 
@@ -565,6 +565,10 @@ static void bnb_node(bnb_ctx* B, int8_t* assign) {
   if (B->limit) return;
   if (B->nodes >= M->par.max_nodes) {
     B->limit = FH_ST_NODE_LIMIT;
+    return;
+  }
+  if (M->par.max_work > 0 && B->iters_before + B->iters >= M->par.max_work) {
+    B->limit = FH_ST_ITER_LIMIT;
     return;
   }
   B->nodes++;
@@ -644,6 +648,7 @@ static int miqp_bnb(const fh_problem* pr, const fh_face* faces, const fh_params*
   B.best_cost = INFINITY;
   B.nodes = 0;
   B.iters = 0;
+  B.iters_before = *iters;
   B.limit = 0;
   int8_t assign[FH_MAX_SEG];
   for (int t = 0; t < FH_MAX_SEG; t++) assign[t] = fixed_assign ? fixed_assign[t] : -1;
@@ -725,7 +730,8 @@ void orc_solve_fixed(const fh_problem* pr, const fh_face* faces, const fh_params
   double dt_init = orc_dt_initial(pr);
   int status = FH_ST_INFEASIBLE;
   double x[NV_MAX];
-  for (double f = pr->f_init; f <= pr->f_final && !res->solved; f = f + pr->f_inc) { /* :445-446 */
+  for (double f = pr->f_init; f <= pr->f_final && !res->solved && !(par->max_work > 0 && status == FH_ST_ITER_LIMIT);
+       f = f + pr->f_inc) { /* :445-446 */
     res->trials++;
     double two_dc = 2 * pr->dc;
     res->dt = f * (dt_init > two_dc ? dt_init : two_dc); /* findDT :494-497 */
@@ -841,6 +847,8 @@ void orc_default_params(fh_params* p) {
   p->dep_tol = 1e-10;
   p->max_nodes = 100000;
   p->max_iters = 2000;
+  p->max_work = 0;
+  p->reserved = 0;
 }
 
 size_t orc_sizeof_problem(void) { return sizeof(fh_problem); }

@@ -354,3 +354,23 @@ def test_fixed_binaries_config_c1(ctx, oracle, fixture_corridor, known_answers):
     compare(got, ref)
     assert got["status"][5] == abi.FH_ST_BAD_INPUT
     assert 0 < got["solved"].mean() < 1
+
+
+def test_work_cap_bounds_the_worst_case(oracle):
+    """fh_params.max_work: a per-problem cap on active-set iterations (the reference sets no Gurobi TimeLimit)."""
+    import torch  # noqa: F401
+    from faster_amd import capi
+
+    c = capi.Context(0)
+    pr, faces, _ = corridor.whole_batch(256, seed=3, p_choices=(5, 6))
+    par = abi.default_params()
+    par["max_work"] = 60
+    c.set_params(par)
+    got = c.solve_batch(pr, faces)
+    full = oracle.solve_batch(pr, faces)
+    capped = got["status"] == abi.FH_ST_ITER_LIMIT
+    assert capped.any() and np.all(got["solved"][capped] == 0)
+    assert np.all(got["qp_iters"] <= 60 + par["max_iters"])       # the cap is checked between nodes
+    fine = ~capped
+    compare(got[fine], full[fine])                                  # problems below the cap are unaffected
+    c.close()
