@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--n-seg", type=int, default=10)
     ap.add_argument("--max-poly", type=int, default=6)
     ap.add_argument("--min-poly", type=int, default=2)
+    ap.add_argument("--workload", choices=["c4", "c5"], default="c4",
+                    help="c4 (default, the metric's configuration): synthetic corridors; c5: Monte-Carlo forest, corridors from the "
+                         "voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes (BASELINE config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=6,
@@ -89,7 +92,16 @@ def main():
     from faster_amd import abi, capi, corridor, shard
 
     B, N = args.pairs, args.n_seg
-    whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
+    if args.workload == "c5":
+        from faster_amd import build as fb, frontend
+
+        fb.build_frontend()
+        N = args.n_seg = 15
+        args.max_poly = 8
+        whole, faces, finfo = frontend.forest_batch(B, seed=5 + 1000 * rank, n_seg=N, max_poly=8)
+        B = len(whole)  # pairs without a path are dropped
+    else:
+        whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
     safe_t = corridor.safe_templates(whole)
     max_faces = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
 
@@ -185,8 +197,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "C4: %d whole+safe paired solves per GPU per step (N=%d segments, deg=3, <=%d polytopes whole / <=3 safe), "
-                            "synthetic corridors (faster_amd/corridor.py seed 3)" % (B, N, args.max_poly),
+                "workload": ("C4: %d whole+safe paired solves per GPU per step (N=%d segments, deg=3, <=%d polytopes whole / <=3 safe), "
+                             "synthetic corridors (faster_amd/corridor.py seed 3)" % (B, N, args.max_poly)) if args.workload == "c4" else
+                            ("C5: %d whole+safe paired solves per GPU per step in a random forest (20x20x3 m, 0.1 trees/m^2), corridors from "
+                             "the voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes" % B),
                 "pairs_per_gpu": B,
                 "pipelines_in_flight": len(pipes),
                 "parallelism": "batch-sharded x%d, RCCL all_gather of result summaries" % world if world > 1 else "single GPU",

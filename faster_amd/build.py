@@ -51,9 +51,25 @@ def build_host(force=False, verbose=False):
     return HOST_SO
 
 
+FRONT_SO = os.path.join(HERE, "libfasterfront.so")
+FRONT_SOURCES = [os.path.join(HERE, "host", "corridor_frontend.cpp")]
+FRONT_DEPS = FRONT_SOURCES + [os.path.join(HERE, "host", "corridor_frontend.hpp")]
+
+
+def build_frontend(force=False, verbose=False):
+    """CPU corridor front-end (voxel path search + ellipsoid decomposition), SURVEY.md 8(f) N1."""
+    if force or _stale(FRONT_SO, FRONT_DEPS):
+        cmd = ["g++", "-O2", "-std=c++14", "-fPIC", "-fopenmp", "-shared", "-o", FRONT_SO] + FRONT_SOURCES
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return FRONT_SO
+
+
 def build_all(force=False, verbose=False):
     build_device(force, verbose)
     build_host(force, verbose)
+    build_frontend(force, verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,130 @@
+"""ctypes binding of the CPU corridor front-end (faster_amd/libfasterfront.so) and the Monte-Carlo
+forest workload of BASELINE config 5."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfasterfront.so")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError("%s is missing: run `python -m faster_amd.build`" % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        vp, i32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        L.ff_decompose.restype = i32
+        L.ff_decompose.argtypes = [vp, i32, vp, i32, vp, f64, f64, vp, i32, vp, vp]
+        L.ff_plan.restype = i32
+        L.ff_plan.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, vp, i32]
+        L.ff_corridor_batch.restype = i32
+        L.ff_corridor_batch.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, f64, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def decompose(path, cloud, drone_radius=0.05, z_ground=0.0, bbox=(2.0, 2.0, 1.0), max_faces=4096):
+    """JPS_Manager::cvxEllipsoidDecomp for one path. Returns ([(A, b) per segment], ellipsoids[n_seg, 15])."""
+    path, cloud, bbox = _c(path).reshape(-1, 3), _c(cloud).reshape(-1, 3), _c(bbox)
+    nseg = len(path) - 1
+    faces = np.zeros((max_faces, 4))
+    off = np.zeros(nseg + 1, dtype=np.int32)
+    ell = np.zeros((nseg, 15))
+    tot = lib().ff_decompose(abi.ptr(path), len(path), abi.ptr(cloud) if len(cloud) else None, len(cloud), abi.ptr(bbox), drone_radius,
+                             z_ground, abi.ptr(faces), max_faces, abi.ptr(off), abi.ptr(ell))
+    if tot < 0:
+        raise RuntimeError("max_faces too small")
+    return [(faces[off[i]:off[i + 1], :3].copy(), faces[off[i]:off[i + 1], 3].copy()) for i in range(nseg)], ell
+
+
+def plan(cloud, cells, res, center, z_ground, z_max, inflation, start, goal, max_points=4096):
+    """JPS_Manager::solveJPS3D (A* variant). Returns the cleaned path [k, 3] or None."""
+    cloud = _c(cloud).reshape(-1, 3)
+    out = np.zeros((max_points, 3))
+    k = lib().ff_plan(abi.ptr(cloud) if len(cloud) else None, len(cloud), int(cells[0]), int(cells[1]), int(cells[2]), res, abi.ptr(_c(center)),
+                      z_ground, z_max, inflation, abi.ptr(_c(start)), abi.ptr(_c(goal)), abi.ptr(out), max_points)
+    if k < 0:
+        raise RuntimeError("max_points too small")
+    return out[:k].copy() if k > 0 else None
+
+
+def forest_cloud(seed, size=(20.0, 20.0, 3.0), density=0.1, radius=0.3, spacing=0.15):
+    """Random forest of vertical cylinders (BASELINE config 5: 20 x 20 x 3 m, r = 0.3 m, 0.1 trees/m^2) sampled as the
+    occupied-point cloud a mapper would deliver (surface points every `spacing` m)."""
+    rng = np.random.default_rng(seed)
+    n_trees = int(round(density * size[0] * size[1]))
+    centres = rng.uniform([0.5, 0.5], [size[0] - 0.5, size[1] - 0.5], size=(n_trees, 2))
+    ang = np.arange(0, 2 * np.pi, spacing / radius)
+    zs = np.arange(0.0, size[2] + 1e-9, spacing)
+    ring = np.stack([radius * np.cos(ang), radius * np.sin(ang)], axis=1)
+    pts = (centres[:, None, None, :] + ring[None, None, :, :]) + np.zeros((1, len(zs), 1, 1))
+    cloud = np.concatenate([pts.reshape(-1, 2), np.tile(np.repeat(zs, len(ang)), n_trees)[:, None]], axis=1)
+    return cloud, centres
+
+
+def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, drone_radius=0.05,
+                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, **kw):
+    """BASELINE config 5: n start/goal pairs in one random forest; corridors from the voxel path search + ellipsoid
+    decomposition (this front-end).  Returns (problems, faces, info)."""
+    from . import corridor
+
+    rng = np.random.default_rng(seed + 1)
+    cloud, centres = forest_cloud(seed, size)
+
+    def free_points(k):
+        out = np.zeros((0, 3))
+        while len(out) < k:
+            p = np.column_stack([rng.uniform(1, size[0] - 1, 2 * k), rng.uniform(1, size[1] - 1, 2 * k), rng.uniform(0.8, size[2] - 0.8, 2 * k)])
+            d = np.min(np.linalg.norm(p[:, None, :2] - centres[None, :, :], axis=2), axis=1)
+            out = np.vstack([out, p[d > 0.3 + inflation + 0.35]])
+        return out[:k]
+
+    starts = free_points(n)
+    goals = free_points(n)
+    for _ in range(8):  # resample goals that are too close
+        near = np.linalg.norm(goals - starts, axis=1) < min_goal_dist
+        if not near.any():
+            break
+        goals[near] = free_points(int(near.sum()))
+    cells = (int(size[0] / res) + 10, int(size[1] / res) + 10, int(size[2] / res))
+    center = np.array([size[0] / 2, size[1] / 2, size[2] / 2])
+    faces = np.zeros((n, faces_per_problem, 4))
+    face_off = np.zeros((n, 9), dtype=np.int32)
+    n_poly = np.zeros(n, dtype=np.int32)
+    goal_out = np.zeros((n, 3))
+    overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
+                                       inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
+                                       faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
+    ok = n_poly > 0
+    counts = face_off[np.arange(n), n_poly]
+    flat = np.concatenate([faces[i, :counts[i]] for i in np.nonzero(ok)[0]]) if ok.any() else np.zeros((0, 4))
+    fc = np.zeros(len(flat), dtype=abi.face_dtype)
+    fc["a"], fc["b"] = flat[:, :3], flat[:, 3]
+    idx = np.nonzero(ok)[0]
+    pr = abi.make_problems(len(idx))
+    pr["n_seg"] = n_seg
+    pr["n_poly"] = n_poly[idx]
+    pr["force_final_pos"] = 1 if force_final else 0
+    pr["face_off"] = face_off[idx]
+    pr["face_begin"] = np.concatenate([[0], np.cumsum(counts[idx])[:-1]]).astype(np.int32)
+    pr["dc"] = 0.01
+    pr["v_max"], pr["a_max"], pr["j_max"] = kw.get("v_max", 5.0), kw.get("a_max", 5.0), kw.get("j_max", 8.0)
+    pr["f_init"], pr["f_final"], pr["f_inc"] = 1.0, 10.0, 1.0
+    u = goal_out[idx] - starts[idx]
+    u /= np.maximum(np.linalg.norm(u, axis=1, keepdims=True), 1e-9)
+    pr["x0"][:, 0:3] = starts[idx]
+    pr["x0"][:, 3:6] = u * rng.uniform(0, 1.5, size=(len(idx), 1))
+    pr["xf"][:, 0:3] = goal_out[idx]
+    info = {"cloud": cloud, "starts": starts[idx], "goals": goals[idx], "no_path": int((~ok).sum()), "overflow": int(overflow),
+            "faces_per_polytope": float(counts[idx].sum() / max(n_poly[idx].sum(), 1))}
+    return pr, fc, info

@@ -1,0 +1,255 @@
+// corridor_frontend.cpp — path search + C wrapper of the corridor front-end (see corridor_frontend.hpp).
+#include "corridor_frontend.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <limits>
+#include <queue>
+
+namespace fhfront {
+
+namespace {
+
+// jps3d's clean-up of the raw cell path (jps_planner.cpp:83-105, :36-81)
+std::vector<V3> remove_line_points(const std::vector<V3>& path) {
+  if (path.size() < 3) return path;
+  std::vector<V3> out;
+  out.push_back(path.front());
+  for (size_t i = 1; i + 1 < path.size(); i++) {
+    const V3 p = (path[i + 1] - path[i]) - (path[i] - path[i - 1]);
+    if (std::fabs(p.x) + std::fabs(p.y) + std::fabs(p.z) > 1e-2) out.push_back(path[i]);
+  }
+  out.push_back(path.back());
+  return out;
+}
+
+std::vector<V3> remove_corner_points(const VoxelGrid& g, const std::vector<V3>& path) {
+  if (path.size() < 2) return path;
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<V3> out;
+  V3 prev = path[0];
+  out.push_back(prev);
+  double c1 = g.blocked(path[0], path[1]) ? inf : (path[0] - path[1]).norm();
+  for (size_t i = 1; i + 1 < path.size(); i++) {
+    const V3 a = path[i], b = path[i + 1];
+    const double c2 = g.blocked(a, b) ? inf : (a - b).norm();
+    const double c3 = g.blocked(prev, b) ? inf : (prev - b).norm();
+    if (c3 < c1 + c2) c1 = c3;
+    else {
+      out.push_back(a);
+      c1 = (a - b).norm();
+      prev = a;
+    }
+  }
+  out.push_back(path.back());
+  return out;
+}
+
+struct Node {
+  double f, g;
+  int id;
+};
+struct NodeOrder {  // graph_search.h:19-29: smaller f first; on (near) ties the larger g first
+  bool operator()(const Node& a, const Node& b) const {
+    if (a.f >= b.f - 1e-6 && a.f <= b.f + 1e-6) return a.g < b.g;
+    return a.f > b.f;
+  }
+};
+
+}  // namespace
+
+bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double inflation, std::vector<V3>& path) {
+  path.clear();
+  const V3 start(start_in.x, start_in.y, std::max(start_in.z, 0.0)), goal(goal_in.x, goal_in.y, std::max(goal_in.z, 0.0));
+  int s[3], t[3];
+  grid.to_cell(start, s);
+  grid.to_cell(goal, t);
+  grid.set_free_around(s, inflation);  // jps_manager.cpp:158-159
+  grid.set_free_around(t, inflation);
+  if (!grid.is_free(s[0], s[1], s[2]) || !grid.is_free(t[0], t[1], t[2])) return false;
+
+  const int total = grid.nx * grid.ny * grid.nz;
+  std::vector<double> gval((size_t)total, std::numeric_limits<double>::infinity());
+  std::vector<int> parent((size_t)total, -1);
+  std::vector<char> closed((size_t)total, 0);
+  std::priority_queue<Node, std::vector<Node>, NodeOrder> open;
+  const int sid = grid.index(s[0], s[1], s[2]), tid = grid.index(t[0], t[1], t[2]);
+  auto heur = [&](int x, int y, int z) {
+    return std::sqrt((double)(x - t[0]) * (x - t[0]) + (double)(y - t[1]) * (y - t[1]) + (double)(z - t[2]) * (z - t[2]));
+  };
+  gval[sid] = 0;
+  open.push({heur(s[0], s[1], s[2]), 0.0, sid});
+  bool found = false;
+  while (!open.empty()) {
+    const Node cur = open.top();
+    open.pop();
+    if (closed[cur.id]) continue;
+    closed[cur.id] = 1;
+    if (cur.id == tid) { found = true; break; }
+    const int cz = cur.id / (grid.nx * grid.ny), rem = cur.id - cz * grid.nx * grid.ny, cy = rem / grid.nx, cx = rem - cy * grid.nx;
+    for (int dx = -1; dx <= 1; dx++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dz = -1; dz <= 1; dz++) {
+          if (!dx && !dy && !dz) continue;
+          const int x = cx + dx, y = cy + dy, z = cz + dz;
+          if (!grid.is_free(x, y, z)) continue;
+          const int id = grid.index(x, y, z);
+          if (closed[id]) continue;
+          const double ng = cur.g + std::sqrt((double)(dx * dx + dy * dy + dz * dz));
+          if (ng < gval[id]) {
+            gval[id] = ng;
+            parent[id] = cur.id;
+            open.push({ng + heur(x, y, z), ng, id});
+          }
+        }
+  }
+  if (!found) return false;
+  std::vector<V3> raw;
+  for (int id = tid; id >= 0; id = parent[id]) {
+    const int cz = id / (grid.nx * grid.ny), rem = id - cz * grid.nx * grid.ny, cy = rem / grid.nx, cx = rem - cy * grid.nx;
+    raw.push_back(grid.cell_center(cx, cy, cz));
+    if (id == sid) break;
+  }
+  std::reverse(raw.begin(), raw.end());
+  std::vector<V3> p = remove_corner_points(grid, remove_line_points(raw));
+  std::reverse(p.begin(), p.end());
+  p = remove_corner_points(grid, p);
+  std::reverse(p.begin(), p.end());
+  if (p.size() > 1) {  // jps_manager.cpp:175-186: ends forced onto the requested points
+    p.front() = start;
+    p.back() = goal;
+  } else {
+    p.clear();
+    p.push_back(start);
+    p.push_back(goal);
+  }
+  path = p;
+  return true;
+}
+
+}  // namespace fhfront
+
+// ---- C wrapper (plain pointers) for tests and the Python workload generator -------------------------------------------
+extern "C" {
+
+// Decomposition of one path: writes the rows [a_x a_y a_z b] of polytope i to faces[face_off[i] .. face_off[i+1]).
+// Returns the total number of faces, or -1 if max_faces is too small.  ellipsoids (optional): per segment 15 doubles
+// (R row major 9, axes 3, centre 3).
+int ff_decompose(const double* path_xyz, int n_points, const double* cloud_xyz, int n_cloud, const double* local_bbox,
+                 double drone_radius, double z_ground, double* faces, int max_faces, int* face_off, double* ellipsoids) {
+  using namespace fhfront;
+  std::vector<V3> path, cloud;
+  for (int i = 0; i < n_points; i++) path.push_back(V3(path_xyz[3 * i], path_xyz[3 * i + 1], path_xyz[3 * i + 2]));
+  for (int i = 0; i < n_cloud; i++) cloud.push_back(V3(cloud_xyz[3 * i], cloud_xyz[3 * i + 1], cloud_xyz[3 * i + 2]));
+  std::vector<Ellipsoid> ell;
+  const std::vector<LinearConstraint> cs =
+      decompose_path(path, cloud, drone_radius, z_ground, V3(local_bbox[0], local_bbox[1], local_bbox[2]), &ell);
+  int total = 0;
+  face_off[0] = 0;
+  for (size_t i = 0; i < cs.size(); i++) {
+    for (size_t f = 0; f < cs[i].faces(); f++) {
+      if (total >= max_faces) return -1;
+      faces[4 * total + 0] = cs[i].A[3 * f + 0];
+      faces[4 * total + 1] = cs[i].A[3 * f + 1];
+      faces[4 * total + 2] = cs[i].A[3 * f + 2];
+      faces[4 * total + 3] = cs[i].b[f];
+      total++;
+    }
+    face_off[i + 1] = total;
+    if (ellipsoids) {
+      double* e = ellipsoids + 15 * i;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) e[3 * r + c] = ell[i].R.m[r][c];
+      e[9] = ell[i].axes.x; e[10] = ell[i].axes.y; e[11] = ell[i].axes.z;
+      e[12] = ell[i].d.x; e[13] = ell[i].d.y; e[14] = ell[i].d.z;
+    }
+  }
+  return total;
+}
+
+// Voxel grid from a point cloud (FASTER's readMap) + path search.  Returns the number of path vertices (0 = no path),
+// or -1 if max_points is too small.
+int ff_plan(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y, int cells_z, double res, const double* center,
+            double z_ground, double z_max, double inflation, const double* start, const double* goal, double* path_xyz,
+            int max_points) {
+  using namespace fhfront;
+  std::vector<V3> cloud;
+  for (int i = 0; i < n_cloud; i++) cloud.push_back(V3(cloud_xyz[3 * i], cloud_xyz[3 * i + 1], cloud_xyz[3 * i + 2]));
+  VoxelGrid g;
+  g.build(cloud, cells_x, cells_y, cells_z, res, V3(center[0], center[1], center[2]), z_ground, z_max, inflation);
+  std::vector<V3> path;
+  if (!plan_path(g, V3(start[0], start[1], start[2]), V3(goal[0], goal[1], goal[2]), inflation, path)) return 0;
+  if ((int)path.size() > max_points) return -1;
+  for (size_t i = 0; i < path.size(); i++) {
+    path_xyz[3 * i] = path[i].x; path_xyz[3 * i + 1] = path[i].y; path_xyz[3 * i + 2] = path[i].z;
+  }
+  return (int)path.size();
+}
+
+// Batch corridor generation for Monte-Carlo workloads (BASELINE config 5): one shared cloud, n start/goal pairs.
+// Per pair: voxel path search -> Faster::createMoreVertexes (faster/src/faster.cpp:80-97, segments longer than
+// `max_vertex_dist` are cut) -> deleteVertexes (faster/src/utils.cpp:1117-1124, at most max_poly segments kept) ->
+// decomposition.  Outputs per pair i: n_poly[i] (0 = no path), face_off[i][0..8], faces at faces[i*faces_per_problem ...],
+// goal[i] = last kept vertex (the solver's E, faster.cpp:393-394).  OpenMP over pairs.
+int ff_corridor_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y, int cells_z, double res, const double* center,
+                      double z_ground, double z_max, double inflation, double drone_radius, const double* starts,
+                      const double* goals, int n, int max_poly, double max_vertex_dist, int faces_per_problem, double* faces,
+                      int* face_off, int* n_poly, double* goal_out) {
+  using namespace fhfront;
+  std::vector<V3> cloud;
+  for (int i = 0; i < n_cloud; i++) cloud.push_back(V3(cloud_xyz[3 * i], cloud_xyz[3 * i + 1], cloud_xyz[3 * i + 2]));
+  VoxelGrid base;
+  base.build(cloud, cells_x, cells_y, cells_z, res, V3(center[0], center[1], center[2]), z_ground, z_max, inflation);
+  int overflow = 0;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int i = 0; i < n; i++) {
+    VoxelGrid g = base;  // the search frees the cells around start and goal
+    n_poly[i] = 0;
+    for (int k = 0; k < 9; k++) face_off[9 * i + k] = 0;
+    std::vector<V3> path;
+    const V3 s(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), t(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]);
+    goal_out[3 * i] = t.x; goal_out[3 * i + 1] = t.y; goal_out[3 * i + 2] = t.z;
+    if (!plan_path(g, s, t, inflation, path)) continue;
+    for (size_t j = 0; j + 1 < path.size(); j++) {  // createMoreVertexes
+      const double dist = (path[j + 1] - path[j]).norm();
+      const int add = (int)std::floor(dist / max_vertex_dist);
+      if (dist > max_vertex_dist) {
+        const V3 v = (path[j + 1] - path[j]).normalized();
+        for (int k = 0; k < add; k++) {
+          path.insert(path.begin() + j + 1, path[j] + v * max_vertex_dist);
+          j++;
+        }
+      }
+    }
+    // (createMoreVertexes repeats the end point when a leg is an exact multiple of the spacing; the reference would then
+    //  decompose a zero-length segment — dropped here)
+    for (size_t j = 0; j + 1 < path.size();) {
+      if ((path[j + 1] - path[j]).norm() < 1e-9) path.erase(path.begin() + j + 1);
+      else j++;
+    }
+    if ((int)path.size() > max_poly + 1) path.resize(max_poly + 1);  // deleteVertexes
+    const std::vector<LinearConstraint> cs = decompose_path(path, cloud, drone_radius, z_ground);
+    int total = 0;
+    bool fits = true;
+    for (size_t p = 0; p < cs.size() && fits; p++) {
+      for (size_t f = 0; f < cs[p].faces(); f++) {
+        if (total >= faces_per_problem) { fits = false; break; }
+        double* row = faces + 4 * ((size_t)i * faces_per_problem + total);
+        row[0] = cs[p].A[3 * f]; row[1] = cs[p].A[3 * f + 1]; row[2] = cs[p].A[3 * f + 2]; row[3] = cs[p].b[f];
+        total++;
+      }
+      face_off[9 * i + p + 1] = total;
+    }
+    if (!fits) {
+#pragma omp atomic
+      overflow++;
+      continue;
+    }
+    for (size_t p = cs.size(); p < 8; p++) face_off[9 * i + p + 1] = total;
+    n_poly[i] = (int)cs.size();
+    goal_out[3 * i] = path.back().x; goal_out[3 * i + 1] = path.back().y; goal_out[3 * i + 2] = path.back().z;
+  }
+  return overflow;
+}
+
+}  // extern "C"

@@ -374,3 +374,20 @@ def test_work_cap_bounds_the_worst_case(oracle):
     fine = ~capped
     compare(got[fine], full[fine])                                  # problems below the cap are unaffected
     c.close()
+
+
+def test_forest_corridors_config_c5(ctx, oracle):
+    """BASELINE config 5 inputs: corridors from the voxel path search + ellipsoid decomposition front-end
+    (faster_amd/host/corridor_frontend.hpp) in a random forest, N=15, <=8 polytopes."""
+    from faster_amd import build as fb, frontend
+
+    fb.build_frontend()
+    pr, faces, info = frontend.forest_batch(384, seed=5, n_seg=15, max_poly=8)
+    assert len(pr) > 300 and info["overflow"] == 0
+    got = ctx.solve_batch(pr, faces)
+    ref = oracle.solve_batch(pr, faces)
+    ok = compare(got, ref)
+    assert ok.mean() > 0.8
+    check_assignment_valid(pr, faces, got)
+    pr2, faces2, _ = frontend.forest_batch(384, seed=6, n_seg=10, max_poly=6, force_final=False)
+    compare(ctx.solve_batch(pr2, faces2), oracle.solve_batch(pr2, faces2))
