@@ -40,6 +40,11 @@ namespace fh {
 #define FH_T1(slot)
 #endif
 #define FH_MAX_TRIALS 4096
+// Gram-Schmidt is repeated when the first pass cancels more than this fraction of |g|^2 (Daniel-Gragg-Kaufman-Stewart use
+// 1/2; a smaller value trades a bounded loss of orthogonality, O(eps / sqrt(threshold)) per inserted row, for half the sweeps)
+#ifndef FH_REORTH_THRESHOLD
+#define FH_REORTH_THRESHOLD 0.05
+#endif
 
 enum { K_EQ = 0, K_JBOX = 1, K_VBOX = 2, K_ABOX = 3, K_POLY = 4 };
 // weight kinds of a row: which linear functional of the state at the start of segment tt
@@ -442,7 +447,7 @@ struct Solver {
   }
 
   // ---- normal of row `id` in jerk space: g[v], v = 3 s + i.  returns |g|^2 ----
-  __device__ double build_g(int id) {
+  __device__ double build_g(int id, double& gv_out) {
     const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
     double gv = 0;
     if (lane < n) {
@@ -472,6 +477,7 @@ struct Solver {
     }
     if (lane < NVP) g[lane] = gv;
     FH_SYNC();
+    gv_out = gv;
     return wave_sum(gv * gv);
   }
 
@@ -502,18 +508,51 @@ struct Solver {
     return a0 + a1;
   }
 
+  // Same sweeps with the vector operand taken from registers (lane k holds v_k) and broadcast with v_readlane instead of
+  // LDS broadcast reads: the LDS pipe is the busiest unit of this kernel, the VALU has headroom.
+  __device__ __forceinline__ double col_dot_reg(const double* __restrict__ M, int col, double vreg, int n8) const {
+    double a0 = 0, a1 = 0;
+    for (int i0 = 0; i0 < n8; i0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        a0 += M[(i0 + j) * S + col] * readlane_f64(vreg, i0 + j);
+        a1 += M[(i0 + j + 1) * S + col] * readlane_f64(vreg, i0 + j + 1);
+      }
+    }
+    return a0 + a1;
+  }
+  __device__ __forceinline__ double row_dot_reg(const double* __restrict__ M, int row, double vreg, int q8) const {
+    double a0 = 0, a1 = 0;
+    const double* Mr = M + row * S;
+    for (int c0 = 0; c0 < q8; c0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        a0 += Mr[c0 + j] * readlane_f64(vreg, c0 + j);
+        a1 += Mr[c0 + j + 1] * readlane_f64(vreg, c0 + j + 1);
+      }
+    }
+    return a0 + a1;
+  }
+
   // ---- z = (I - Q1 Q1^T) g, d = Q1^T g (lane c holds d_c, lane i holds z_i). Re-orthogonalises when the first
   // pass cancels more than half of |g|^2 (Daniel-Gragg-Kaufman-Stewart).  returns |z|^2 ----
-  __device__ double project(double gg, double& dc, double& zi) {
+  __device__ double project(double gg, double gv, double& dc, double& zi) {
     const int n8 = (n + 7) & ~7, q8 = (q + 7) & ~7;
     const int ll = lane < NVP ? lane : NVP - 1;  // lanes beyond the padded size compute a harmless duplicate
+#ifndef FH_READLANE_BROADCAST
     dc = row_dot(Q, ll, g, n8);
     if (lane < NVP) d[lane] = dc;
     FH_SYNC();
     zi = g[ll] - col_dot(Q, ll, d, q8);
+#else
+    dc = row_dot_reg(Q, ll, gv, n8);      // gv: lane i holds g_i (0 beyond n)
+    if (lane >= q) dc = 0.0;              // columns beyond q are zero anyway; keep the register vector clean
+    zi = gv - col_dot_reg(Q, ll, dc, q8);
+#endif
     if (lane >= NVP) zi = 0.0;
     double zz = wave_sum(zi * zi);
-    if (zz < 0.5 * gg) {
+    if (zz < FH_REORTH_THRESHOLD * gg) {
+#ifndef FH_READLANE_BROADCAST
       if (lane < NVP) z[lane] = zi;
       FH_SYNC();
       const double ec = row_dot(Q, ll, z, n8);
@@ -521,6 +560,12 @@ struct Solver {
       if (lane < NVP) r[lane] = ec;
       FH_SYNC();
       zi -= col_dot(Q, ll, r, q8);
+#else
+      double ec = row_dot_reg(Q, ll, zi, n8);
+      if (lane >= q) ec = 0.0;
+      dc += ec;
+      zi -= col_dot_reg(Q, ll, ec, q8);
+#endif
       if (lane >= NVP) zi = 0.0;
       zz = wave_sum(zi * zi);
     }
@@ -787,13 +832,13 @@ struct Solver {
         if (cbad) return 1;
         if (id < 0) return 0;
       }
-      double gg;
-      { FH_T0(); gg = build_g(id); FH_T1(4); }
+      double gg, gv;
+      { FH_T0(); gg = build_g(id, gv); FH_T1(4); }
       double up = 0;
       for (;;) {  // until row `id` is active
         if (++it > max_iters) return 3;
         double dc, zi, zz, rc;
-        { FH_T0(); zz = project(gg, dc, zi); FH_T1(5); }
+        { FH_T0(); zz = project(gg, gv, dc, zi); FH_T1(5); }
         FH_T0();
         rc = backsolve(dc);
         const bool dependent = zz <= dep2 * gg;
