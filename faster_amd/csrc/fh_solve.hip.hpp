@@ -212,11 +212,10 @@ struct Solver {
   double* tolf;                                       // [n_faces] feas_tol / |a_f|
   fh_face* faces;                                     // [n_faces] NORMALISED rows: a/|a| and bt = -(b + feas_tol)/|a|, so that
                                                       //           a.cp + bt > 0  <=>  the original row is violated by more than feas_tol
-  unsigned long long* polyact;                        // [NSEG][4] active-row bit per face
-  int *act, *boxact, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_order, *face_off;
+  int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_order, *face_off;
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NSEG * 4 + NVP + 5 * NVP + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + 12) +
+    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 5 * NVP + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + 12) +
            sizeof(int) * (7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 1 + 3) + (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
   }
 
@@ -243,8 +242,7 @@ struct Solver {
     Q = p; p += NVP * S;
     R = p; p += RPSZ;
     x = p; p += NVP;  u = p; p += NVP;  rinv = p; p += NVP;
-    polyact = reinterpret_cast<unsigned long long*>(p); p += NSEG * 4;
-    act = reinterpret_cast<int*>(p); boxact = act + NVP; p += NVP;
+    act = reinterpret_cast<int*>(p); p += NVP / 2;
     // ---- end of the snapshot block ----
     z = p; p += NVP;  g = p; p += NVP;  d = p; p += NVP;  r = p; p += NVP;  bestx = p; p += NVP;
     P0 = p; p += NT * 3;  V0 = p; p += NT * 3;  A0 = p; p += NT * 3;
@@ -268,7 +266,7 @@ struct Solver {
   // A snapshot holds only what is live: the first q columns of Q1 (contiguous: column major), the first q columns of the
   // packed R, and the fixed tail (x, u, 1/diag, active masks).  Workspace slot: [tail | Q | R], each padded for the
   // 16-B-per-lane copy granularity.
-  static constexpr int SNAP_TAIL = 3 * NVP + NSEG * 4 + NVP;
+  static constexpr int SNAP_TAIL = 3 * NVP + NVP / 2;  // x, u, 1/diag, active row ids
   static constexpr int SNAP_QOFF = (SNAP_TAIL + 127) & ~127;
   static constexpr int SNAP_ROFF = SNAP_QOFF + ((NVP * S + 127) & ~127) + 128;
   static constexpr int SNAP_PADDED = SNAP_ROFF + ((RPSZ + 127) & ~127) + 128;  // doubles per workspace slot
@@ -320,7 +318,7 @@ struct Solver {
   __device__ void init_problem() {
     for (int i = lane; i < NVP * S; i += 64) Q[i] = 0.0;
     for (int i = lane; i < RPSZ; i += 64) R[i] = 0.0;
-    if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; r[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; boxact[lane] = 0; }
+    if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; r[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
     q = 0;
     FH_SYNC();
   }
@@ -387,7 +385,6 @@ struct Solver {
     bool bad = false;
     if (lane < n) {
       const int t = lane / 3, i = lane - 3 * t;
-      const int ba = boxact[lane];
       const double xv = x[lane];
       const double V = Vc[lane], A = Ac[lane];
       const double iV = t >= 1 ? wni[W_V * NT + t] : 0.0, iA = t >= 1 ? wni[W_A * NT + t] : 0.0;  // t = 0 rows are constants
@@ -396,7 +393,7 @@ struct Solver {
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         const double sc = cand[c] * inv[c];
-        const bool take = cand[c] > tol && !((ba >> c) & 1) && sc > bs;
+        const bool take = cand[c] > tol && sc > bs;
         bs = take ? sc : bs;
         bv = take ? cand[c] : bv;
         bid = take ? mk_id(c < 2 ? K_JBOX : (c < 4 ? K_VBOX : K_ABOX), t, i, c & 1) : bid;
@@ -411,7 +408,6 @@ struct Solver {
       const int F = p >= 0 ? face_off[p + 1] - f0 : 0;
       const int cl = live ? lane : 0;
       const double c0 = CP[cl * 3 + 0], c1 = CP[cl * 3 + 1], c2 = CP[cl * 3 + 2];
-      const unsigned long long am = polyact[cl];
       const double wi = wni[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
       int bf = -1;
       double bvt = 0;
@@ -421,8 +417,7 @@ struct Solver {
           const int f = fb + j;
           const fh_face fc = faces[f0 + (f < F ? f : 0)];
           const double vt = fma(fc.a[0], c0, fma(fc.a[1], c1, fma(fc.a[2], c2, fc.b)));
-          const bool inactive = !((f < 32 ? (unsigned)am : (unsigned)(am >> 32)) >> (f & 31) & 1u);
-          const bool take = (f < F) && inactive && vt > bvt;
+          const bool take = (f < F) && vt > bvt;  // (an active row has v ~ 0, i.e. vt ~ -tol/|a| < 0: never re-selected)
           bvt = take ? vt : bvt;
           bf = take ? f : bf;
         }
@@ -604,23 +599,6 @@ struct Solver {
     return rc;
   }
 
-  __device__ void set_active(int id, bool on) {
-    const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
-    if (kind == K_EQ) return;
-    if (lane == 0) {
-      if (kind == K_POLY) {
-        unsigned long long m = polyact[t * 4 + k];
-        m = on ? (m | (1ull << f)) : (m & ~(1ull << f));
-        polyact[t * 4 + k] = m;
-      } else {
-        const int bit = (kind == K_JBOX ? 1 : (kind == K_VBOX ? 4 : 16)) << f;
-        int b = boxact[3 * t + k];
-        b = on ? (b | bit) : (b & ~bit);
-        boxact[3 * t + k] = b;
-      }
-    }
-  }
-
   __device__ void add_row(int id, double zi, double zz, double dc, double up) {
     const double rho = sqrt(zz);
     const double inv = 1.0 / rho;
@@ -632,14 +610,11 @@ struct Solver {
       act[q] = id;
       u[q] = up;
     }
-    set_active(id, true);
     q++;
     FH_SYNC();
   }
 
   __device__ void drop_row(int kpos) {
-    set_active(act[kpos], false);
-    FH_SYNC();
     // shift the bookkeeping and the columns of R left
     int a_next = 0;
     double u_next = 0;
@@ -685,10 +660,8 @@ struct Solver {
     if (lane < NVP) {
       for (int c = 0; c < q; c++) Q[c * S + lane] = 0.0;  // columns >= q are zero already
       x[lane] = 0;
-      boxact[lane] = 0;
     }
     q = 0;
-    for (int i = lane; i < NSEG * 4; i += 64) polyact[i] = 0ull;
     FH_SYNC();
   }
 
