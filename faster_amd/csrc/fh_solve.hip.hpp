@@ -388,15 +388,17 @@ struct Solver {
       const double xv = x[lane];
       const double V = Vc[lane], A = Ac[lane];
       const double iV = t >= 1 ? wni[W_V * NT + t] : 0.0, iA = t >= 1 ? wni[W_A * NT + t] : 0.0;  // t = 0 rows are constants
-      const double cand[6] = {xv - jmax, -xv - jmax, V - vmax, -V - vmax, A - amax, -A - amax};
-      const double inv[6] = {1.0, 1.0, iV, iV, iA, iA};
+      const double val[3] = {xv, V, A};
+      const double lim[3] = {jmax, vmax, amax};
+      const double inv[3] = {1.0, iV, iA};
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const double sc = cand[c] * inv[c];
-        const bool take = cand[c] > tol && sc > bs;
+      for (int c = 0; c < 3; c++) {  // |value| - limit: at most one of the two box rows of a quantity can be violated
+        const double cv = fabs(val[c]) - lim[c];
+        const double sc = cv * inv[c];
+        const bool take = cv > tol && sc > bs;
         bs = take ? sc : bs;
-        bv = take ? cand[c] : bv;
-        bid = take ? mk_id(c < 2 ? K_JBOX : (c < 4 ? K_VBOX : K_ABOX), t, i, c & 1) : bid;
+        bv = take ? cv : bv;
+        bid = take ? mk_id(c == 0 ? K_JBOX : (c == 1 ? K_VBOX : K_ABOX), t, i, val[c] < 0.0 ? 1 : 0) : bid;
       }
     }
     {  // corridor rows: wave-uniform trip count (max faces per polytope) so that the face loads of 4 rows are in flight.
@@ -796,14 +798,20 @@ struct Solver {
       double vp;
       {
         FH_T0();
-        const double xl = (lane < n) ? x[lane] : 0.0;
-        cost = wave_sum(xl * xl);
-        if (cost >= ub) return 2;
+        if (ub < INFINITY) {  // the dual objective is a lower bound: prune against the incumbent
+          const double xl = (lane < n) ? x[lane] : 0.0;
+          cost = wave_sum(xl * xl);
+          if (cost >= ub) return 2;
+        }
         bool cbad;
         scan(id, vp, cbad);
         FH_T1(3);
         if (cbad) return 1;
-        if (id < 0) return 0;
+        if (id < 0) {
+          const double xl = (lane < n) ? x[lane] : 0.0;
+          cost = wave_sum(xl * xl);
+          return 0;
+        }
       }
       double gg, gv;
       { FH_T0(); gg = build_g(id, gv); FH_T1(4); }
