@@ -34,6 +34,7 @@
  * exact (no MIP gap), so the result is the global optimum over all P^N assignments.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -376,7 +377,16 @@ static int gi_solve(int n, int me, const orc_row* eq, int mi, const orc_row* in,
   memset(S->x, 0, sizeof(S->x));
   const double tol = par->feas_tol, dep2 = par->dep_tol * par->dep_tol;
   double z[NV_MAX], d[NV_MAX], r[NV_MAX];
-  char* active = (char*)calloc((size_t)mi + 1, 1);
+  /* per-thread scratch that only grows: large per-solve malloc/free pairs turn into mmap/munmap and do not scale */
+  static __thread char* active_buf = NULL;
+  static __thread size_t active_cap = 0;
+  if ((size_t)mi + 1 > active_cap) {
+    free(active_buf);
+    active_cap = 2 * ((size_t)mi + 1);
+    active_buf = (char*)malloc(active_cap);
+  }
+  char* active = active_buf;
+  memset(active, 0, (size_t)mi + 1);
   int it = 0, status = -1;
 
   /* equalities first: always a full step, never dropped */
@@ -461,7 +471,6 @@ static int gi_solve(int n, int me, const orc_row* eq, int mi, const orc_row* in,
       gi_drop(S, kb);
     }
   }
-  free(active);
   double f = 0;
   for (int i = 0; i < n; i++) {
     xout[i] = S->x[i];
@@ -643,8 +652,17 @@ static int miqp_bnb(const fh_problem* pr, const fh_face* faces, const fh_params*
     if (c > nf) nf = c;
   }
   size_t max_in = (size_t)18 * pr->n_seg + (size_t)4 * pr->n_seg * (nf > 0 ? nf : 1) + 8;
-  B.eq = (orc_row*)malloc(sizeof(orc_row) * 9);
-  B.in = (orc_row*)malloc(sizeof(orc_row) * max_in);
+  static __thread orc_row* eq_buf = NULL;
+  static __thread orc_row* in_buf = NULL;
+  static __thread size_t in_cap = 0;
+  if (!eq_buf) eq_buf = (orc_row*)malloc(sizeof(orc_row) * 9);
+  if (max_in > in_cap) {
+    free(in_buf);
+    in_cap = 2 * max_in;
+    in_buf = (orc_row*)malloc(sizeof(orc_row) * in_cap);
+  }
+  B.eq = eq_buf;
+  B.in = in_buf;
   B.best_cost = INFINITY;
   B.nodes = 0;
   B.iters = 0;
@@ -666,8 +684,6 @@ static int miqp_bnb(const fh_problem* pr, const fh_face* faces, const fh_params*
     }
   }
   if (!screened_out) bnb_node(&B, assign);
-  free(B.eq);
-  free(B.in);
   *nodes += B.nodes;
   *iters += B.iters;
   if (B.limit) return B.limit;
@@ -757,10 +773,18 @@ void orc_solve(const fh_problem* pr, const fh_face* faces, const fh_params* par,
   orc_solve_fixed(pr, faces, par, fixed, res);
 }
 
-void orc_solve_batch(const fh_problem* pr, const fh_face* faces, const fh_params* par, int n, fh_result* res) {
-#pragma omp parallel for schedule(dynamic, 4)
+/* threads <= 0: the OpenMP default (all cores) */
+void orc_solve_batch_mt(const fh_problem* pr, const fh_face* faces, const fh_params* par, int n, fh_result* res, int threads) {
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
   for (int i = 0; i < n; i++) orc_solve(&pr[i], faces, par, &res[i]);
 }
+
+void orc_solve_batch(const fh_problem* pr, const fh_face* faces, const fh_params* par, int n, fh_result* res) {
+  orc_solve_batch_mt(pr, faces, par, n, res, 0);
+}
+
+int orc_max_threads(void) { return omp_get_max_threads(); }
 
 /* One MIQP for a given dt (one callOptimizer()), optionally with pinned segments. Returns FH_ST_*. */
 int orc_miqp_dt(const fh_problem* pr, const fh_face* faces, const fh_params* par, double dt,

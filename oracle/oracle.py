@@ -35,6 +35,8 @@ def lib():
         L.orc_dt_initial.restype = ctypes.c_double
         L.orc_dt_initial.argtypes = [ctypes.c_void_p]
         L.orc_solve_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_solve_batch_mt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.orc_max_threads.restype = ctypes.c_int
         L.orc_solve_fixed.argtypes = [ctypes.c_void_p] * 5
         L.orc_miqp_dt.restype = ctypes.c_int
         L.orc_miqp_dt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
@@ -63,10 +65,14 @@ def solve_batch(problems, faces, params=None, threads=None):
     faces = np.ascontiguousarray(faces)
     res = np.zeros(problems.shape[0], dtype=abi.result_dtype)
     par = _params(params)
-    if threads is not None:
-        os.environ["OMP_NUM_THREADS"] = str(threads)
-    lib().orc_solve_batch(abi.ptr(problems), abi.ptr(faces), abi.ptr(par.reshape(1)), problems.shape[0], abi.ptr(res))
+    # explicit thread count (an OMP_NUM_THREADS change after libgomp is loaded has no effect); None/0 = all cores
+    lib().orc_solve_batch_mt(abi.ptr(problems), abi.ptr(faces), abi.ptr(par.reshape(1)), problems.shape[0], abi.ptr(res),
+                             int(threads or 0))
     return res
+
+
+def max_threads():
+    return lib().orc_max_threads()
 
 
 def solve_fixed(problem, faces, assign, params=None):
