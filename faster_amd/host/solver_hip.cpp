@@ -118,9 +118,47 @@ void SolverHip::absorb(const fh_result& r) {
   resetX();                                      // the last trial's resetX (:456)
 }
 
-bool SolverHip::genNewTraj() {
-  std::vector<SolverHip*> one(1, this);
-  return genNewTrajBatch(one)[0];
+int SolverHip::solveProblems(const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n, fh_result* results) {
+  if (!ensureContext()) return device_rc_ != FH_OK ? device_rc_ : FH_ERR_DEVICE;
+  const int rc = fh_solve_batch(ctx_, problems, faces, n_faces, n, results);
+  if (rc != FH_OK) device_err_ = fh_last_error(ctx_);
+  return rc;
+}
+
+int SolverHip::sampleProblems(const fh_problem* problems, const fh_result* results, int n, int max_samples, fh_state* states,
+                              int32_t* counts) {
+  if (!ensureContext()) return device_rc_ != FH_OK ? device_rc_ : FH_ERR_DEVICE;
+  const int rc = fh_sample_batch(ctx_, problems, results, n, max_samples, states, counts);
+  if (rc != FH_OK) device_err_ = fh_last_error(ctx_);
+  return rc;
+}
+
+bool SolverHip::genNewTraj() {  // solverGurobi.cpp:426-477 for one solver object
+  const auto t0 = std::chrono::steady_clock::now();
+  trials_ = 0;
+  runtime_ms_ = 0;
+  std::memset(&last_, 0, sizeof(last_));
+  if (factor_initial_ < 1) std::printf("factor_initial_ is less than one, it doesn't make sense\n");  // :438-441
+  if (cb_.should_terminate_) {  // the factor loop is not entered (:445); flag cleared at the end (:474)
+    cb_.should_terminate_ = false;
+    return false;
+  }
+  if (polytopes_.size() > (size_t)FH_MAX_POLY) {
+    std::fprintf(stderr, "SolverHip: %zu polytopes exceed FH_MAX_POLY=%d\n", polytopes_.size(), FH_MAX_POLY);
+    return false;
+  }
+  fh_problem pr;
+  std::vector<fh_face> faces;
+  fillProblem(pr, faces, 0);
+  fh_result r;
+  device_rc_ = solveProblems(&pr, faces.empty() ? nullptr : faces.data(), (int64_t)faces.size(), 1, &r);
+  runtime_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (device_rc_ != FH_OK) {
+    std::fprintf(stderr, "SolverHip::genNewTraj: device error %d: %s\n", device_rc_, device_err_.c_str());
+    return false;
+  }
+  absorb(r);
+  return r.solved != 0;
 }
 
 std::vector<bool> SolverHip::genNewTrajBatch(const std::vector<SolverHip*>& solvers) {
@@ -174,16 +212,14 @@ std::vector<bool> SolverHip::genNewTrajBatch(const std::vector<SolverHip*>& solv
 
 void SolverHip::fillX() {  // solverGurobi.cpp:122-168
   if (!last_.solved || X_temp_.empty()) return;  // the reference would read an unsolved model here (throws)
-  if (!ensureContext()) return;
   fh_problem pr;
   std::vector<fh_face> unused;
   fillProblem(pr, unused, 0);
   const int cap = (int)X_temp_.size();  // honours a caller that resized X_temp_
   std::vector<fh_state> st((size_t)cap);
   int32_t count = 0;
-  device_rc_ = fh_sample_batch(ctx_, &pr, &last_, 1, cap, st.data(), &count);
+  device_rc_ = sampleProblems(&pr, &last_, 1, cap, st.data(), &count);
   if (device_rc_ != FH_OK) {
-    device_err_ = fh_last_error(ctx_);
     std::fprintf(stderr, "SolverHip::fillX: device error %d: %s\n", device_rc_, device_err_.c_str());
     return;
   }

@@ -29,7 +29,7 @@ struct solverhip_callback {
 class SolverHip {
 public:
   SolverHip();
-  ~SolverHip();
+  virtual ~SolverHip();
   SolverHip(const SolverHip&) = delete;
   SolverHip& operator=(const SolverHip&) = delete;
 
@@ -76,6 +76,11 @@ public:
   solverhip_callback cb_;
 
 protected:
+  // The two places where the class crosses the C ABI.  Virtual so that CPU-only test harnesses can substitute another
+  // implementation of the same two calls (tests/cpp/oracle_solver.hpp); the product never overrides them.
+  virtual int solveProblems(const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n, fh_result* results);
+  virtual int sampleProblems(const fh_problem* problems, const fh_result* results, int n, int max_samples, fh_state* states,
+                             int32_t* counts);
   void fillProblem(fh_problem& pr, std::vector<fh_face>& faces, int face_begin) const;
   void absorb(const fh_result& r);
   bool ensureContext();

@@ -1,0 +1,95 @@
+// Closed-loop exercise of the replan stub (faster_amd/host/replan_stub.hpp) in a random forest with a limited sensing radius:
+// each cycle the map is updated (trees seen so far = occupied; lattice points never seen = unknown), replan() is called, and the
+// vehicle follows the committed plan for a few states.  Prints one JSON object with what the Python test asserts on.
+//   usage: test_replan_stub <gpu|oracle> [path/to/liboracle.so] [seed]
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "replan_stub.hpp"
+#ifdef WITH_ORACLE
+#include "oracle_solver.hpp"
+#endif
+#include "solver_hip.hpp"
+
+using fhfront::V3;
+
+template <class Solver>
+int run(unsigned seed) {
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  const double W = 16.0, H = 3.0, tree_r = 0.3, sense = 3.0;  // sensing radius < Ra: the whole trajectory enters unknown space
+  std::vector<V3> trees;
+  for (int i = 0; i < 20; i++) {
+    V3 c(2.5 + U(rng) * (W - 5.0), 1.0 + U(rng) * (W - 2.0), 0);
+    trees.push_back(c);
+  }
+  std::vector<V3> tree_pts;
+  for (const V3& c : trees)
+    for (double z = 0; z <= H; z += 0.2)
+      for (double a = 0; a < 6.28; a += 0.5) tree_pts.push_back(V3(c.x + tree_r * std::cos(a), c.y + tree_r * std::sin(a), z));
+  std::vector<V3> lattice;
+  for (double x = 0; x <= W; x += 0.5)
+    for (double y = 0; y <= W; y += 0.5)
+      for (double z = 0.25; z <= H; z += 0.5) lattice.push_back(V3(x, y, z));
+  std::vector<char> tree_seen(tree_pts.size(), 0), lat_seen(lattice.size(), 0);
+
+  fhreplan::Params par;
+  par.wdx = par.wdy = 24; par.wdz = 3; par.res = 0.2; par.z_max = H; par.Ra = 4.0; par.drone_radius = 0.1; par.inflation_jps = 0.3;
+  fhreplan::Planner<Solver> planner(par);
+  state s0, goal;
+  s0.setPos(0.8, 0.8, 1.0);
+  goal.setPos(W - 1.0, W - 0.8, 1.2);
+  planner.setTerminalGoal(goal);
+  state cur = s0;
+  int committed = 0, failed = 0, cycles = 0, safe_needed = 0;
+  double min_clear = 1e9, max_jump = 0, max_speed = 0, max_norm = 0;
+  int stage_hist[6] = {0, 0, 0, 0, 0, 0};
+  double last_whole_factor = 0;
+  for (; cycles < 400; cycles++) {
+    const V3 here = fhreplan::pos_of(cur);
+    for (size_t i = 0; i < tree_pts.size(); i++)
+      if (!tree_seen[i] && (tree_pts[i] - here).norm() < sense) tree_seen[i] = 1;
+    for (size_t i = 0; i < lattice.size(); i++)
+      if (!lat_seen[i] && (lattice[i] - here).norm() < sense) lat_seen[i] = 1;
+    std::vector<V3> occ, unk;
+    for (size_t i = 0; i < tree_pts.size(); i++) if (tree_seen[i]) occ.push_back(tree_pts[i]);
+    for (size_t i = 0; i < lattice.size(); i++) if (!lat_seen[i]) unk.push_back(lattice[i]);
+    planner.updateState(cur);
+    planner.updateMap(occ, unk);
+    fhreplan::ReplanLog log;
+    const bool ok = planner.replan(&log);
+    stage_hist[log.stage]++;
+    if (ok) { committed++; safe_needed += log.needed_safe ? 1 : 0; last_whole_factor = log.whole_factor; }
+    else if (planner.status() != fhreplan::Status::GOAL_REACHED) failed++;
+    if (planner.status() == fhreplan::Status::GOAL_REACHED) break;
+    for (int k = 0; k < 25; k++) {  // fly 0.25 s along the committed plan
+      state nxt;
+      if (!planner.getNextGoal(nxt)) break;
+      const V3 a = fhreplan::pos_of(cur), b = fhreplan::pos_of(nxt);
+      max_jump = std::max(max_jump, (b - a).norm());
+      max_speed = std::max(max_speed, std::max(std::fabs(nxt.vel.x()), std::max(std::fabs(nxt.vel.y()), std::fabs(nxt.vel.z()))));
+      max_norm = std::max(max_norm, nxt.vel.norm());
+      cur = nxt;
+      for (const V3& c : trees) min_clear = std::min(min_clear, std::hypot(b.x - c.x, b.y - c.y) - tree_r);
+    }
+  }
+  const V3 end = fhreplan::pos_of(cur), g = fhreplan::pos_of(goal);
+  std::printf("{\"reached\": %d, \"cycles\": %d, \"committed\": %d, \"failed\": %d, \"safe_needed\": %d, \"dist_to_goal\": %.4f, "
+              "\"min_clearance\": %.4f, \"max_jump\": %.5f, \"max_speed\": %.4f, \"max_speed_norm\": %.4f, \"stages\": [%d, %d, %d, %d, %d, %d], \"last_whole_factor\": %.2f}\n",
+              planner.status() == fhreplan::Status::GOAL_REACHED ? 1 : 0, cycles, committed, failed, safe_needed, (end - g).norm(), min_clear,
+              max_jump, max_speed, max_norm, stage_hist[0], stage_hist[1], stage_hist[2], stage_hist[3], stage_hist[4], stage_hist[5], last_whole_factor);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const char* mode = argc > 1 ? argv[1] : "gpu";
+  const unsigned seed = argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u;
+#ifdef WITH_ORACLE
+  if (!std::strcmp(mode, "oracle")) {
+    OracleSolver::lib_path() = argc > 2 ? argv[2] : "oracle/liboracle.so";
+    return run<OracleSolver>(seed);
+  }
+#endif
+  return run<SolverHip>(seed);
+}
