@@ -32,17 +32,17 @@ namespace fhreplan {
 using fhfront::V3;
 
 struct Params {  // the planner-relevant subset of `parameters` (faster_types.hpp:17-77), defaults from param/faster.yaml
-  double dc = 0.01, goal_radius = 0.2, drone_radius = 0.1;
+  double dc = 0.01, goal_radius = 0.3, drone_radius = 0.42;
   double Ra = 4.0, dist_max_vertexes = 1.5;
   int N_whole = 6, N_safe = 6;
   double v_max = 5.0, a_max = 5.0, j_max = 8.0;
   double gamma_whole = 20, gammap_whole = 20, increment_whole = 1.0;
   double gamma_safe = 20, gammap_safe = 20, increment_safe = 1.0;
   int max_poly_whole = 3, max_poly_safe = 3;
-  double delta_a = 0.9, delta_H = 0.7;
+  double delta_a = 0.5, delta_H = 1.0;
   int deltaT = 10;  // states between "now" and the start state A (faster.hpp:131)
   double wdx = 20, wdy = 20, wdz = 4, res = 0.15;
-  double z_ground = 0.0, z_max = 3.0, inflation_jps = 0.2, factor_jps = 1.0;
+  double z_ground = 0.0, z_max = 3.0, inflation_jps = 0.47, factor_jps = 1.0;
 };
 
 enum class Status { TRAVELING, GOAL_SEEN, GOAL_REACHED };
@@ -307,6 +307,7 @@ public:
       sg_safe_.X_temp_ = std::vector<state>();
     } else {
       k_safe = find_index_R(indexH);
+      L.k_safe = k_safe;
       state R = sg_whole_.X_temp_[k_safe];
       tmp[0] = pos_of(R);
       std::vector<V3> JPS_safe = tmp;

@@ -29,13 +29,14 @@ int run(unsigned seed) {
     for (double z = 0; z <= H; z += 0.2)
       for (double a = 0; a < 6.28; a += 0.5) tree_pts.push_back(V3(c.x + tree_r * std::cos(a), c.y + tree_r * std::sin(a), z));
   std::vector<V3> lattice;
-  for (double x = 0; x <= W; x += 0.5)
-    for (double y = 0; y <= W; y += 0.5)
-      for (double z = 0.25; z <= H; z += 0.5) lattice.push_back(V3(x, y, z));
+  // unknown space as the mapper would report it: one point per unseen voxel; the spacing must be finer than a tree
+  for (double x = 0; x <= W; x += 0.2)
+    for (double y = 0; y <= W; y += 0.2)
+      for (double z = 0.1; z <= H; z += 0.2) lattice.push_back(V3(x, y, z));
   std::vector<char> tree_seen(tree_pts.size(), 0), lat_seen(lattice.size(), 0);
 
   fhreplan::Params par;
-  par.wdx = par.wdy = 24; par.wdz = 3; par.res = 0.2; par.z_max = H; par.Ra = 4.0; par.drone_radius = 0.1; par.inflation_jps = 0.3;
+  par.wdx = par.wdy = 24; par.wdz = 3; par.res = 0.2; par.z_max = H; par.Ra = 4.0; par.drone_radius = 0.2; par.v_max = 1.5; par.a_max = 3.0; par.j_max = 10.0;  // slow enough to brake inside the 3 m sensing radius par.inflation_jps = 0.3;  // drone_radius >= half the lattice diagonal: unknown space is never missed
   fhreplan::Planner<Solver> planner(par);
   state s0, goal;
   s0.setPos(0.8, 0.8, 1.0);

@@ -30,13 +30,15 @@ def build():
 def check(out):
     assert out["reached"] == 1, out
     assert out["dist_to_goal"] < 0.3
-    assert out["committed"] >= 5 and out["committed"] >= 3 * out["failed"]
-    assert out["safe_needed"] >= 1                      # unknown space forced at least one safe trajectory
-    assert out["min_clearance"] > 0.0                   # never inside a tree
+    assert out["committed"] >= 10
+    # failures are mostly "no safe trajectory from R" (stage 3): the reference then keeps the committed plan, as here
+    assert out["stages"][1] == 0 and out["stages"][4] == 0
+    assert out["safe_needed"] >= 5                      # the 3 m sensing radius (< Ra) forces safe trajectories
+    assert out["min_clearance"] >= 0.2 - 1e-3           # never closer to a tree than the drone radius used for the corridors
     # consecutive goals are 10 ms apart; at a splice the reference erases A itself and appends A + DC (appendToPlan,
     # faster.cpp:606-648), i.e. one 20 ms step: continuity means no jump beyond that
     assert out["max_jump"] <= 2.1 * 0.01 * out["max_speed_norm"] + 2e-3
-    assert out["max_speed"] <= 5.0 + 1e-6
+    assert out["max_speed"] <= 1.5 * 1.1                # the reference bounds velocity at segment starts only (solverGurobi.cpp:393-405)
 
 
 @pytest.mark.parametrize("seed", [1, 2])
