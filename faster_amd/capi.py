@@ -16,6 +16,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
     "fh_solve_batch", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device",
+    "fh_decompose_batch", "fh_decompose_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
 
@@ -56,6 +57,10 @@ def lib():
         L.fh_sample_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp]
         L.fh_pair_glue_device.restype = i32
         L.fh_pair_glue_device.argtypes = [vp, vp, vp, vp, i32, f64, f64, i32, vp, vp]
+        L.fh_decompose_batch.restype = i32
+        L.fh_decompose_batch.argtypes = [vp, vp, i32, vp, i32, vp, f64, f64, i32, vp, vp]
+        L.fh_decompose_batch_device.restype = i32
+        L.fh_decompose_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, f64, f64, i32, vp, vp]
         L.fh_sync.restype = i32
         L.fh_sync.argtypes = [vp]
         L.fh_timing_reset.restype = i32
@@ -141,6 +146,18 @@ class Context:
         self._check(lib().fh_sample_batch(self._h, abi.ptr(problems), abi.ptr(results), n, max_samples, abi.ptr(states),
                                           abi.ptr(counts)), "fh_sample_batch")
         return states, counts
+
+    def decompose_batch(self, cloud, segments, drone_radius=0.05, z_ground=0.0, bbox=(2.0, 2.0, 1.0), max_faces=64):
+        """cvxEllipsoidDecomp on the device for [n, 6] segments sharing one cloud. Returns (faces[n, max_faces], counts[n])."""
+        cloud = np.ascontiguousarray(cloud, dtype=np.float64).reshape(-1, 3)
+        segments = np.ascontiguousarray(segments, dtype=np.float64).reshape(-1, 6)
+        bbox = np.ascontiguousarray(bbox, dtype=np.float64)
+        n = segments.shape[0]
+        faces = np.zeros((n, max_faces), dtype=abi.face_dtype)
+        counts = np.zeros(n, dtype=np.int32)
+        self._check(lib().fh_decompose_batch(self._h, abi.ptr(cloud) if len(cloud) else None, len(cloud), abi.ptr(segments), n, abi.ptr(bbox),
+                                             drone_radius, z_ground, max_faces, abi.ptr(faces), abi.ptr(counts)), "fh_decompose_batch")
+        return faces, counts
 
     # ---- device-pointer entry points (raw addresses; memory owned by the caller, e.g. torch tensors) ----
     def solve_batch_device(self, d_problems, d_faces, n, max_seg, max_faces, d_results):

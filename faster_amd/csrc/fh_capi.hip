@@ -14,6 +14,7 @@
 #include "../../include/fasterhip.h"
 #include "fh_sample.hip.hpp"
 #include "fh_solve.hip.hpp"
+#include "fh_decomp.hip.hpp"
 
 struct fh_ctx {
   int device = 0;
@@ -289,6 +290,49 @@ int fh_timing_read(fh_ctx* ctx, double* ms, int cap) {
     ms[i] = (double)t;
   }
   return count;
+}
+
+int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_segments, int n_segments,
+                              const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* d_faces,
+                              int32_t* d_counts) {
+  if (!ctx || n_cloud < 0 || n_segments < 0 || max_faces < 8 || !local_bbox) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n_segments == 0) return FH_OK;
+  if (!d_segments || !d_faces || !d_counts || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
+  if (!(local_bbox[0] > 0) || !(local_bbox[1] > 0) || !(local_bbox[2] > 0) || !(drone_radius >= 0)) return FH_ERR_ARG;
+  const int grid = std::min(n_segments, ctx->n_cu * 4);  // LDS: 25 KB per workgroup
+  int rc;
+  if ((rc = ensure(ctx, 7, sizeof(double) * (size_t)grid * (3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8))) != FH_OK) return rc;
+  hipLaunchKernelGGL(fh::decomp_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_cloud_xyz, n_cloud, d_segments, n_segments,
+                     local_bbox[0], local_bbox[1], local_bbox[2], drone_radius, z_ground, max_faces, (double*)ctx->d_buf[7], d_faces,
+                     d_counts);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const double* segments, int n_segments,
+                       const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* faces, int32_t* counts) {
+  if (!ctx || n_cloud < 0 || n_segments < 0 || max_faces < 8) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n_segments == 0) return FH_OK;
+  if (!segments || !faces || !counts || (n_cloud > 0 && !cloud_xyz)) return FH_ERR_ARG;
+  int rc;
+  const size_t cb = sizeof(double) * 3 * (size_t)std::max(n_cloud, 1), sb = sizeof(double) * 6 * (size_t)n_segments;
+  const size_t fb = sizeof(fh_face) * (size_t)n_segments * (size_t)max_faces, nb = sizeof(int32_t) * (size_t)n_segments;
+  if ((rc = ensure(ctx, 0, cb)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 1, sb)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 3, fb)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 4, nb)) != FH_OK) return rc;
+  if (n_cloud > 0) FH_HIP(hipMemcpyAsync(ctx->d_buf[0], cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud, hipMemcpyHostToDevice, ctx->stream));
+  FH_HIP(hipMemcpyAsync(ctx->d_buf[1], segments, sb, hipMemcpyHostToDevice, ctx->stream));
+  FH_HIP(hipMemsetAsync(ctx->d_buf[3], 0, fb, ctx->stream));
+  rc = fh_decompose_batch_device(ctx, (const double*)ctx->d_buf[0], n_cloud, (const double*)ctx->d_buf[1], n_segments, local_bbox,
+                                 drone_radius, z_ground, max_faces, (fh_face*)ctx->d_buf[3], (int32_t*)ctx->d_buf[4]);
+  if (rc != FH_OK) return rc;
+  FH_HIP(hipMemcpyAsync(faces, ctx->d_buf[3], fb, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipMemcpyAsync(counts, ctx->d_buf[4], nb, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
 }
 
 double fh_last_kernel_ms(fh_ctx* ctx) {

@@ -1,0 +1,255 @@
+// fh_decomp.hip.hpp — batched convex decomposition around path segments on the device (gfx950, wave64, FP64).
+//
+// GPU version of next-row N1: what JPS_Manager::cvxEllipsoidDecomp (faster/src/jps_manager.cpp:80-127) computes per
+// path segment through DecompUtil's LineSegment3D::dilate — obstacle inflation + ellipsoid fit (line_segment.h:156-252), separating
+// planes (decomp_base.h:83-115, ellipsoid.h:48-73), local bounding box (line_segment.h:57-98), conversion to A x <= b around the segment
+// midpoint (polyhedron.h:131-152) and the ground plane (jps_manager.cpp:113-124).  Same arithmetic as the host version
+// (faster_amd/host/corridor_frontend.hpp), one wavefront per segment:
+//   * one coalesced sweep over the obstacle cloud keeps the points inside the segment's local box (ballot + mbcnt compaction into an
+//     LDS list, already inflated towards the ellipsoid centre);
+//   * every "closest point" of the reference is a lane-parallel arg-min over that list on the DPP network; every "drop the points the
+//     new plane/ellipsoid excludes" is a lane-parallel flag update.  The loops themselves (shrink the axes, add planes) are the
+//     reference's and stay sequential per segment; thousands of segments run side by side.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/fasterhip.h"
+#include "fh_solve.hip.hpp"  // wave reductions
+
+namespace fh {
+
+#define FH_DECOMP_CAP 1024  // obstacle points of interest per segment (points inside the local box); more => count = -1
+#define FH_DECOMP_EPS 1e-10  // DecompUtil's epsilon_
+
+struct D3 {
+  double x, y, z;
+};
+__device__ __forceinline__ D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double norm(D3 a) { return sqrt(dot(a, a)); }
+
+struct Rot {  // row major
+  double m[3][3];
+};
+__device__ __forceinline__ D3 mul(const Rot& R, D3 v) {
+  return d3(R.m[0][0] * v.x + R.m[0][1] * v.y + R.m[0][2] * v.z, R.m[1][0] * v.x + R.m[1][1] * v.y + R.m[1][2] * v.z,
+            R.m[2][0] * v.x + R.m[2][1] * v.y + R.m[2][2] * v.z);
+}
+__device__ __forceinline__ D3 mulT(const Rot& R, D3 v) {
+  return d3(R.m[0][0] * v.x + R.m[1][0] * v.y + R.m[2][0] * v.z, R.m[0][1] * v.x + R.m[1][1] * v.y + R.m[2][1] * v.z,
+            R.m[0][2] * v.x + R.m[1][2] * v.y + R.m[2][2] * v.z);
+}
+__device__ __forceinline__ Rot rot_onto(D3 v) {  // Rz(yaw) Ry(pitch), zero roll (geometric_utils.h:27-35)
+  const double pitch = atan2(-v.z, sqrt(v.x * v.x + v.y * v.y)), yaw = atan2(v.y, v.x);
+  const double cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw);
+  Rot r;
+  r.m[0][0] = cy * cp; r.m[0][1] = -sy; r.m[0][2] = cy * sp;
+  r.m[1][0] = sy * cp; r.m[1][1] = cy;  r.m[1][2] = sy * sp;
+  r.m[2][0] = -sp;     r.m[2][1] = 0;   r.m[2][2] = cp;
+  return r;
+}
+__device__ __forceinline__ Rot rot_roll(const Rot& Ri, double roll) {  // Ri * Rx(roll)
+  const double c = cos(roll), s = sin(roll);
+  Rot r;
+  for (int i = 0; i < 3; i++) {
+    r.m[i][0] = Ri.m[i][0];
+    r.m[i][1] = Ri.m[i][1] * c + Ri.m[i][2] * s;
+    r.m[i][2] = -Ri.m[i][1] * s + Ri.m[i][2] * c;
+  }
+  return r;
+}
+__device__ __forceinline__ double ell_dist(const Rot& R, D3 ax, D3 c, D3 q) {
+  const D3 l = mulT(R, q - c);
+  return norm(d3(l.x / ax.x, l.y / ax.y, l.z / ax.z));
+}
+__device__ __forceinline__ int sgn_i(double v) { return (0.0 < v) - (v < 0.0); }
+
+// arg-min of the ellipsoid distance over the list entries whose flag has `bit`; returns the list index (-1 if none)
+template <class PD, class PF>
+__device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt, unsigned char bit, const Rot& R, D3 ax, D3 c, int lane) {
+  double best = INFINITY;
+  int bi = -1;
+  for (int i = lane; i < cnt; i += 64)
+    if (flag[i] & bit) {
+      const double dd = ell_dist(R, ax, c, d3(px[i], py[i], pz[i]));
+      if (dd < best) { best = dd; bi = i; }
+    }
+  const double mn = wave_min(best);
+  if (!(mn < INFINITY)) {  // empty set, or every distance is NaN: any member (the host version does the same)
+    int anyi = -1;
+    for (int i = lane; i < cnt && anyi < 0; i += 64)
+      if (flag[i] & bit) anyi = i;
+    const int l2 = first_lane(anyi >= 0);
+    return l2 >= 0 ? __builtin_amdgcn_readlane(anyi, l2) : -1;
+  }
+  const int L = first_lane(best == mn);
+  return __builtin_amdgcn_readlane(bi, L);
+}
+
+#define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the list lives in the HBM workspace (dense clouds); more => count = -1
+
+// The decomposition of one segment with its list of box points at px/py/pz/flag (LDS for <= FH_DECOMP_CAP points, else the
+// per-workgroup HBM workspace).  `store`: compaction pass of the cloud sweep into the list.
+template <class PD, class PF>
+__device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
+                               const D3* bn, double inflate, double z_ground, int max_faces, fh_face* __restrict__ out,
+                               int32_t* __restrict__ count_out, int lane) {
+  const D3 dvec = p2 - p1;
+  const double f = norm(dvec) / 2;
+  const Rot Ri = rot_onto(dvec);
+  const D3 c = (p1 + p2) * 0.5;
+  // ---- sweep the cloud: keep the points inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
+  int cnt = 0;
+  for (int base = 0; base < n_cloud; base += 64) {
+    const int i = base + lane;
+    bool in = false;
+    D3 q = d3(0, 0, 0);
+    if (i < n_cloud) {
+      q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
+      in = true;
+#pragma unroll
+      for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
+    }
+    const unsigned long long m = __ballot(in);
+    if (m) {
+      if (in) {
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        const D3 l = mulT(Ri, q - c);
+        const D3 qi = mul(Ri, d3(l.x - sgn_i(l.x) * inflate, l.y - sgn_i(l.y) * inflate, l.z - sgn_i(l.z) * inflate)) + c;
+        px[pos] = qi.x; py[pos] = qi.y; pz[pos] = qi.z;
+      }
+      cnt += __popcll(m);
+    }
+  }
+  __syncthreads();
+
+  // ---- ellipsoid fit (line_segment.h:156-252)
+  D3 axes = d3(f, f, f);
+  for (int i = lane; i < cnt; i += 64) {
+    const bool fi = ell_dist(Ri, axes, c, d3(px[i], py[i], pz[i])) <= 1.0;
+    flag[i] = (unsigned char)((fi ? 3 : 0) | 4);  // first, inside; remain
+  }
+  __syncthreads();
+  Rot Rf = Ri;
+  D3 cur = axes;
+  for (int guard = 0; guard <= cnt; guard++) {  // second axis
+    const int ic = closest_in(px, py, pz, flag, cnt, 2, Rf, cur, c, lane);
+    if (ic < 0) break;
+    const D3 pw = d3(px[ic], py[ic], pz[ic]);
+    D3 l = mulT(Ri, pw - c);
+    Rf = rot_roll(Ri, atan2(l.z, l.y));
+    l = mulT(Rf, pw - c);
+    if (l.x < axes.x) axes.y = fabs(l.y) / sqrt(1 - (l.x / axes.x) * (l.x / axes.x));
+    cur = d3(axes.x, axes.y, axes.y);
+    for (int i = lane; i < cnt; i += 64)
+      if ((flag[i] & 2) && !(1 - ell_dist(Rf, cur, c, d3(px[i], py[i], pz[i])) > FH_DECOMP_EPS)) flag[i] &= (unsigned char)~2;
+    __syncthreads();
+  }
+  for (int i = lane; i < cnt; i += 64) {  // third axis back to its initial length; restart from the first set
+    const bool in2 = (flag[i] & 1) && ell_dist(Rf, axes, c, d3(px[i], py[i], pz[i])) <= 1.0;
+    flag[i] = (unsigned char)((flag[i] & ~2) | (in2 ? 2 : 0));
+  }
+  __syncthreads();
+  for (int guard = 0; guard <= cnt; guard++) {
+    const int ic = closest_in(px, py, pz, flag, cnt, 2, Rf, axes, c, lane);
+    if (ic < 0) break;
+    const D3 l = mulT(Rf, d3(px[ic], py[ic], pz[ic]) - c);
+    const double dd = 1 - (l.x / axes.x) * (l.x / axes.x) - (l.y / axes.y) * (l.y / axes.y);
+    if (dd > FH_DECOMP_EPS) axes.z = fabs(l.z) / sqrt(dd);
+    for (int i = lane; i < cnt; i += 64)
+      if ((flag[i] & 2) && !(1 - ell_dist(Rf, axes, c, d3(px[i], py[i], pz[i])) > FH_DECOMP_EPS)) flag[i] &= (unsigned char)~2;
+    __syncthreads();
+  }
+
+  // ---- separating planes (decomp_base.h:83-115), written straight as rows oriented around the midpoint (polyhedron.h:131-152)
+  int rows = 0;
+  bool too_many = false;
+  auto emit = [&](D3 p, D3 n) {
+    double off = dot(p, n);
+    if (dot(n, c) - off > 0) { n = n * -1.0; off = -off; }
+    if (rows < max_faces) {
+      if (lane == 0) { out[rows].a[0] = n.x; out[rows].a[1] = n.y; out[rows].a[2] = n.z; out[rows].b = off; }
+    } else too_many = true;
+    rows++;
+  };
+  for (int guard = 0; guard <= cnt; guard++) {
+    const int ic = closest_in(px, py, pz, flag, cnt, 4, Rf, axes, c, lane);
+    if (ic < 0) break;
+    const D3 cp = d3(px[ic], py[ic], pz[ic]);
+    const D3 l = mulT(Rf, cp - c);
+    const D3 g = mul(Rf, d3(l.x / (axes.x * axes.x), l.y / (axes.y * axes.y), l.z / (axes.z * axes.z)));
+    const double gn = norm(g);
+    if (!(gn > 0) || !isfinite(gn)) break;  // degenerate ellipsoid: no separating planes (as the host version)
+    const D3 n = g * (1.0 / gn);
+    emit(cp, n);
+    for (int i = lane; i < cnt; i += 64)
+      if ((flag[i] & 4) && !(dot(n, d3(px[i], py[i], pz[i]) - cp) < 0)) flag[i] &= (unsigned char)~4;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) emit(bp[k], bn[k]);
+  if (rows < max_faces) {  // ground plane -z <= -z_ground (jps_manager.cpp:113-124)
+    if (lane == 0) { out[rows].a[0] = 0; out[rows].a[1] = 0; out[rows].a[2] = -1; out[rows].b = -z_ground; }
+  } else too_many = true;
+  rows++;
+  if (lane == 0) *count_out = too_many ? -1 : rows;
+}
+
+// Persistent workgroups of one wavefront, segments taken in a grid-stride loop.  segments: [n][6] = p1, p2.  faces: [n][max_faces] rows
+// (a, b); counts[n] = rows written, -1 on overflow.  workspace: per workgroup 3 * CAP_GLOBAL doubles + CAP_GLOBAL bytes.
+__global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
+                                                    int n_segments, double bx, double by, double bz, double inflate, double z_ground,
+                                                    int max_faces, double* __restrict__ workspace, fh_face* __restrict__ faces,
+                                                    int32_t* __restrict__ counts) {
+  __shared__ double lpx[FH_DECOMP_CAP], lpy[FH_DECOMP_CAP], lpz[FH_DECOMP_CAP];
+  __shared__ unsigned char lflag[FH_DECOMP_CAP];  // bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
+  const int lane = threadIdx.x;
+  double* gpx = workspace + (size_t)blockIdx.x * (size_t)(3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8);
+  double* gpy = gpx + FH_DECOMP_CAP_GLOBAL;
+  double* gpz = gpy + FH_DECOMP_CAP_GLOBAL;
+  unsigned char* gflag = reinterpret_cast<unsigned char*>(gpz + FH_DECOMP_CAP_GLOBAL);
+  for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+    __syncthreads();
+    const D3 p1 = d3(segments[6 * seg + 0], segments[6 * seg + 1], segments[6 * seg + 2]);
+    const D3 p2 = d3(segments[6 * seg + 3], segments[6 * seg + 4], segments[6 * seg + 5]);
+    fh_face* out = faces + (size_t)seg * (size_t)max_faces;
+    // local bounding box (line_segment.h:57-98), plane order kept: +h, -h, +dir, -dir, +v, -v
+    const D3 dvec = p2 - p1;
+    const D3 dir = dvec * (1.0 / norm(dvec));
+    D3 dh = d3(dir.y, -dir.x, 0.0);
+    if (norm(dh) == 0) dh = d3(-1, 0, 0);
+    dh = dh * (1.0 / norm(dh));
+    const D3 dv = d3(dir.y * dh.z - dir.z * dh.y, dir.z * dh.x - dir.x * dh.z, dir.x * dh.y - dir.y * dh.x);
+    D3 bp[6], bn[6];
+    bp[0] = p1 + dh * by; bn[0] = dh;
+    bp[1] = p1 - dh * by; bn[1] = dh * -1.0;
+    bp[2] = p2 + dir * bx; bn[2] = dir;
+    bp[3] = p1 - dir * bx; bn[3] = dir * -1.0;
+    bp[4] = p1 + dv * bz; bn[4] = dv;
+    bp[5] = p1 - dv * bz; bn[5] = dv * -1.0;
+    // first sweep: how many cloud points fall in the box decides where the list lives
+    int cnt = 0;
+    for (int base = 0; base < n_cloud; base += 64) {
+      const int i = base + lane;
+      bool in = false;
+      if (i < n_cloud) {
+        const D3 q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
+        in = true;
+#pragma unroll
+        for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
+      }
+      cnt += __popcll(__ballot(in));
+    }
+    if (cnt <= FH_DECOMP_CAP)
+      decomp_segment(lpx, lpy, lpz, lflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane);
+    else if (cnt <= FH_DECOMP_CAP_GLOBAL)
+      decomp_segment(gpx, gpy, gpz, gflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane);
+    else if (lane == 0)
+      counts[seg] = -1;
+  }
+}
+
+}  // namespace fh

@@ -160,6 +160,19 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
                         const fh_face* d_faces, int n, double r_frac, double shrink, int max_safe_poly,
                         fh_problem* d_safe, fh_face* d_safe_faces);
 
+/* ---- next row N1 on the device: convex decomposition around path segments ------------------------------ */
+/* JPS_Manager::cvxEllipsoidDecomp (faster/src/jps_manager.cpp:80-127) for a batch of path segments that share one obstacle
+ * cloud: per segment the rows [a | b] of its polytope (separating planes of the inflated obstacle points found by DecompUtil's
+ * LineSegment3D::dilate, the 6 faces of the local bounding box, the ground plane -z <= -z_ground), oriented around the segment
+ * midpoint.  cloud_xyz: [n_cloud][3]; segments: [n_segments][6] = p1, p2; faces: [n_segments][max_faces]; counts[i] = rows of
+ * segment i, or -1 if it needs more than max_faces rows or has more than 1024 obstacle points inside its local box.
+ * local_bbox must be positive (FASTER uses (2, 2, 1)).  The host version copies in and out and synchronises. */
+int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_segments, int n_segments,
+                              const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* d_faces,
+                              int32_t* d_counts);
+int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const double* segments, int n_segments,
+                       const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* faces, int32_t* counts);
+
 int fh_sync(fh_ctx* ctx);
 
 /* Timing of the solve kernel, measured with HIP events recorded around every solve-kernel launch on

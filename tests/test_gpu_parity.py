@@ -391,3 +391,40 @@ def test_forest_corridors_config_c5(ctx, oracle):
     check_assignment_valid(pr, faces, got)
     pr2, faces2, _ = frontend.forest_batch(384, seed=6, n_seg=10, max_poly=6, force_final=False)
     compare(ctx.solve_batch(pr2, faces2), oracle.solve_batch(pr2, faces2))
+
+
+def test_gpu_decomposition_matches_host_frontend(ctx):
+    """Next row N1 on the device: fh_decompose_batch against the host front-end (faster_amd/host/corridor_frontend.hpp) on random
+    scenes and on forest paths; polytopes compared as sets of rows (the order of two touching points is a last-bit tie)."""
+    from faster_amd import build as fb, frontend
+
+    fb.build_frontend()
+    key = lambda M: M[np.lexsort(np.round(M, 7).T[::-1])]
+    rng = np.random.default_rng(7)
+    total = 0
+    for scene in range(6):
+        if scene < 4:
+            path = np.cumsum(np.vstack([rng.uniform(-3, 3, 3) * [1, 1, 0] + [0, 0, 1.2], rng.uniform(0.8, 2.5, (4, 1)) * (rng.normal(size=(4, 3)) * [1, 1, 0.2])]), axis=0)
+            path[:, 2] = np.clip(path[:, 2], 0.6, 2.4)
+            cloud = rng.uniform(path.min(0) - 2.5, path.max(0) + 2.5, size=(700, 3))
+            keep = np.ones(len(cloud), bool)
+            for a, b in zip(path[:-1], path[1:]):
+                t = np.clip(((cloud - a) @ (b - a)) / ((b - a) @ (b - a)), 0, 1)
+                keep &= np.linalg.norm(cloud - (a + t[:, None] * (b - a)), axis=1) > 0.45
+            cloud = cloud[keep]
+        else:
+            cloud, _ = frontend.forest_cloud(scene)
+            path = frontend.plan(cloud, (110, 110, 15), 0.2, np.array([10.0, 10.0, 1.5]), 0.0, 3.0, 0.3, np.array([1.5, 1.2, 1.0]), np.array([17.5, 18.0, 1.4]))
+            assert path is not None
+        segs = np.hstack([path[:-1], path[1:]])
+        faces, counts = ctx.decompose_batch(cloud, segs, drone_radius=0.05, z_ground=0.0, max_faces=64)
+        ref, _ = frontend.decompose(path, cloud, drone_radius=0.05, z_ground=0.0)
+        for i, (A, b) in enumerate(ref):
+            assert counts[i] == len(b), (scene, i, counts[i], len(b))
+            got = np.column_stack([faces["a"][i, :counts[i]], faces["b"][i, :counts[i]]])
+            np.testing.assert_allclose(key(got), key(np.column_stack([A, b])), atol=1e-9)
+            total += 1
+    assert total >= 20
+    # overflow reporting: too few rows allowed
+    faces, counts = ctx.decompose_batch(cloud, segs[:2], max_faces=8)
+    assert np.all(counts == -1)
