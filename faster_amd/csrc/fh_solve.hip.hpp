@@ -74,31 +74,59 @@ __device__ __forceinline__ double dpp_f64(double identity, double v) {
   hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), hi, CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// Zero-filling variant (bound_ctrl, every row written): no `old` operand to initialise.  Rows 0 and 2 pick up partial sums
+// they do not need in the row_bcast steps; only lane 63 is read, and it sees the values of before each step.
+template <int CTRL>
+__device__ __forceinline__ double dpp0_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// v_max_f64 / v_min_f64 without the canonicalising self-max the fmax/fmin lowering adds (no NaNs reach the reductions)
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// lanes l and l+32 exchange a double and add: both halves end up with the same sum (v_permlane32_swap, gfx950)
+__device__ __forceinline__ double halves_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<0x111, 0xf>(0.0, v);
-  v += dpp_f64<0x112, 0xf>(0.0, v);
-  v += dpp_f64<0x114, 0xf>(0.0, v);
-  v += dpp_f64<0x118, 0xf>(0.0, v);
-  v += dpp_f64<0x142, 0xa>(0.0, v);
-  v += dpp_f64<0x143, 0xc>(0.0, v);
+  v += dpp0_f64<0x111>(v);
+  v += dpp0_f64<0x112>(v);
+  v += dpp0_f64<0x114>(v);
+  v += dpp0_f64<0x118>(v);
+  v += dpp0_f64<0x142>(v);
+  v += dpp0_f64<0x143>(v);
   return readlane_f64(v, 63);
 }
-__device__ __forceinline__ double wave_max(double v) {
-  v = fmax(v, dpp_f64<0x111, 0xf>(-INFINITY, v));
-  v = fmax(v, dpp_f64<0x112, 0xf>(-INFINITY, v));
-  v = fmax(v, dpp_f64<0x114, 0xf>(-INFINITY, v));
-  v = fmax(v, dpp_f64<0x118, 0xf>(-INFINITY, v));
-  v = fmax(v, dpp_f64<0x142, 0xa>(-INFINITY, v));
-  v = fmax(v, dpp_f64<0x143, 0xc>(-INFINITY, v));
+// max(0, max over the lanes): every caller only asks whether the maximum is positive and where it sits
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+  v = vmax_f64(v, dpp0_f64<0x111>(v));
+  v = vmax_f64(v, dpp0_f64<0x112>(v));
+  v = vmax_f64(v, dpp0_f64<0x114>(v));
+  v = vmax_f64(v, dpp0_f64<0x118>(v));
+  v = vmax_f64(v, dpp0_f64<0x142>(v));
+  v = vmax_f64(v, dpp0_f64<0x143>(v));
   return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_min(double v) {
-  v = fmin(v, dpp_f64<0x111, 0xf>(INFINITY, v));
-  v = fmin(v, dpp_f64<0x112, 0xf>(INFINITY, v));
-  v = fmin(v, dpp_f64<0x114, 0xf>(INFINITY, v));
-  v = fmin(v, dpp_f64<0x118, 0xf>(INFINITY, v));
-  v = fmin(v, dpp_f64<0x142, 0xa>(INFINITY, v));
-  v = fmin(v, dpp_f64<0x143, 0xc>(INFINITY, v));
+  v = vmin_f64(v, dpp_f64<0x111, 0xf>(INFINITY, v));
+  v = vmin_f64(v, dpp_f64<0x112, 0xf>(INFINITY, v));
+  v = vmin_f64(v, dpp_f64<0x114, 0xf>(INFINITY, v));
+  v = vmin_f64(v, dpp_f64<0x118, 0xf>(INFINITY, v));
+  v = vmin_f64(v, dpp_f64<0x142, 0xa>(INFINITY, v));
+  v = vmin_f64(v, dpp_f64<0x143, 0xc>(INFINITY, v));
   return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int first_lane(bool pred) {  // lowest lane with pred, -1 if none (uniform)
@@ -412,16 +440,19 @@ struct Solver {
       const double c0 = CP[cl * 3 + 0], c1 = CP[cl * 3 + 1], c2 = CP[cl * 3 + 2];
       const double wi = wni[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
       int bf = -1;
-      double bvt = 0;
+      double bvt = (F > 0) ? 0.0 : INFINITY;  // dead lanes never take
+      const int fl = F > 0 ? F - 1 : 0;        // rows beyond the lane's polytope re-read its last row: never a strict improvement
+      const fh_face* fp = faces + f0;
       for (int fb = 0; fb < maxF; fb += 4) {
+        fh_face fc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fc[j] = fp[min(fb + j, fl)];  // the four loads in flight before the first use
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int f = fb + j;
-          const fh_face fc = faces[f0 + (f < F ? f : 0)];
-          const double vt = fma(fc.a[0], c0, fma(fc.a[1], c1, fma(fc.a[2], c2, fc.b)));
-          const bool take = (f < F) && vt > bvt;  // (an active row has v ~ 0, i.e. vt ~ -tol/|a| < 0: never re-selected)
+          const double vt = fma(fc[j].a[0], c0, fma(fc[j].a[1], c1, fma(fc[j].a[2], c2, fc[j].b)));
+          const bool take = vt > bvt;  // (an active row has v ~ 0, i.e. vt ~ -tol/|a| < 0: never re-selected)
           bvt = take ? vt : bvt;
-          bf = take ? f : bf;
+          bf = take ? fb + j : bf;
         }
       }
       if (bf >= 0) {
@@ -433,7 +464,7 @@ struct Solver {
       }
     }
     const_bad = wave_any(bad);
-    const double mx = wave_max(bs);
+    const double mx = wave_max_nonneg(bs);
     id_out = -1;
     v_out = 0;
     if (mx > 0) {
@@ -505,6 +536,56 @@ struct Solver {
     return a0 + a1;
   }
 
+  // Two-way split of the same sweeps for NVP <= 32: lanes l and l+32 serve the same row/column, take alternate blocks of
+  // four terms and exchange their partial sums, so that the upper half of the wavefront is not idle.
+  // (For NVP = 32 a trip covers 16 terms, 8 per half, with every load issued before the first use; the padded length is
+  // rounded up to 16, which stays inside the zero padding.)
+  static constexpr int SPLIT_U = (NVP % 16 == 0) ? 8 : 4;
+  __device__ __forceinline__ double col_dot2(const double* __restrict__ M, int col, const double* __restrict__ v, int n8) const {
+    const int hh = (lane >> 5) * 4;
+    const double* Mc = M + hh * S + col;
+    const double* vv = v + hh;
+    const int nn = (n8 + 2 * SPLIT_U - 1) & ~(2 * SPLIT_U - 1);
+    double a0 = 0, a1 = 0;
+    for (int i0 = 0; i0 < nn; i0 += 2 * SPLIT_U) {
+      double m[SPLIT_U], w[SPLIT_U];
+#pragma unroll
+      for (int j = 0; j < SPLIT_U; j++) {
+        const int k = i0 + (j >> 2) * 8 + (j & 3);
+        m[j] = Mc[k * S];
+        w[j] = vv[k];
+      }
+#pragma unroll
+      for (int j = 0; j < SPLIT_U; j += 2) {
+        a0 += m[j] * w[j];
+        a1 += m[j + 1] * w[j + 1];
+      }
+    }
+    return halves_sum(a0 + a1);
+  }
+  __device__ __forceinline__ double row_dot2(const double* __restrict__ M, int row, const double* __restrict__ v, int q8) const {
+    const int hh = (lane >> 5) * 4;
+    const double* Mr = M + row * S + hh;
+    const double* vv = v + hh;
+    const int nn = (q8 + 2 * SPLIT_U - 1) & ~(2 * SPLIT_U - 1);
+    double a0 = 0, a1 = 0;
+    for (int c0 = 0; c0 < nn; c0 += 2 * SPLIT_U) {
+      double m[SPLIT_U], w[SPLIT_U];
+#pragma unroll
+      for (int j = 0; j < SPLIT_U; j++) {
+        const int k = c0 + (j >> 2) * 8 + (j & 3);
+        m[j] = Mr[k];
+        w[j] = vv[k];
+      }
+#pragma unroll
+      for (int j = 0; j < SPLIT_U; j += 2) {
+        a0 += m[j] * w[j];
+        a1 += m[j + 1] * w[j + 1];
+      }
+    }
+    return halves_sum(a0 + a1);
+  }
+
   // Same sweeps with the vector operand taken from registers (lane k holds v_k) and broadcast with v_readlane instead of
   // LDS broadcast reads: the LDS pipe is the busiest unit of this kernel, the VALU has headroom.
   __device__ __forceinline__ double col_dot_reg(const double* __restrict__ M, int col, double vreg, int n8) const {
@@ -535,6 +616,28 @@ struct Solver {
   // pass cancels more than half of |g|^2 (Daniel-Gragg-Kaufman-Stewart).  returns |z|^2 ----
   __device__ double project(double gg, double gv, double& dc, double& zi) {
     const int n8 = (n + 7) & ~7, q8 = (q + 7) & ~7;
+    if constexpr (NVP <= 32) {
+      const int l5 = lane & 31;
+      const int ll = l5 < NVP ? l5 : NVP - 1;  // lanes beyond the padded size compute a harmless duplicate
+      dc = row_dot2(Q, ll, g, n8);
+      if (lane < NVP) d[lane] = dc;
+      FH_SYNC();
+      zi = g[ll] - col_dot2(Q, ll, d, q8);
+      if (lane >= NVP) zi = 0.0;
+      double zz = wave_sum(zi * zi);
+      if (zz < FH_REORTH_THRESHOLD * gg) {
+        if (lane < NVP) z[lane] = zi;
+        FH_SYNC();
+        const double ec = row_dot2(Q, ll, z, n8);
+        dc += ec;
+        if (lane < NVP) r[lane] = ec;
+        FH_SYNC();
+        zi -= col_dot2(Q, ll, r, q8);
+        if (lane >= NVP) zi = 0.0;
+        zz = wave_sum(zi * zi);
+      }
+      return zz;
+    }
     const int ll = lane < NVP ? lane : NVP - 1;  // lanes beyond the padded size compute a harmless duplicate
 #ifndef FH_READLANE_BROADCAST
     dc = row_dot(Q, ll, g, n8);
@@ -932,7 +1035,7 @@ struct Solver {
       }
       fullassign[lane] = full;
     }
-    const double bw = wave_max(score);
+    const double bw = wave_max_nonneg(score);
     FH_SYNC();
     if (!(bw > 0.0)) return -1;  // (normalised rows carry the tolerance)
     return first_lane(score == bw);
