@@ -65,6 +65,35 @@ __device__ __forceinline__ double uniform_f64(double v) {
 }
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Scheduling fences.  in_flight(a): every element of `a` (just loaded) must be in its register here, so the loads are issued
+// back to back and their LDS latencies overlap (the scheduler of this register-tight kernel otherwise serialises
+// load -> wait -> use chains to save registers).  opaque(v): hides a lane constant from loop-invariant code motion, so that
+// values derived from it are recomputed where they are used instead of living in registers across the whole solve.
+__device__ __forceinline__ void in_flight(double (&a)[3]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])); }
+__device__ __forceinline__ void in_flight(double (&a)[4]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
+__device__ __forceinline__ void in_flight(double (&a)[6]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+}
+__device__ __forceinline__ void in_flight(double (&a)[9]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
+}
+__device__ __forceinline__ void in_flight(double (&a)[10]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]));
+}
+__device__ __forceinline__ void in_flight(double (&a)[12]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
+}
+__device__ __forceinline__ void in_flight(double (&a)[16]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+__device__ __forceinline__ double opaque(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // Wave64 reductions on the DPP network (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 / row_bcast:31
 // across rows; the total lands in lane 63) instead of ds_bpermute round trips through the LDS crossbar.
 template <int CTRL, int ROW_MASK>
@@ -379,16 +408,27 @@ struct Solver {
   __device__ void compute_states() {
     if (lane < (N + 1) * 3) {
       const int tt = lane / 3, i = lane - 3 * tt;
-      double p = P0[lane], v = V0[lane], a = A0[lane];
-      const double h2 = h * h, h3 = h2 * h;
+      // sum_{s<tt} c(m) x_s with m = tt-1-s and c polynomial in m: three moments S_k = sum m^k x_s carry all three states
+      // (cP = h^3 (1/6 + m/2 + m^2/2), cV = h^2 (1/2 + m), cA = h); nothing per-(lane, s) to keep in registers.
+      double xr[NSEG];
 #pragma unroll
-      for (int s = 0; s < NSEG; s++) {  // all loads in flight at once; segments s >= tt contribute nothing
-        const double xs = (s < tt) ? x[3 * s + i] : 0.0;
-        const double dm = (double)(tt - 1 - s);
-        p += h3 * (1.0 / 6.0 + 0.5 * dm + 0.5 * dm * dm) * xs;
-        v += h2 * (0.5 + dm) * xs;
-        a += h * xs;
+      for (int s = 0; s < NSEG; s++) xr[s] = x[3 * s + i];  // unpredicated (x is zero padded)
+      in_flight(xr);
+      double s0 = 0, s1 = 0, s2 = 0;
+      const double dm0 = opaque((double)(tt - 1));
+#pragma unroll
+      for (int s = 0; s < NSEG; s++) {
+        const double dm = dm0 - (double)s;
+        const double xs = xr[s] * fmin(fmax(dm + 1.0, 0.0), 1.0);  // segments s >= tt contribute nothing
+        const double t1 = dm * xs;
+        s0 += xs;
+        s1 += t1;
+        s2 = fma(dm, t1, s2);
       }
+      const double h2 = h * h, h3 = h2 * h;
+      const double p = P0[lane] + h3 * (s0 * (1.0 / 6.0) + 0.5 * s1 + 0.5 * s2);
+      const double v = V0[lane] + h2 * (0.5 * s0 + s1);
+      const double a = A0[lane] + h * s0;
       Pc[lane] = p; Vc[lane] = v; Ac[lane] = a;
     }
     FH_SYNC();
@@ -397,8 +437,12 @@ struct Solver {
       const int o = (t + (k == 3 ? 1 : 0)) * 3;
       const double wv = k == 1 ? h / 3.0 : (k == 2 ? 2.0 * h / 3.0 : 0.0);
       const double wa = k == 2 ? h * h / 6.0 : 0.0;
+      double st[9];
 #pragma unroll
-      for (int i = 0; i < 3; i++) CP[lane * 3 + i] = Pc[o + i] + wv * Vc[o + i] + wa * Ac[o + i];
+      for (int i = 0; i < 3; i++) { st[i] = Pc[o + i]; st[3 + i] = Vc[o + i]; st[6 + i] = Ac[o + i]; }
+      in_flight(st);
+#pragma unroll
+      for (int i = 0; i < 3; i++) CP[lane * 3 + i] = st[i] + wv * st[3 + i] + wa * st[6 + i];
     }
     FH_SYNC();
   }
@@ -673,35 +717,28 @@ struct Solver {
   }
 
   // ---- r = R^{-1} d, column-oriented; lane c returns r_c ----
+  // Row-scaled recurrence: lane l carries (d_l - sum_{j>l} R_lj r_j) / R_ll, which is final (= r_l) once column l has been
+  // consumed, so that the serial chain per column is one broadcast and one FMA; the scaled, masked coefficients
+  // R_lc / R_ll do not depend on the recurrence and are prepared four columns ahead.
   __device__ double backsolve(double dc) {
-    double rc = 0;
     const int ll = lane < NVP ? lane : NVP - 1;
     const double ri = (lane < q) ? rinv[lane] : 0.0;
-    double dcur = dc;
+    double dh = dc * ri;
     int c = q - 1;
-    for (; c >= 3; c -= 4) {  // the four R loads do not depend on the recurrence: issue them first
-      const double r0 = R[rp(min(ll, c), c)], r1 = R[rp(min(ll, c - 1), c - 1)], r2 = R[rp(min(ll, c - 2), c - 2)],
-                   r3 = R[rp(min(ll, c - 3), c - 3)];
-      double val = readlane_f64(dcur * ri, c);
-      if (lane == c) rc = val;
-      if (lane < c) dcur -= r0 * val;
-      val = readlane_f64(dcur * ri, c - 1);
-      if (lane == c - 1) rc = val;
-      if (lane < c - 1) dcur -= r1 * val;
-      val = readlane_f64(dcur * ri, c - 2);
-      if (lane == c - 2) rc = val;
-      if (lane < c - 2) dcur -= r2 * val;
-      val = readlane_f64(dcur * ri, c - 3);
-      if (lane == c - 3) rc = val;
-      if (lane < c - 3) dcur -= r3 * val;
+    for (; c >= 3; c -= 4) {
+      double m[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) m[j] = R[rp(min(ll, c - j), c - j)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) m[j] = (lane < c - j) ? m[j] * ri : 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) dh = fma(-m[j], readlane_f64(dh, c - j), dh);
     }
-    for (; c >= 0; c--) {
-      const double r0 = R[rp(min(ll, c), c)];
-      const double val = readlane_f64(dcur * ri, c);
-      if (lane == c) rc = val;
-      if (lane < c) dcur -= r0 * val;
+    for (; c >= 1; c--) {
+      const double m0 = (lane < c) ? R[rp(min(ll, c), c)] * ri : 0.0;
+      dh = fma(-m0, readlane_f64(dh, c), dh);
     }
-    return rc;
+    return dh;
   }
 
   __device__ void add_row(int id, double zi, double zz, double dc, double up) {
@@ -966,27 +1003,36 @@ struct Solver {
     allowed_first = allowed_last = 0xffffffffu;
     if (P == 0) return;
     bool ok0 = false, okN = false;
-    if (lane < P) {
-      double w0 = -INFINITY, wN = -INFINITY;
-      const int f0 = face_off[lane], f1 = face_off[lane + 1];
-      for (int k = 0; k < 3; k++) {
-        double c0[3], cN[3];
+    {  // one lane per polytope, wave-uniform trip count (lanes beyond P and rows beyond a polytope re-read a valid row)
+      const bool live = lane < P;
+      const int f0 = live ? face_off[lane] : 0, F = live ? face_off[lane + 1] - f0 : 0;
+      const int fl = F > 0 ? F - 1 : 0;
+      const fh_face* fp = faces + f0;
+      double c0[9], cN[9];
+      const double h3 = h / 3.0, h23 = 2.0 * h / 3.0, h26 = h * h / 6.0;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const double p0 = pr.x0[i], v0 = pr.x0[3 + i], a0 = pr.x0[6 + i];
-          const double pf = xfl[i], vf = xfl[3 + i], af = xfl[6 + i];
-          c0[i] = k == 0 ? p0 : (k == 1 ? p0 + v0 * (h / 3.0) : p0 + v0 * (2.0 * h / 3.0) + a0 * (h * h / 6.0));
-          cN[i] = k == 0 ? pf : (k == 1 ? pf - vf * (h / 3.0) : pf - vf * (2.0 * h / 3.0) + af * (h * h / 6.0));
-        }
-#pragma unroll 4
-        for (int f = f0; f < f1; f++) {
-          const fh_face fc = faces[f];
-          w0 = fmax(w0, fma(fc.a[0], c0[0], fma(fc.a[1], c0[1], fma(fc.a[2], c0[2], fc.b))));
-          wN = fmax(wN, fma(fc.a[0], cN[0], fma(fc.a[1], cN[1], fma(fc.a[2], cN[2], fc.b))));
+      for (int i = 0; i < 3; i++) {
+        const double p0 = pr.x0[i], v0 = pr.x0[3 + i], a0 = pr.x0[6 + i];
+        const double pf = xfl[i], vf = xfl[3 + i], af = xfl[6 + i];
+        c0[i] = p0; c0[3 + i] = p0 + v0 * h3; c0[6 + i] = p0 + v0 * h23 + a0 * h26;
+        cN[i] = pf; cN[3 + i] = pf - vf * h3; cN[6 + i] = pf - vf * h23 + af * h26;
+      }
+      double w0 = -INFINITY, wN = -INFINITY;
+      for (int fb = 0; fb < maxF; fb += 2) {
+        fh_face fc[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fc[j] = fp[min(fb + j, fl)];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            w0 = vmax_f64(w0, fma(fc[j].a[0], c0[3 * k], fma(fc[j].a[1], c0[3 * k + 1], fma(fc[j].a[2], c0[3 * k + 2], fc[j].b))));
+            wN = vmax_f64(wN, fma(fc[j].a[0], cN[3 * k], fma(fc[j].a[1], cN[3 * k + 1], fma(fc[j].a[2], cN[3 * k + 2], fc[j].b))));
+          }
         }
       }
-      ok0 = !(w0 > 0.0);
-      okN = !(wN > 0.0);
+      ok0 = live && F > 0 ? !(w0 > 0.0) : live;
+      okN = live && F > 0 ? !(wN > 0.0) : live;
     }
     allowed_first = (unsigned)__ballot(ok0);
     if (force_final) allowed_last = (unsigned)__ballot(okN);
@@ -1005,20 +1051,27 @@ struct Solver {
       const int t = live ? pair / P : 0, p = live ? pair - t * P : 0;
       const bool need = live && assign[t] < 0 && ((allowed_mask(t) >> p) & 1u);
       const int f0 = face_off[p], F = need ? face_off[p + 1] - f0 : 0;
+      // every face row is read once for the four control points of the segment; rows beyond the polytope re-read its last
+      // row (harmless for a maximum), so that the trip count is wave-uniform and four rows are in flight
+      double c[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) c[k] = CP[t * 12 + k];
+      in_flight(c);
+      const int fl = F > 0 ? F - 1 : 0;
+      const fh_face* fp = faces + f0;
       double worst = -INFINITY;
+      for (int fb = 0; fb < maxF; fb += 4) {
+        fh_face fc[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const double c0 = CP[(t * 4 + k) * 3 + 0], c1 = CP[(t * 4 + k) * 3 + 1], c2 = CP[(t * 4 + k) * 3 + 2];
-        for (int fb = 0; fb < maxF; fb += 4) {
+        for (int j = 0; j < 4; j++) fc[j] = fp[min(fb + j, fl)];
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int f = fb + j;
-            const fh_face fc = faces[f0 + (f < F ? f : 0)];
-            const double v = fma(fc.a[0], c0, fma(fc.a[1], c1, fma(fc.a[2], c2, fc.b)));
-            worst = (f < F) ? fmax(worst, v) : worst;
-          }
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            worst = vmax_f64(worst, fma(fc[j].a[0], c[3 * k], fma(fc[j].a[1], c[3 * k + 1], fma(fc[j].a[2], c[3 * k + 2], fc[j].b))));
         }
       }
+      if (!need) worst = -INFINITY;
       if (live) viol[t * FH_MAX_POLY + p] = (assign[t] < 0 && !need) ? INFINITY : worst;
     }
     FH_SYNC();
