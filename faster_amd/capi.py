@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
-    "fh_solve_batch", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device",
+    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device",
     "fh_decompose_batch", "fh_decompose_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
@@ -49,6 +49,8 @@ def lib():
         L.fh_set_stream.argtypes = [vp, vp]
         L.fh_solve_batch.restype = i32
         L.fh_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.fh_solve_batch_speculative.restype = i32
+        L.fh_solve_batch_speculative.argtypes = [vp, vp, vp, i64, i32, i32, vp]
         L.fh_solve_batch_device.restype = i32
         L.fh_solve_batch_device.argtypes = [vp, vp, vp, i32, i32, i32, vp]
         L.fh_sample_batch.restype = i32
@@ -135,6 +137,17 @@ class Context:
         fptr = abi.ptr(faces) if faces.shape[0] else None
         self._check(lib().fh_solve_batch(self._h, abi.ptr(problems), fptr, faces.shape[0], problems.shape[0], abi.ptr(res)),
                     "fh_solve_batch")
+        return res
+
+    def solve_batch_speculative(self, problems, faces, width):
+        """fh_solve_batch with the factor line search run `width` factors at a time (same results, lower latency)."""
+        problems = np.ascontiguousarray(problems)
+        faces = np.ascontiguousarray(faces)
+        assert problems.dtype == abi.problem_dtype and faces.dtype == abi.face_dtype
+        res = np.zeros(problems.shape[0], dtype=abi.result_dtype)
+        fptr = abi.ptr(faces) if faces.shape[0] else None
+        self._check(lib().fh_solve_batch_speculative(self._h, abi.ptr(problems), fptr, faces.shape[0], problems.shape[0],
+                                                     int(width), abi.ptr(res)), "fh_solve_batch_speculative")
         return res
 
     def sample_batch(self, problems, results, max_samples):

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -220,6 +221,82 @@ int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces
   if (rc != FH_OK) return rc;
   FH_HIP(hipMemcpyAsync(results, ctx->d_buf[2], sizeof(fh_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+
+int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
+                               int width, fh_result* results) {
+  if (!ctx || n < 0 || n_faces < 0) return FH_ERR_ARG;
+  if (width <= 1 || ctx->par.max_work > 0) return fh_solve_batch(ctx, problems, faces, n_faces, n, results);
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  if (n == 0) return FH_OK;
+  if (!problems || !results || (n_faces > 0 && !faces)) return FH_ERR_ARG;
+  // the factors of every problem, accumulated exactly as the reference loop does (repeated += in double)
+  struct Search {
+    std::vector<double> factors;
+    size_t next = 0;
+    bool done = false, passthrough = false;
+    long long nodes = 0, iters = 0;
+  };
+  std::vector<Search> search((size_t)n);
+  for (int i = 0; i < n; i++) {
+    const fh_problem& p = problems[i];
+    Search& s = search[(size_t)i];
+    const bool window_ok = p.f_inc > 0 && std::isfinite(p.f_init) && std::isfinite(p.f_final) &&
+                           (p.f_final - p.f_init) / p.f_inc <= (double)FH_MAX_TRIALS;
+    if (!window_ok) { s.passthrough = true; continue; }  // the kernel reports FH_ST_BAD_INPUT
+    for (double f = p.f_init; f <= p.f_final; f = f + p.f_inc) s.factors.push_back(f);
+    if (s.factors.empty()) s.passthrough = true;          // empty window: zero trials, as the sequential search
+  }
+  std::vector<fh_problem> sub;
+  std::vector<int> owner;
+  std::vector<fh_result> sub_res;
+  for (;;) {
+    sub.clear();
+    owner.clear();
+    for (int i = 0; i < n; i++) {
+      Search& s = search[(size_t)i];
+      if (s.done) continue;
+      if (s.passthrough) { sub.push_back(problems[i]); owner.push_back(i); continue; }
+      for (int k = 0; k < width && s.next + (size_t)k < s.factors.size(); k++) {
+        fh_problem q = problems[i];
+        q.f_init = q.f_final = s.factors[s.next + (size_t)k];
+        q.f_inc = 1.0;
+        sub.push_back(q);
+        owner.push_back(i);
+      }
+    }
+    if (sub.empty()) break;
+    sub_res.resize(sub.size());
+    const int rc = fh_solve_batch(ctx, sub.data(), faces, n_faces, (int)sub.size(), sub_res.data());
+    if (rc != FH_OK) return rc;
+    for (size_t a = 0; a < sub.size();) {
+      const int i = owner[a];
+      Search& s = search[(size_t)i];
+      size_t b = a;
+      while (b < sub.size() && owner[b] == i) b++;
+      if (s.passthrough) {
+        results[i] = sub_res[a];
+        s.done = true;
+      } else {
+        for (size_t k = a; k < b && !s.done; k++) {
+          const fh_result& r = sub_res[k];
+          s.nodes += r.nodes;
+          s.iters += r.qp_iters;
+          s.next++;
+          const bool last = s.next == s.factors.size();
+          if (r.solved || r.status == FH_ST_BAD_INPUT || last) {
+            results[i] = r;
+            results[i].trials = r.status == FH_ST_BAD_INPUT ? 0 : (int32_t)s.next;
+            results[i].nodes = (int32_t)s.nodes;
+            results[i].qp_iters = (int32_t)s.iters;
+            s.done = true;
+          }
+        }
+      }
+      a = b;
+    }
+  }
   return FH_OK;
 }
 

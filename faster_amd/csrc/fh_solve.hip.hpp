@@ -93,6 +93,10 @@ __device__ __forceinline__ double opaque(double v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // Wave64 reductions on the DPP network (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 / row_bcast:31
 // across rows; the total lands in lane 63) instead of ds_bpermute round trips through the LDS crossbar.
@@ -933,6 +937,9 @@ struct Solver {
   }
   __device__ int qp_loop(double ub, int max_iters, int& it, double& cost) {
     for (;;) {
+#ifdef FH_OPAQUE_LANE  // (measured: 184 instead of 226 VGPRs, 3 % slower)
+      lane = opaque(lane);  // lane-derived indices and masks are recomputed per iteration instead of being kept (and spilled) across the solve
+#endif
       { FH_T0(); compute_states(); FH_T1(2); }
       int id;
       double vp;

@@ -120,7 +120,8 @@ void SolverHip::absorb(const fh_result& r) {
 
 int SolverHip::solveProblems(const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n, fh_result* results) {
   if (!ensureContext()) return device_rc_ != FH_OK ? device_rc_ : FH_ERR_DEVICE;
-  const int rc = fh_solve_batch(ctx_, problems, faces, n_faces, n, results);
+  // concurrent_factors_ <= 1: the sequential line search inside one wavefront; otherwise the same search, `width` factors at a time
+  const int rc = fh_solve_batch_speculative(ctx_, problems, faces, n_faces, n, concurrent_factors_, results);
   if (rc != FH_OK) device_err_ = fh_last_error(ctx_);
   return rc;
 }

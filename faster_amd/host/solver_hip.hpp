@@ -50,6 +50,9 @@ public:
   void createVars() {}
   void setMaxConstraints() {}
   void setThreads(int) {}
+  // Extension (no reference counterpart): run the factor line search of genNewTraj `width` factors at a time on separate
+  // wavefronts (fh_solve_batch_speculative): same result as the sequential search, lower latency for a single replan.
+  void setConcurrentFactors(int width) { concurrent_factors_ = width < 1 ? 1 : width; }
   void setVerbose(int verbose) { verbose_ = verbose; }
   void setWMax(double w_max) { w_max_ = w_max; }  // isWmaxSatisfied is commented out in the reference (:459-462)
   void setMode(int mode) { mode_ = mode; }
@@ -92,6 +95,7 @@ protected:
   std::vector<LinearConstraint3D> polytopes_;
   bool forceFinalConstraint_ = true;
   double factor_initial_ = 2, factor_final_ = 2, factor_increment_ = 2;  // solverGurobi.hpp:178-180
+  int concurrent_factors_ = 1;
   double w_max_ = 1;
   int mode_ = 0;
   int verbose_ = 0;

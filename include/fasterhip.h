@@ -131,6 +131,18 @@ int fh_set_stream(fh_ctx* ctx, void* hip_stream);
 int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
                    fh_result* results);
 
+/* Concurrent time-allocation search: same inputs, outputs and RESULTS as fh_solve_batch, but the factor
+ * line search of genNewTraj (solverGurobi.cpp:445-446, `for (i = f_init; i <= f_final && !solved; i += f_inc)`) is run
+ * `width` factors at a time, every factor as its own single-trial problem on its own wavefront, and the first (smallest)
+ * feasible factor wins.  Trials of the reference are independent of one another (the model is rebuilt from scratch per
+ * trial, :447-466), so this is the sequential first-feasible rule evaluated concurrently: factor, dt, coefficients, cost,
+ * assignment and `trials` (= index of the winning factor + 1) are bit-identical to fh_solve_batch; nodes / qp_iters are
+ * summed over the trials the sequential search would have run.  Meant for single problems and small batches (a replan is
+ * ONE whole + ONE safe solve): it trades up to `width` times the work for the latency of one trial.  width <= 1, or a
+ * work cap (fh_params.max_work > 0, which couples the trials), falls back to fh_solve_batch. */
+int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
+                               int width, fh_result* results);
+
 /* Same, with every pointer already resident in device memory (HBM). Asynchronous on the
  * context's stream; call fh_sync() before reading results.  max_seg / max_faces are upper bounds on
  * n_seg and on the per-problem face count of the batch (they select the kernel instantiation and its

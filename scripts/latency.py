@@ -14,11 +14,21 @@ for name, (pr, faces) in cases.items():
     for _ in range(50):
         t = time.perf_counter(); r = ctx.solve_batch(pr, faces); ts.append(time.perf_counter() - t)
     print("%-34s median %.3f ms  min %.3f ms  kernel %.3f ms  (iters %d nodes %d)" % (name, 1e3 * np.median(ts), 1e3 * min(ts), ctx.last_kernel_ms(), r["qp_iters"][0], r["nodes"][0]))
+    for width in (3, 10):  # N4: the same line search, `width` factors at a time
+        ts = []
+        for _ in range(50):
+            t = time.perf_counter(); r2 = ctx.solve_batch_speculative(pr, faces, width); ts.append(time.perf_counter() - t)
+        assert all(np.array_equal(r2[k], r[k]) for k in abi.result_dtype.names)
+        print("%-34s   width %2d: median %.3f ms  min %.3f ms  (trials %d)" % ("", width, 1e3 * np.median(ts), 1e3 * min(ts), r2["trials"][0]))
 for n in (1, 16, 256):
     ts = []
     for _ in range(20):
         t = time.perf_counter(); r = ctx.solve_batch(w[:n], f); ts.append(time.perf_counter() - t)
     print("synthetic C4-whole batch %4d: median %.3f ms (%.1f us/solve) kernel %.3f ms" % (n, 1e3 * np.median(ts), 1e6 * np.median(ts) / n, ctx.last_kernel_ms()))
+    ts = []
+    for _ in range(20):
+        t = time.perf_counter(); r2 = ctx.solve_batch_speculative(w[:n], f, 10); ts.append(time.perf_counter() - t)
+    print("   same, 10 factors at a time      : median %.3f ms (mean trials %.2f)" % (1e3 * np.median(ts), r2["trials"].mean()))
 # PCIe-inclusive throughput of the host-pointer path at the bench batch size
 w, f, _ = corridor.whole_batch(32768, seed=3, p_choices=(2, 3, 4, 5, 6))
 ctx.solve_batch(w, f)

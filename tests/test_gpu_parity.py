@@ -428,3 +428,24 @@ def test_gpu_decomposition_matches_host_frontend(ctx):
     # overflow reporting: too few rows allowed
     faces, counts = ctx.decompose_batch(cloud, segs[:2], max_faces=8)
     assert np.all(counts == -1)
+
+
+def test_concurrent_factor_search_is_the_sequential_rule(ctx):
+    """the line search run `width` factors at a time returns the sequential first-feasible result bit
+    for bit (factor_that_worked_ semantics of solverGurobi.cpp:445-467), incl. unsolved, empty-window and bad records."""
+    whole, faces, _ = corridor.whole_batch(96, seed=21, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    safe, sfaces, _ = corridor.safe_batch(64, seed=22)
+    pr, fc = corridor.concat([(whole, faces), (safe, sfaces)])
+    pr = pr.copy()
+    pr["f_inc"][:40] = 0.5                      # 19 factors in [1, 10]
+    pr["f_final"][40:48] = 1.5                  # short windows: mostly unsolved
+    pr["f_init"][48:50] = 11.0                  # empty window
+    pr["n_seg"][50] = 0                         # bad record
+    pr["f_inc"][51] = 0.0                       # bad window
+    seq = ctx.solve_batch(pr, fc)
+    assert (seq["solved"] == 1).sum() > 60 and (seq["solved"] == 0).sum() > 8 and seq["trials"].max() >= 4
+    for width in (2, 3, 10, 64):
+        got = ctx.solve_batch_speculative(pr, fc, width)
+        for name in abi.result_dtype.names:
+            assert np.array_equal(got[name], seq[name]), (width, name)
+    assert np.array_equal(ctx.solve_batch_speculative(pr, fc, 1)["coeff"], seq["coeff"])
