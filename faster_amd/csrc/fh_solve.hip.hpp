@@ -264,22 +264,28 @@ struct Solver {
 
   // ---- LDS carve (doubles first) ----
   double *Q, *R;                                      // Q1 column major [NVP cols][S] (column c = active slot); R packed upper triangular [RPSZ]
-  double *x, *z, *g, *d, *r, *u, *rinv, *bestx;       // [NVP]
-  double *P0, *V0, *A0, *Pc, *Vc, *Ac;                // [NT*3] jerk-free / current states at segment starts
+  double *x, *z, *g, *d, *r, *u, *rinv;               // [NVP] (r aliases d: only live inside the re-orthogonalisation pass)
+  double *Pc, *Vc, *Ac;                               // [NT*3] current states at segment starts
   double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
-  double* wni;                                        // [W_KINDS][NT] their inverses (0 where the factor is 0)
+  double* wtab;                                       // [W_KINDS][NT] scratch (aliases z..): inverse row norms, read once per trial
   double* viol;                                       // [NSEG][FH_MAX_POLY]
   double* xfl;                                        // [9] goal state (+3 pad)
   double* tolf;                                       // [n_faces] feas_tol / |a_f|
   fh_face* faces;                                     // [n_faces] NORMALISED rows: a/|a| and bt = -(b + feas_tol)/|a|, so that
                                                       //           a.cp + bt > 0  <=>  the original row is violated by more than feas_tol
-  int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_order, *face_off;
+  int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *face_off;
+  signed char* stk_order;                             // [NSEG][FH_MAX_POLY] child order per tree level
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 5 * NVP + 6 * NT * 3 + NSEG * 12 + W_KINDS * NT + 12) +
-           sizeof(int) * (7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 1 + 3) + (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
+    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 3 * NVP + 3 * NT * 3 + NSEG * 12 + 12) +
+           sizeof(int) * (8 * NSEG + FH_MAX_POLY + 1 + 3) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
+           (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
   }
 
+  // ---- per-lane state kept in registers (LDS is what limits the number of resident solves) ----
+  double p0r, v0r, a0r;   // lane = (tt, i) < 3 NT: zero-jerk propagation of x0 to the start of segment tt (per trial)
+  double wbv, wba, wcp;   // inverse row norms of this lane's box rows (lane = (t, i)) and corridor rows (lane = (t, k)) (per trial)
+  double bestx_r;         // lane < n: incumbent jerks
   // ---- wave-uniform scalars ----
   int lane, N, n, q, P;
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
@@ -305,21 +311,20 @@ struct Solver {
     x = p; p += NVP;  u = p; p += NVP;  rinv = p; p += NVP;
     act = reinterpret_cast<int*>(p); p += NVP / 2;
     // ---- end of the snapshot block ----
-    z = p; p += NVP;  g = p; p += NVP;  d = p; p += NVP;  r = p; p += NVP;  bestx = p; p += NVP;
-    P0 = p; p += NT * 3;  V0 = p; p += NT * 3;  A0 = p; p += NT * 3;
+    z = p; p += NVP;  g = p; p += NVP;  d = p; p += NVP;  r = d;
     Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
     CP = p; p += NSEG * 12;
-    wni = p; p += W_KINDS * NT;
-    viol = z;  // [NSEG][FH_MAX_POLY] aliases z,g,d,r: only live between two active-set runs (analyze, init_equalities)
-    static_assert(NSEG * FH_MAX_POLY <= 4 * NVP && 3 * NT + 9 <= 4 * NVP, "viol / equality scratch must fit in z,g,d,r");
+    viol = z;  // [NSEG][FH_MAX_POLY] aliases z,g,d: only live between two active-set runs (analyze, init_equalities)
+    wtab = z;  // [W_KINDS][NT], live inside setup_trial only
+    static_assert(NSEG * FH_MAX_POLY <= 3 * NVP && 3 * NT + 9 <= 3 * NVP && W_KINDS * NT <= 3 * NVP, "scratch must fit in z,g,d");
     xfl = p; p += 12;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
     stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_q = ip; ip += NSEG;
-    stk_order = ip; ip += NSEG * FH_MAX_POLY;
     face_off = ip; ip += FH_MAX_POLY + 1;
-    ip += (4 - ((7 * NSEG + NSEG * FH_MAX_POLY + FH_MAX_POLY + 1) & 3)) & 3;  // back to 16-B alignment
-    faces = reinterpret_cast<fh_face*>(ip);  // [max_faces] 32-B rows, read 16 B at a time
+    stk_order = reinterpret_cast<signed char*>(ip);
+    const size_t off = (size_t)(reinterpret_cast<unsigned char*>(ip) - base) + NSEG * FH_MAX_POLY;
+    faces = reinterpret_cast<fh_face*>(base + ((off + 15) & ~(size_t)15));  // [max_faces] 32-B rows, read 16 B at a time
     tolf = reinterpret_cast<double*>(faces + max_faces);
   }
 
@@ -379,22 +384,26 @@ struct Solver {
   __device__ void init_problem() {
     for (int i = lane; i < NVP * S; i += 64) Q[i] = 0.0;
     for (int i = lane; i < RPSZ; i += 64) R[i] = 0.0;
-    if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; r[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
+    if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
     q = 0;
     FH_SYNC();
   }
 
   // ---- per trial: jerk-free states and row-norm table for step h ----
   __device__ void setup_trial(const fh_problem& pr) {
-    if (lane < 3) {  // zero-jerk propagation of x0 (3 lanes, N serial steps)
-      double p = pr.x0[lane], v = pr.x0[3 + lane], a = pr.x0[6 + lane];
-      P0[lane] = p; V0[lane] = v; A0[lane] = a;
+    {  // zero-jerk propagation of x0 to the start of segment tt = lane / 3 (same recurrence, step by step, as the oracle)
+      const int tt = lane / 3, i = lane - 3 * tt;
+      const bool on = lane < 3 * NT;
+      double p = on ? pr.x0[i] : 0.0, v = on ? pr.x0[3 + i] : 0.0;
+      const double a = on ? pr.x0[6 + i] : 0.0;
       for (int t = 0; t < N; t++) {
-        p = p + v * h + 0.5 * a * h * h;
-        v = v + a * h;
-        P0[(t + 1) * 3 + lane] = p; V0[(t + 1) * 3 + lane] = v; A0[(t + 1) * 3 + lane] = a;
+        const double pn = p + v * h + 0.5 * a * h * h, vn = v + a * h;
+        p = (t < tt) ? pn : p;
+        v = (t < tt) ? vn : v;
       }
+      p0r = p; v0r = v; a0r = a;
     }
+    FH_SYNC();  // the scratch below aliases z, g, d
     for (int idx = lane; idx < W_KINDS * NT; idx += 64) {
       const int kind = idx / NT, tt = idx % NT;
       double s = 0;
@@ -403,9 +412,18 @@ struct Solver {
         s += c * c;
       }
       const double w = sqrt(s);
-      wni[idx] = w > 0.0 ? 1.0 / w : 0.0;
+      wtab[idx] = w > 0.0 ? 1.0 / w : 0.0;
     }
     FH_SYNC();
+    {  // each lane keeps the inverse norms of the rows it scans
+      const int t = lane / 3;
+      const bool box = lane < n && t >= 1;  // t = 0 box rows are constants
+      wbv = box ? wtab[W_V * NT + t] : 0.0;
+      wba = box ? wtab[W_A * NT + t] : 0.0;
+      const int tc = lane >> 2, k = lane & 3;
+      wcp = (lane < 4 * N) ? wtab[(k == 3 ? W_P : k) * NT + tc + (k == 3 ? 1 : 0)] : 0.0;
+    }
+    FH_SYNC();  // (z, g, d are rewritten in full before they are read again)
   }
 
   // ---- states at segment starts and Bezier control points of the current x (getCP0..3, :833-862) ----
@@ -430,9 +448,9 @@ struct Solver {
         s2 = fma(dm, t1, s2);
       }
       const double h2 = h * h, h3 = h2 * h;
-      const double p = P0[lane] + h3 * (s0 * (1.0 / 6.0) + 0.5 * s1 + 0.5 * s2);
-      const double v = V0[lane] + h2 * (0.5 * s0 + s1);
-      const double a = A0[lane] + h * s0;
+      const double p = p0r + h3 * (s0 * (1.0 / 6.0) + 0.5 * s1 + 0.5 * s2);
+      const double v = v0r + h2 * (0.5 * s0 + s1);
+      const double a = a0r + h * s0;
       Pc[lane] = p; Vc[lane] = v; Ac[lane] = a;
     }
     FH_SYNC();
@@ -463,7 +481,7 @@ struct Solver {
       const int t = lane / 3, i = lane - 3 * t;
       const double xv = x[lane];
       const double V = Vc[lane], A = Ac[lane];
-      const double iV = t >= 1 ? wni[W_V * NT + t] : 0.0, iA = t >= 1 ? wni[W_A * NT + t] : 0.0;  // t = 0 rows are constants
+      const double iV = wbv, iA = wba;  // (zero for the constant t = 0 rows)
       const double val[3] = {xv, V, A};
       const double lim[3] = {jmax, vmax, amax};
       const double inv[3] = {1.0, iV, iA};
@@ -486,7 +504,7 @@ struct Solver {
       const int F = p >= 0 ? face_off[p + 1] - f0 : 0;
       const int cl = live ? lane : 0;
       const double c0 = CP[cl * 3 + 0], c1 = CP[cl * 3 + 1], c2 = CP[cl * 3 + 2];
-      const double wi = wni[(k == 3 ? W_P : k) * NT + t + (k == 3 ? 1 : 0)];
+      const double wi = wcp;
       int bf = -1;
       double bvt = (F > 0) ? 0.0 : INFINITY;  // dead lanes never take
       const int fl = F > 0 ? F - 1 : 0;        // rows beyond the lane's polytope re-read its last row: never a strict improvement
@@ -863,6 +881,13 @@ struct Solver {
 #pragma unroll
       for (int j = 0; j < 3; j++) eqq[j * NT + lane] = Qv[j];
     }
+    // zero-jerk end state of this lane's axis (registers of the lanes (N, i))
+    double endP = 0, endV = 0, endA = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double ep = readlane_f64(p0r, 3 * N + i), ev = readlane_f64(v0r, 3 * N + i), ea = readlane_f64(a0r, 3 * N + i);
+      if (lane == i) { endP = ep; endV = ev; endA = ea; }
+    }
     // per axis: forward substitution R^T y = rhs, consistency of skipped rows
     bool bad = false;
     if (lane < 3) {
@@ -871,7 +896,7 @@ struct Solver {
       for (int j = 0; j < 3; j++) {
         if (j < nrow) {
           const int kind = j + koff;
-          const double base = kind == 0 ? P0[N * 3 + lane] : (kind == 1 ? V0[N * 3 + lane] : A0[N * 3 + lane]);
+          const double base = kind == 0 ? endP : (kind == 1 ? endV : endA);
           double rhs = xfl[kind * 3 + lane] - base;
 #pragma unroll
           for (int jp = 0; jp < 3; jp++)
@@ -1160,22 +1185,22 @@ struct Solver {
         if (bseg < 0) {  // leaf: feasible for the MIQP
           if (cost < best_cost) {
             best_cost = cost;
-            if (lane < n) bestx[lane] = x[lane];
+            if (lane < n) bestx_r = x[lane];
             if (lane < N) bestassign[lane] = fullassign[lane];
             FH_SYNC();
           }
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
           { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED); FH_T1(10); }  // the children inherit this node's factorisation
           if (lane == 0) {
-            int* ord = &stk_order[depth * FH_MAX_POLY];
+            signed char* ord = &stk_order[depth * FH_MAX_POLY];
             const unsigned am = allowed_mask(bseg);
             int cnt = 0;
             for (int p = 0; p < P; p++)
-              if ((am >> p) & 1u) ord[cnt++] = p;
+              if ((am >> p) & 1u) ord[cnt++] = (signed char)p;
             stk_cnt[depth] = cnt;
             for (int a = 1; a < cnt; a++)
               for (int b = a; b > 0 && viol[bseg * FH_MAX_POLY + ord[b]] < viol[bseg * FH_MAX_POLY + ord[b - 1]]; b--) {
-                const int tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp;
+                const signed char tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp;
               }
             stk_seg[depth] = bseg;
             stk_q[depth] = q;
@@ -1328,7 +1353,7 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
 
   if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
     FH_SYNC();
-    if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx[lane] : 0.0;
+    if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
     FH_SYNC();
     sv.compute_states();
   }
@@ -1338,7 +1363,7 @@ __device__ void solve_one(Solver<NSEG>& sv, const fh_problem& pr, const fh_face*
     double v = 0.0;
     if (solved && t < sv.N) {
       const int o = 3 * t + i;
-      v = kind == 0 ? sv.bestx[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
+      v = kind == 0 ? sv.x[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
     }
     res.coeff[t][rem] = v;
   }
