@@ -51,6 +51,21 @@ def measured_traffic():
     return best
 
 
+def measured_valu_insts():
+    """VALU wave-instructions per launch of solve_kernel<10> from the committed SQ_INSTS_VALU pass (profiles/r*_pmc_summary.json)."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+        try:
+            v = json.load(open(f))["fh::solve_kernel<10>"]["SQ_INSTS_VALU"]["mean_per_dispatch"]
+        except Exception:
+            v = None
+        if v:
+            best = float(v)
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +240,7 @@ def main():
                 "launches_timed": int(len(kernel_ms)),
                 "pipelines_in_flight": len(pipes),
                 "aggregate_achieved": (bytes_whole + bytes_safe) * args.steps / elapsed / 1e9,
+                "issue_side": issue_side(measured_valu_insts(), elapsed / args.steps / 2.0) if args.workload == "c4" and N == 10 else None,
                 "note": "latency/FP64-ALU bound by construction (SURVEY.md 8(d)): ~4-7 KB compulsory HBM bytes per pair; launches of "
                         "different pipelines overlap, so per-launch durations include time shared with other launches "
                         "(aggregate_achieved = all algorithmic bytes of the timed region / wall time)",
@@ -238,6 +254,16 @@ def main():
         dist.destroy_process_group()
     for pp in pipes:
         pp.ctx.close()
+
+
+def issue_side(valu_insts, launch_s):
+    """What actually bounds the kernel: wave64 VALU instructions occupy a 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at
+    2.4 GHz.  launch_s = steady-state time per launch (two solve launches per step).  Reported next to the contract's HBM figures."""
+    if not valu_insts:
+        return None
+    busy = valu_insts * 4.0 / (256 * 4 * 2.4e9) / launch_s
+    return {"valu_wave_insts_per_launch": valu_insts, "steady_state_ms_per_launch": 1e3 * launch_s, "valu_pipes_busy_frac": busy,
+            "source": "SQ_INSTS_VALU of the committed PMC pass x 4 cycles / (1024 SIMDs x 2.4 GHz)"}
 
 
 def cpu_baseline(whole, faces, safe, sfaces, target_s):
