@@ -449,3 +449,40 @@ def test_concurrent_factor_search_is_the_sequential_rule(ctx):
         for name in abi.result_dtype.names:
             assert np.array_equal(got[name], seq[name]), (width, name)
     assert np.array_equal(ctx.solve_batch_speculative(pr, fc, 1)["coeff"], seq["coeff"])
+
+
+def test_gpu_decomposition_edge_cases(ctx):
+    """Empty cloud (box + ground plane only), a vertical segment (degenerate horizontal direction, line_segment.h:62-66), a cloud
+    denser than the LDS list (points spill to the HBM workspace) and a batch larger than the resident grid."""
+    from faster_amd import build as fb, frontend
+
+    fb.build_frontend()
+    key = lambda M: M[np.lexsort(np.round(M, 7).T[::-1])]
+
+    def check(cloud, path, **kw):
+        segs = np.hstack([path[:-1], path[1:]])
+        faces, counts = ctx.decompose_batch(cloud, segs, max_faces=96, **kw)
+        ref, _ = frontend.decompose(path, cloud, **kw)
+        for i, (A, b) in enumerate(ref):
+            assert counts[i] == len(b), (i, counts[i], len(b))
+            got = np.column_stack([faces["a"][i, :counts[i]], faces["b"][i, :counts[i]]])
+            np.testing.assert_allclose(key(got), key(np.column_stack([A, b])), atol=1e-9)
+        return counts
+
+    path = np.array([[0.0, 0.0, 1.0], [1.5, 0.5, 1.2], [1.5, 0.5, 2.4], [3.0, 0.0, 2.0]])  # middle leg is vertical
+    c = check(np.zeros((0, 3)), path)
+    assert np.all(c == 7)
+    rng = np.random.default_rng(11)
+    dense = rng.uniform([-2.5, -2.5, 0.0], [5.5, 3.0, 3.5], size=(9000, 3))  # > 1024 points in every local box
+    keep = np.ones(len(dense), bool)
+    for a, b in zip(path[:-1], path[1:]):
+        t = np.clip(((dense - a) @ (b - a)) / ((b - a) @ (b - a)), 0, 1)
+        keep &= np.linalg.norm(dense - (a + t[:, None] * (b - a)), axis=1) > 0.4
+    dense = dense[keep]
+    check(dense, path, drone_radius=0.1)
+    # many segments (more than resident workgroups): every copy of a segment gives the same polytope
+    segs = np.tile(np.hstack([path[:-1], path[1:]]), (1500, 1))
+    faces, counts = ctx.decompose_batch(dense[::8], segs, max_faces=96)
+    for k in range(3):
+        assert np.all(counts[k::3] == counts[k])
+        assert np.array_equal(faces["b"][k::3], np.broadcast_to(faces["b"][k], faces["b"][k::3].shape))
