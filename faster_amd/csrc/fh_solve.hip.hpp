@@ -286,6 +286,7 @@ struct Solver {
   double p0r, v0r, a0r;   // lane = (tt, i) < 3 NT: zero-jerk propagation of x0 to the start of segment tt (per trial)
   double wbv, wba, wcp;   // inverse row norms of this lane's box rows (lane = (t, i)) and corridor rows (lane = (t, k)) (per trial)
   double bestx_r;         // lane < n: incumbent jerks
+  int scan_f0, scan_F;    // lane = (t, k): first row and row count of the polytope segment t is assigned to (0 rows: free) (per node)
   // ---- wave-uniform scalars ----
   int lane, N, n, q, P;
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
@@ -469,6 +470,14 @@ struct Solver {
     FH_SYNC();
   }
 
+  // assign[] only changes between two active-set runs: the scan lanes look their rows up once per run
+  __device__ void bind_assignment() {
+    const bool live = lane < 4 * N;
+    const int p = live ? assign[lane >> 2] : -1;
+    scan_f0 = p >= 0 ? face_off[p] : 0;
+    scan_F = p >= 0 ? face_off[p + 1] - scan_f0 : 0;
+  }
+
   // ---- most violated inactive inequality row; violation relative to the row norm. id<0: none. ----
   // Box rows: lane = variable.  Corridor rows: lane = (segment, control point), sweeping the faces of the
   // segment's polytope (4 lanes share each face read).  Sets const_bad if a jerk-independent row (segment 0,
@@ -499,9 +508,7 @@ struct Solver {
        // All rows of a lane share the weight factor, so the lane maximises the normalised violation and scales once.
       const bool live = lane < 4 * N;
       const int t = live ? (lane >> 2) : 0, k = lane & 3;
-      const int p = live ? assign[t] : -1;
-      const int f0 = p >= 0 ? face_off[p] : 0;
-      const int F = p >= 0 ? face_off[p + 1] - f0 : 0;
+      const int f0 = scan_f0, F = scan_F;  // rows of the polytope this lane's segment is assigned to (bind_assignment)
       const int cl = live ? lane : 0;
       const double c0 = CP[cl * 3 + 0], c1 = CP[cl * 3 + 1], c2 = CP[cl * 3 + 2];
       const double wi = wcp;
@@ -541,7 +548,7 @@ struct Solver {
   }
 
   // ---- normal of row `id` in jerk space: g[v], v = 3 s + i.  returns |g|^2 ----
-  __device__ double build_g(int id, double& gv_out) {
+  __device__ double build_g(int id) {
     const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
     double gv = 0;
     if (lane < n) {
@@ -571,7 +578,6 @@ struct Solver {
     }
     if (lane < NVP) g[lane] = gv;
     FH_SYNC();
-    gv_out = gv;
     return wave_sum(gv * gv);
   }
 
@@ -580,10 +586,13 @@ struct Solver {
   __device__ __forceinline__ double col_dot(const double* __restrict__ M, int col, const double* __restrict__ v, int n8) const {
     double a0 = 0, a1 = 0;
     for (int i0 = 0; i0 < n8; i0 += 8) {
+      double m[8], w[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { m[j] = M[(i0 + j) * S + col]; w[j] = v[i0 + j]; }  // every load issued before the first use
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
-        a0 += M[(i0 + j) * S + col] * v[i0 + j];
-        a1 += M[(i0 + j + 1) * S + col] * v[i0 + j + 1];
+        a0 += m[j] * w[j];
+        a1 += m[j + 1] * w[j + 1];
       }
     }
     return a0 + a1;
@@ -593,10 +602,13 @@ struct Solver {
     double a0 = 0, a1 = 0;
     const double* Mr = M + row * S;
     for (int c0 = 0; c0 < q8; c0 += 8) {
+      double m[8], w[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { m[j] = Mr[c0 + j]; w[j] = v[c0 + j]; }
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
-        a0 += Mr[c0 + j] * v[c0 + j];
-        a1 += Mr[c0 + j + 1] * v[c0 + j + 1];
+        a0 += m[j] * w[j];
+        a1 += m[j + 1] * w[j + 1];
       }
     }
     return a0 + a1;
@@ -652,35 +664,9 @@ struct Solver {
     return halves_sum(a0 + a1);
   }
 
-  // Same sweeps with the vector operand taken from registers (lane k holds v_k) and broadcast with v_readlane instead of
-  // LDS broadcast reads: the LDS pipe is the busiest unit of this kernel, the VALU has headroom.
-  __device__ __forceinline__ double col_dot_reg(const double* __restrict__ M, int col, double vreg, int n8) const {
-    double a0 = 0, a1 = 0;
-    for (int i0 = 0; i0 < n8; i0 += 8) {
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        a0 += M[(i0 + j) * S + col] * readlane_f64(vreg, i0 + j);
-        a1 += M[(i0 + j + 1) * S + col] * readlane_f64(vreg, i0 + j + 1);
-      }
-    }
-    return a0 + a1;
-  }
-  __device__ __forceinline__ double row_dot_reg(const double* __restrict__ M, int row, double vreg, int q8) const {
-    double a0 = 0, a1 = 0;
-    const double* Mr = M + row * S;
-    for (int c0 = 0; c0 < q8; c0 += 8) {
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        a0 += Mr[c0 + j] * readlane_f64(vreg, c0 + j);
-        a1 += Mr[c0 + j + 1] * readlane_f64(vreg, c0 + j + 1);
-      }
-    }
-    return a0 + a1;
-  }
-
   // ---- z = (I - Q1 Q1^T) g, d = Q1^T g (lane c holds d_c, lane i holds z_i). Re-orthogonalises when the first
   // pass cancels more than half of |g|^2 (Daniel-Gragg-Kaufman-Stewart).  returns |z|^2 ----
-  __device__ double project(double gg, double gv, double& dc, double& zi) {
+  __device__ double project(double gg, double& dc, double& zi) {
     const int n8 = (n + 7) & ~7, q8 = (q + 7) & ~7;
     if constexpr (NVP <= 32) {
       const int l5 = lane & 31;
@@ -705,20 +691,13 @@ struct Solver {
       return zz;
     }
     const int ll = lane < NVP ? lane : NVP - 1;  // lanes beyond the padded size compute a harmless duplicate
-#ifndef FH_READLANE_BROADCAST
     dc = row_dot(Q, ll, g, n8);
     if (lane < NVP) d[lane] = dc;
     FH_SYNC();
     zi = g[ll] - col_dot(Q, ll, d, q8);
-#else
-    dc = row_dot_reg(Q, ll, gv, n8);      // gv: lane i holds g_i (0 beyond n)
-    if (lane >= q) dc = 0.0;              // columns beyond q are zero anyway; keep the register vector clean
-    zi = gv - col_dot_reg(Q, ll, dc, q8);
-#endif
     if (lane >= NVP) zi = 0.0;
     double zz = wave_sum(zi * zi);
     if (zz < FH_REORTH_THRESHOLD * gg) {
-#ifndef FH_READLANE_BROADCAST
       if (lane < NVP) z[lane] = zi;
       FH_SYNC();
       const double ec = row_dot(Q, ll, z, n8);
@@ -726,12 +705,6 @@ struct Solver {
       if (lane < NVP) r[lane] = ec;
       FH_SYNC();
       zi -= col_dot(Q, ll, r, q8);
-#else
-      double ec = row_dot_reg(Q, ll, zi, n8);
-      if (lane >= q) ec = 0.0;
-      dc += ec;
-      zi -= col_dot_reg(Q, ll, ec, q8);
-#endif
       if (lane >= NVP) zi = 0.0;
       zz = wave_sum(zi * zi);
     }
@@ -956,15 +929,13 @@ struct Solver {
   // returns 0 optimal, 1 infeasible, 2 bounded out by `ub`, 3 iteration limit ----
   __device__ int qp_run(double ub, int max_iters, int& iters, double& cost) {
     int it = 0;
+    bind_assignment();
     const int st = qp_loop(ub, max_iters, it, cost);
     iters += it;
     return st;
   }
   __device__ int qp_loop(double ub, int max_iters, int& it, double& cost) {
     for (;;) {
-#ifdef FH_OPAQUE_LANE  // (measured: 184 instead of 226 VGPRs, 3 % slower)
-      lane = opaque(lane);  // lane-derived indices and masks are recomputed per iteration instead of being kept (and spilled) across the solve
-#endif
       { FH_T0(); compute_states(); FH_T1(2); }
       int id;
       double vp;
@@ -985,13 +956,13 @@ struct Solver {
           return 0;
         }
       }
-      double gg, gv;
-      { FH_T0(); gg = build_g(id, gv); FH_T1(4); }
+      double gg;
+      { FH_T0(); gg = build_g(id); FH_T1(4); }
       double up = 0;
       for (;;) {  // until row `id` is active
         if (++it > max_iters) return 3;
         double dc, zi, zz, rc;
-        { FH_T0(); zz = project(gg, gv, dc, zi); FH_T1(5); }
+        { FH_T0(); zz = project(gg, dc, zi); FH_T1(5); }
         FH_T0();
         rc = backsolve(dc);
         const bool dependent = zz <= dep2 * gg;
