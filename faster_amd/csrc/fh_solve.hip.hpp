@@ -289,6 +289,7 @@ struct Solver {
   int scan_f0, scan_F;    // lane = (t, k): first row and row count of the polytope segment t is assigned to (0 rows: free) (per node)
   // ---- wave-uniform scalars ----
   int lane, N, n, q, P;
+  int qe;  // number of equality rows: always the first columns of the factorisation
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
   unsigned poly_ok;  // polytopes without a violated zero-normal face (such a polytope can never hold a segment)
 #ifdef FH_PROFILE
@@ -715,12 +716,14 @@ struct Solver {
   // Row-scaled recurrence: lane l carries (d_l - sum_{j>l} R_lj r_j) / R_ll, which is final (= r_l) once column l has been
   // consumed, so that the serial chain per column is one broadcast and one FMA; the scaled, masked coefficients
   // R_lc / R_ll do not depend on the recurrence and are prepared four columns ahead.
+  // The equality rows are always the first qe columns and their multipliers are never read (free sign, never dropped), so the
+  // recurrence stops at the first inequality column: lanes below qe return 0.
   __device__ double backsolve(double dc) {
     const int ll = lane < NVP ? lane : NVP - 1;
-    const double ri = (lane < q) ? rinv[lane] : 0.0;
+    const double ri = (lane < q && lane >= qe) ? rinv[lane] : 0.0;
     double dh = dc * ri;
     int c = q - 1;
-    for (; c >= 3; c -= 4) {
+    for (; c >= qe + 4; c -= 4) {
       double m[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) m[j] = R[rp(min(ll, c - j), c - j)];
@@ -729,7 +732,7 @@ struct Solver {
 #pragma unroll
       for (int j = 0; j < 4; j++) dh = fma(-m[j], readlane_f64(dh, c - j), dh);
     }
-    for (; c >= 1; c--) {
+    for (; c >= qe + 1; c--) {
       const double m0 = (lane < c) ? R[rp(min(ll, c), c)] * ri : 0.0;
       dh = fma(-m0, readlane_f64(dh, c), dh);
     }
@@ -921,6 +924,7 @@ struct Solver {
       u[lane] = 0.0;
     }
     q = 3 * cnt;
+    qe = q;
     FH_SYNC();
     return true;
   }
@@ -968,7 +972,7 @@ struct Solver {
         const bool dependent = zz <= dep2 * gg;
         double ratio = INFINITY;
         if (lane < q && (act[lane] >> 24) != K_EQ && rc > 0) ratio = u[lane] / rc;
-        const double t1 = wave_min(ratio);
+        const double t1 = wave_any(ratio < INFINITY) ? wave_min(ratio) : INFINITY;  // (no blocking row in most iterations)
         const int kb = (t1 < INFINITY) ? first_lane(ratio == t1) : -1;
         if (kb < 0 && dependent) return 1;
         const double t2 = dependent ? INFINITY : vp / zz;
@@ -1374,6 +1378,7 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
   sv.carve(smem, max_faces);
   sv.lane = threadIdx.x;
   sv.q = 0;
+  sv.qe = 0;
   double* ws = workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   for (;;) {
     // tickets only ever grow: this launch owns [ticket_base, ticket_base + n_problems); every workgroup draws exactly one
