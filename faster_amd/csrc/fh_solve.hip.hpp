@@ -143,6 +143,15 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += dpp0_f64<0x143>(v);
   return readlane_f64(v, 63);
 }
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xf, 0xf, true);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xf, 0xf, true);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 // max(0, max over the lanes): every caller only asks whether the maximum is positive and where it sits
 __device__ __forceinline__ double wave_max_nonneg(double v) {
   v = vmax_f64(v, dpp0_f64<0x111>(v));
@@ -1009,13 +1018,9 @@ struct Solver {
   __device__ void screen_constant_rows(const fh_problem& pr) {
     allowed_first = allowed_last = 0xffffffffu;
     if (P == 0) return;
-    bool ok0 = false, okN = false;
-    {  // one lane per polytope, wave-uniform trip count (lanes beyond P and rows beyond a polytope re-read a valid row)
-      const bool live = lane < P;
-      const int f0 = live ? face_off[lane] : 0, F = live ? face_off[lane + 1] - f0 : 0;
-      const int fl = F > 0 ? F - 1 : 0;
-      const fh_face* fp = faces + f0;
-      double c0[9], cN[9];
+    // one lane per face row (all polytopes side by side), six wave-uniform points per row; a violated row marks its polytope
+    double c0[9], cN[9];
+    {
       const double h3 = h / 3.0, h23 = 2.0 * h / 3.0, h26 = h * h / 6.0;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
@@ -1024,25 +1029,26 @@ struct Solver {
         c0[i] = p0; c0[3 + i] = p0 + v0 * h3; c0[6 + i] = p0 + v0 * h23 + a0 * h26;
         cN[i] = pf; cN[3 + i] = pf - vf * h3; cN[6 + i] = pf - vf * h23 + af * h26;
       }
-      double w0 = -INFINITY, wN = -INFINITY;
-      for (int fb = 0; fb < maxF; fb += 2) {
-        fh_face fc[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) fc[j] = fp[min(fb + j, fl)];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            w0 = vmax_f64(w0, fma(fc[j].a[0], c0[3 * k], fma(fc[j].a[1], c0[3 * k + 1], fma(fc[j].a[2], c0[3 * k + 2], fc[j].b))));
-            wN = vmax_f64(wN, fma(fc[j].a[0], cN[3 * k], fma(fc[j].a[1], cN[3 * k + 1], fma(fc[j].a[2], cN[3 * k + 2], fc[j].b))));
-          }
-        }
-      }
-      ok0 = live && F > 0 ? !(w0 > 0.0) : live;
-      okN = live && F > 0 ? !(wN > 0.0) : live;
     }
-    allowed_first = (unsigned)__ballot(ok0);
-    if (force_final) allowed_last = (unsigned)__ballot(okN);
+    const int nf = face_off[P];
+    unsigned bad = 0u;  // bits 0..7: polytope excluded for segment 0, bits 8..15: for the last segment
+    for (int fb = 0; fb < nf; fb += 64) {
+      const int f = fb + lane;
+      const bool valid = f < nf;
+      const fh_face fc = faces[valid ? f : 0];
+      double w0 = -INFINITY, wN = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        w0 = vmax_f64(w0, fma(fc.a[0], c0[3 * k], fma(fc.a[1], c0[3 * k + 1], fma(fc.a[2], c0[3 * k + 2], fc.b))));
+        wN = vmax_f64(wN, fma(fc.a[0], cN[3 * k], fma(fc.a[1], cN[3 * k + 1], fma(fc.a[2], cN[3 * k + 2], fc.b))));
+      }
+      int pf = 0;
+      for (int j = 1; j < P; j++) pf += (f >= face_off[j]) ? 1 : 0;
+      if (valid) bad |= ((w0 > 0.0) ? (1u << pf) : 0u) | ((wN > 0.0) ? (256u << pf) : 0u);
+    }
+    bad = wave_or(bad);
+    allowed_first = ~(bad & 255u);
+    if (force_final) allowed_last = ~((bad >> 8) & 255u);
   }
 
   // ---- leaf test / branching choice for the node just solved. returns branch segment or -1 (leaf) ----
