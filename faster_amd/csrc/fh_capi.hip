@@ -42,6 +42,20 @@ struct fh_ctx {
     }                                                                                           \
   } while (0)
 
+// Makes the context's device current for the duration of an entry point (a process may drive several GPUs from one thread)
+// and restores the caller's device on exit.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(const fh_ctx* ctx) {
+    if (ctx && ctx->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != ctx->device)
+      switched = hipSetDevice(ctx->device) == hipSuccess;
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
 static int ensure(fh_ctx* ctx, int slot, size_t bytes) {
   if (bytes <= ctx->d_cap[slot]) return FH_OK;
   if (ctx->d_buf[slot]) FH_HIP(hipFree(ctx->d_buf[slot]));
@@ -169,6 +183,7 @@ int fh_set_stream(fh_ctx* ctx, void* hip_stream) {
 int fh_sync(fh_ctx* ctx) {
   if (!ctx) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   FH_HIP(hipStreamSynchronize(ctx->stream));
   return FH_OK;
 }
@@ -177,6 +192,7 @@ int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_fa
                           int max_faces, fh_result* d_results) {
   if (!ctx || n < 0) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!d_problems || !d_results) return FH_ERR_ARG;
   if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
@@ -191,6 +207,7 @@ int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces
                    fh_result* results) {
   if (!ctx || n < 0 || n_faces < 0) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!problems || !results || (n_faces > 0 && !faces)) return FH_ERR_ARG;
   int max_seg = 1, max_faces = 8;
@@ -229,6 +246,7 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
   if (!ctx || n < 0 || n_faces < 0) return FH_ERR_ARG;
   if (width <= 1 || ctx->par.max_work > 0) return fh_solve_batch(ctx, problems, faces, n_faces, n, results);
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!problems || !results || (n_faces > 0 && !faces)) return FH_ERR_ARG;
   // the factors of every problem, accumulated exactly as the reference loop does (repeated += in double)
@@ -304,6 +322,7 @@ int fh_sample_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_r
                            fh_state* d_states, int32_t* d_counts) {
   if (!ctx || n < 0 || max_samples < 0) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!d_problems || !d_results || !d_counts || (max_samples > 0 && !d_states)) return FH_ERR_ARG;
   hipLaunchKernelGGL(fh::sample_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_problems, d_results, n, max_samples,
@@ -316,6 +335,7 @@ int fh_sample_batch(fh_ctx* ctx, const fh_problem* problems, const fh_result* re
                     fh_state* states, int32_t* counts) {
   if (!ctx || n < 0 || max_samples < 0) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!problems || !results || !counts || (max_samples > 0 && !states)) return FH_ERR_ARG;
   int rc;
@@ -340,6 +360,7 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
                         int n, double r_frac, double shrink, int max_safe_poly, fh_problem* d_safe, fh_face* d_safe_faces) {
   if (!ctx || n < 0) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
@@ -358,6 +379,7 @@ int fh_timing_reset(fh_ctx* ctx) {
 int fh_timing_read(fh_ctx* ctx, double* ms, int cap) {
   if (!ctx || cap < 0 || (cap > 0 && !ms)) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   const int count = (int)(ctx->ev_used / 2);
   if (count == 0) return 0;
   FH_HIP(hipEventSynchronize(ctx->ev[ctx->ev_used - 1]));
@@ -374,6 +396,7 @@ int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_clou
                               int32_t* d_counts) {
   if (!ctx || n_cloud < 0 || n_segments < 0 || max_faces < 8 || !local_bbox) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n_segments == 0) return FH_OK;
   if (!d_segments || !d_faces || !d_counts || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
   if (!(local_bbox[0] > 0) || !(local_bbox[1] > 0) || !(local_bbox[2] > 0) || !(drone_radius >= 0)) return FH_ERR_ARG;
@@ -391,6 +414,7 @@ int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const 
                        const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* faces, int32_t* counts) {
   if (!ctx || n_cloud < 0 || n_segments < 0 || max_faces < 8) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
   if (n_segments == 0) return FH_OK;
   if (!segments || !faces || !counts || (n_cloud > 0 && !cloud_xyz)) return FH_ERR_ARG;
   int rc;
