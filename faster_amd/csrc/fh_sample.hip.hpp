@@ -76,9 +76,10 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
     }
     __syncthreads();
     // contiguous burst: lim*12 doubles, two per lane per store
-    double2* dst = reinterpret_cast<double2*>(out + base);
-    const double2* src = reinterpret_cast<const double2*>(tile);
-    for (int i = lane; i < lim * 6; i += 64) dst[i] = src[i];
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    vec2* dst = reinterpret_cast<vec2*>(out + base);
+    const vec2* src = reinterpret_cast<const vec2*>(tile);
+    for (int i = lane; i < lim * 6; i += 64) __builtin_nontemporal_store(src[i], &dst[i]);  // streamed once, never re-read here
     __syncthreads();
   }
 }
