@@ -80,12 +80,12 @@ def main():
                          "voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes (BASELINE config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     args = ap.parse_args()
 
     # more hardware queues than the HIP default (4) so that the in-flight pipelines really run concurrently
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,6 +166,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(len(pipes)):  # every pipeline allocates its workspace on first use: prime them all, then the W warmup steps
+        step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
