@@ -101,7 +101,13 @@ int main(int argc, char** argv) {
   sg_whole_.setFactorInitialAndFinalAndIncrement(new_init_whole, new_final_whole, inc_whole);
   bool again = sg_whole_.genNewTraj();
   std::printf("\"window\": [%.17g, %.17g],\n", new_init_whole, new_final_whole);
-  dump("whole_again", sg_whole_, again, true);
+  dump("whole_again", sg_whole_, again, false);
+  // extension: the same line search, three factors at a time (fh_solve_batch_speculative) — identical outputs expected
+  sg_whole_.setFactorInitialAndFinalAndIncrement(1, 10, inc_whole);
+  sg_whole_.setConcurrentFactors(3);
+  bool conc = sg_whole_.genNewTraj();
+  if (conc) sg_whole_.fillX();
+  dump("whole_concurrent", sg_whole_, conc, true);
   std::printf("}\n");
   return 0;
 }

@@ -113,3 +113,7 @@ def test_host_class_matches_oracle(tmp_path, oracle, fixture_corridor):
     # window update (faster.cpp:582-588): [max(3-20,1), 3+20] => same first feasible factor
     assert out["window"] == [1.0, 23.0]
     assert out["whole_again"]["solved"] == 1 and out["whole_again"]["factor"] == 3.0
+    # concurrent factor search (SolverHip::setConcurrentFactors): bit-identical to the sequential whole solve
+    c = out["whole_concurrent"]
+    for k in ("solved", "trials", "factor", "dt", "cost", "n", "first", "last"):
+        assert c[k] == w[k], k
