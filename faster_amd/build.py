@@ -10,8 +10,9 @@ SOURCES = [os.path.join(HERE, "csrc", "fh_capi.hip")]
 DEPS = SOURCES + [os.path.join(HERE, "csrc", "fh_solve.hip.hpp"), os.path.join(HERE, "csrc", "fh_sample.hip.hpp"),
                   os.path.join(ROOT, "include", "fasterhip.h")]
 HOST_SO = os.path.join(HERE, "libsolverhip.so")
-HOST_SOURCES = [os.path.join(HERE, "host", "solver_hip.cpp")]
+HOST_SOURCES = [os.path.join(HERE, "host", "solver_hip.cpp"), os.path.join(HERE, "host", "decomp_hip.cpp")]
 HOST_DEPS = HOST_SOURCES + [os.path.join(HERE, "host", "solver_hip.hpp"), os.path.join(HERE, "host", "faster_stub.hpp"),
+                            os.path.join(HERE, "host", "decomp_hip.hpp"), os.path.join(HERE, "host", "corridor_frontend.hpp"),
                             os.path.join(ROOT, "include", "fasterhip.h")]
 
 

@@ -208,8 +208,18 @@ struct ReplanLog {
   size_t n_whole = 0, n_safe = 0;
 };
 
+// the decomposition policy of Planner when none is given: DecompUtil's algorithm on the host (corridor_frontend.hpp);
+// DecompHip (decomp_hip.hpp) is the same step on the device
+struct HostDecomposition {
+  std::vector<fhfront::LinearConstraint> operator()(const std::vector<V3>& path, const std::vector<V3>& cloud, double drone_radius,
+                                                    double z_ground) const {
+    return fhfront::decompose_path(path, cloud, drone_radius, z_ground);
+  }
+};
+
 // Solver: any type with the SolverGurobi surface (SolverHip in the product; an oracle-backed adapter in the CPU tests).
-template <class Solver>
+// Decomposition: callable (path, cloud, drone_radius, z_ground) -> polytopes, the role of JPS_Manager::cvxEllipsoidDecomp.
+template <class Solver, class Decomposition = HostDecomposition>
 class Planner {
 public:
   explicit Planner(const Params& p) : par_(p) {
@@ -281,7 +291,8 @@ public:
     std::vector<V3> JPS_whole = JPS_in;
     keep_first(JPS_whole, par_.max_poly_whole);
     Epos = JPS_whole.back();
-    l_constraints_whole_ = to_solver_constraints(fhfront::decompose_path(JPS_whole, occupied_.pts, par_.drone_radius, par_.z_ground));
+    l_constraints_whole_ = to_solver_constraints(decompose_(JPS_whole, occupied_.pts, par_.drone_radius, par_.z_ground));
+    if (l_constraints_whole_.empty()) { L.stage = 2; return false; }  // (a device decomposition that failed reports an empty corridor)
     if (l_constraints_whole_.back().inside(fhstub::Vec3(G.x, G.y, G.z))) Epos = G;
     state E;
     E.setPos(Epos.x, Epos.y, Epos.z);
@@ -313,7 +324,7 @@ public:
       std::vector<V3> JPS_safe = tmp;
       keep_first(JPS_safe, par_.max_poly_safe);
       Mpos = JPS_safe.back();
-      l_constraints_safe_ = to_solver_constraints(fhfront::decompose_path(JPS_safe, unknown_and_occupied_, par_.drone_radius, par_.z_ground));
+      l_constraints_safe_ = to_solver_constraints(decompose_(JPS_safe, unknown_and_occupied_, par_.drone_radius, par_.z_ground));
       if (l_constraints_safe_.back().inside(fhstub::Vec3(G.x, G.y, G.z))) Mpos = G;
       state M;
       M.setPos(Mpos.x, Mpos.y, Mpos.z);
@@ -380,6 +391,7 @@ private:
   bool state_set_ = false, goal_set_ = false, map_set_ = false;
   Status status_ = Status::TRAVELING;
   std::deque<state> plan_;
+  Decomposition decompose_;
   Cloud occupied_, unknown_;
   std::vector<V3> unknown_and_occupied_;
   std::vector<LinearConstraint3D> l_constraints_whole_, l_constraints_safe_;

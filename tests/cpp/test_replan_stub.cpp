@@ -10,11 +10,12 @@
 #ifdef WITH_ORACLE
 #include "oracle_solver.hpp"
 #endif
+#include "decomp_hip.hpp"
 #include "solver_hip.hpp"
 
 using fhfront::V3;
 
-template <class Solver>
+template <class Solver, class Decomposition>
 int run(unsigned seed) {
   std::mt19937 rng(seed);
   std::uniform_real_distribution<double> U(0.0, 1.0);
@@ -37,7 +38,7 @@ int run(unsigned seed) {
 
   fhreplan::Params par;
   par.wdx = par.wdy = 24; par.wdz = 3; par.res = 0.2; par.z_max = H; par.Ra = 4.0; par.drone_radius = 0.2; par.v_max = 1.5; par.a_max = 3.0; par.j_max = 10.0;  // slow enough to brake inside the 3 m sensing radius par.inflation_jps = 0.3;  // drone_radius >= half the lattice diagonal: unknown space is never missed
-  fhreplan::Planner<Solver> planner(par);
+  fhreplan::Planner<Solver, Decomposition> planner(par);
   state s0, goal;
   s0.setPos(0.8, 0.8, 1.0);
   goal.setPos(W - 1.0, W - 0.8, 1.2);
@@ -89,8 +90,9 @@ int main(int argc, char** argv) {
 #ifdef WITH_ORACLE
   if (!std::strcmp(mode, "oracle")) {
     OracleSolver::lib_path() = argc > 2 ? argv[2] : "oracle/liboracle.so";
-    return run<OracleSolver>(seed);
+    return run<OracleSolver, fhreplan::HostDecomposition>(seed);
   }
 #endif
-  return run<SolverHip>(seed);
+  if (!std::strcmp(mode, "gpu-decomp")) return run<SolverHip, DecompHip>(seed);  // corridor decomposition on the device too
+  return run<SolverHip, fhreplan::HostDecomposition>(seed);
 }

@@ -19,7 +19,7 @@ def build():
     orc.build()
     src = os.path.join(ROOT, "tests", "cpp", "test_replan_stub.cpp")
     deps = [src, os.path.join(ROOT, "tests", "cpp", "oracle_solver.hpp"), fb.HOST_SO] + [os.path.join(ROOT, "faster_amd", "host", f) for f in
-                                                                                         ("replan_stub.hpp", "corridor_frontend.hpp", "corridor_frontend.cpp", "solver_hip.hpp")]
+                                                                                         ("replan_stub.hpp", "corridor_frontend.hpp", "corridor_frontend.cpp", "solver_hip.hpp", "decomp_hip.hpp")]
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-DWITH_ORACLE", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "faster_amd", "host"),
                                src, os.path.join(ROOT, "faster_amd", "host", "corridor_frontend.cpp"), "-o", EXE, "-L", os.path.join(ROOT, "faster_amd"),
@@ -53,5 +53,14 @@ def test_closed_loop_with_oracle_backed_solver(seed):
 def test_closed_loop_on_gpu():
     exe = build()
     r = subprocess.run([exe, "gpu", "-", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    check(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+
+
+@pytest.mark.gpu
+def test_closed_loop_on_gpu_with_device_decomposition():
+    """Same closed loop with the corridor decomposition on the device as well (DecompHip = fh_decompose_batch)."""
+    exe = build()
+    r = subprocess.run([exe, "gpu-decomp", "-", "1"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     check(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
