@@ -29,7 +29,13 @@
 
 namespace fh {
 
+// A workgroup is ONE wavefront (launch bounds 64): its LDS operations are issued and performed in program order, so what a
+// multi-wave kernel would need a barrier for only needs the compiler not to reorder the accesses.
+#ifdef FH_SYNC_BARRIER
 #define FH_SYNC() __syncthreads()
+#else
+#define FH_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#endif
 // -DFH_PROFILE: per-phase cycle counters (s_memtime) accumulated per problem and written into the unused last
 // coefficient row of the result (diagnostic builds only; scripts/phase_profile.py).
 #ifdef FH_PROFILE
@@ -379,7 +385,9 @@ struct Solver {
   }
   // q_saved: number of active rows in the snapshot; the current q may be larger (columns to clear) or smaller
   __device__ void snapshot_restore(const double* __restrict__ ws_level, int q_saved) {
-    FH_SYNC();
+    // the workspace was written by this same wavefront (snapshot_save of an ancestor node): drain its outstanding stores
+    // before reading them back
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (lane < NVP)
       for (int c = q_saved; c < q; c++) Q[c * S + lane] = 0.0;  // keep the zero padding beyond the active columns
     FH_SYNC();
