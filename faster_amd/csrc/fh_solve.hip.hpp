@@ -301,6 +301,7 @@ struct Solver {
   double p0r, v0r, a0r;   // lane = (tt, i) < 3 NT: zero-jerk propagation of x0 to the start of segment tt (per trial)
   double wbv, wba, wcp;   // inverse row norms of this lane's box rows (lane = (t, i)) and corridor rows (lane = (t, k)) (per trial)
   double bestx_r;         // lane < n: incumbent jerks
+  double cp_r[3];         // lane = (t, k): control point k of segment t at the current x (compute_states -> scan)
   int scan_f0, scan_F;    // lane = (t, k): first row and row count of the polytope segment t is assigned to (0 rows: free) (per node)
   // ---- wave-uniform scalars ----
   int lane, N, n, q, P;
@@ -483,7 +484,10 @@ struct Solver {
       for (int i = 0; i < 3; i++) { st[i] = Pc[o + i]; st[3 + i] = Vc[o + i]; st[6 + i] = Ac[o + i]; }
       in_flight(st);
 #pragma unroll
-      for (int i = 0; i < 3; i++) CP[lane * 3 + i] = st[i] + wv * st[3 + i] + wa * st[6 + i];
+      for (int i = 0; i < 3; i++) {
+        cp_r[i] = st[i] + wv * st[3 + i] + wa * st[6 + i];
+        CP[lane * 3 + i] = cp_r[i];  // for the leaf analysis; the row scan of this iteration uses the registers
+      }
     }
     FH_SYNC();
   }
@@ -527,8 +531,7 @@ struct Solver {
       const bool live = lane < 4 * N;
       const int t = live ? (lane >> 2) : 0, k = lane & 3;
       const int f0 = scan_f0, F = scan_F;  // rows of the polytope this lane's segment is assigned to (bind_assignment)
-      const int cl = live ? lane : 0;
-      const double c0 = CP[cl * 3 + 0], c1 = CP[cl * 3 + 1], c2 = CP[cl * 3 + 2];
+      const double c0 = cp_r[0], c1 = cp_r[1], c2 = cp_r[2];  // this lane's control point (compute_states)
       const double wi = wcp;
       int bf = -1;
       double bvt = (F > 0) ? 0.0 : INFINITY;  // dead lanes never take
