@@ -249,7 +249,7 @@ def main():
                         "(aggregate_achieved = all algorithmic bytes of the timed region / wall time)",
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is a property of the host: reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(whole, faces, safe_h, sfaces_h, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
