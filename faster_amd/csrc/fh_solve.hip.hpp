@@ -6,14 +6,16 @@
 // MIQP solve that Gurobi performs inside m.optimize() (:566).
 //
 // Mapping to the machine
-//   * one problem (= one genNewTraj call) per 64-lane wavefront, one wavefront per workgroup; the grid is the
-//     batch, so the hardware dispatcher load-balances problems of different difficulty across the 256 CUs;
+//   * one problem (= one genNewTraj call) per 64-lane wavefront, one wavefront per workgroup; the grid is what is
+//     resident at once (8 workgroups per CU: LDS and VGPR limited) and every workgroup pulls problems from a
+//     device-scope ticket counter, so problems of different difficulty balance across the 256 CUs;
 //   * control flow is wave-uniform: the whole search (factor loop -> branch and bound -> dual active set) is a
 //     scalar program; the 64 lanes are the data-parallel axis inside every step (rows of the constraint scan,
 //     rows/columns of the QR factors, (segment, polytope) pairs of the leaf test);
 //   * everything a solve touches lives in LDS (thin QR of the active normals, states, control points, the
 //     polytope faces staged once per problem with coalesced 32-B face loads); HBM traffic is the compulsory
-//     problem read and result write only;
+//     problem read and result write plus the branch-and-bound node snapshots (live prefix only, L2 resident);
+//   * a workgroup being one wavefront, LDS traffic is ordered by program order: no barriers, only compiler fences;
 //   * the constraint matrix is never formed: rows are (face normal) x (Toeplitz weight of the triple integrator)
 //     and are evaluated from the control points (3 FMAs per row).
 //
