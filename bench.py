@@ -80,6 +80,9 @@ def main():
                          "voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes (BASELINE config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pipeline", choices=["fused", "split"], default="split",
+                    help="split: whole launch -> hand-off launch -> safe launch; fused: one launch, each wavefront takes a pair through "
+                         "whole solve, hand-off and safe solve (same results)")
     ap.add_argument("--inflight", type=int, default=8,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     args = ap.parse_args()
@@ -152,10 +155,14 @@ def main():
         pp = pipes[step_no[0] % len(pipes)]
         step_no[0] += 1
         c = pp.ctx
-        c.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, pp.d_wres.data_ptr())
-        c.pair_glue_device(d_whole.data_ptr(), pp.d_wres.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, pp.d_safe.data_ptr(),
-                           pp.d_sfaces.data_ptr())
-        c.solve_batch_device(pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), B, N, max_faces, pp.d_sres.data_ptr())
+        if args.pipeline == "fused":
+            c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, 0.5, 0.2, 3, pp.d_wres.data_ptr(),
+                                 pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), pp.d_sres.data_ptr())
+        else:
+            c.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, pp.d_wres.data_ptr())
+            c.pair_glue_device(d_whole.data_ptr(), pp.d_wres.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, pp.d_safe.data_ptr(),
+                               pp.d_sfaces.data_ptr())
+            c.solve_batch_device(pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), B, N, max_faces, pp.d_sres.data_ptr())
         if world > 1:  # batch gather of the per-pair summaries (whole cost, safe cost) over RCCL/xGMI
             with torch.cuda.stream(pp.stream):
                 shard.gather_step_summaries(dist, pp.d_wres, pp.d_sres, B, pp.gather.view(world * B, 2))

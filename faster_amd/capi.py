@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
-    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device",
+    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
@@ -59,6 +59,8 @@ def lib():
         L.fh_sample_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp]
         L.fh_pair_glue_device.restype = i32
         L.fh_pair_glue_device.argtypes = [vp, vp, vp, vp, i32, f64, f64, i32, vp, vp]
+        L.fh_solve_pairs_device.restype = i32
+        L.fh_solve_pairs_device.argtypes = [vp, vp, vp, i32, i32, i32, f64, f64, i32, vp, vp, vp, vp]
         L.fh_decompose_batch.restype = i32
         L.fh_decompose_batch.argtypes = [vp, vp, i32, vp, i32, vp, f64, f64, i32, vp, vp]
         L.fh_decompose_batch_device.restype = i32
@@ -180,6 +182,11 @@ class Context:
     def sample_batch_device(self, d_problems, d_results, n, max_samples, d_states, d_counts):
         self._check(lib().fh_sample_batch_device(self._h, d_problems, d_results, n, max_samples, d_states, d_counts),
                     "fh_sample_batch_device")
+
+    def solve_pairs_device(self, d_whole, d_faces, n, max_seg, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe,
+                           d_safe_faces, d_safe_results):
+        self._check(lib().fh_solve_pairs_device(self._h, d_whole, d_faces, n, max_seg, max_faces, r_frac, shrink, max_safe_poly,
+                                                d_whole_results, d_safe, d_safe_faces, d_safe_results), "fh_solve_pairs_device")
 
     def pair_glue_device(self, d_whole, d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces):
         self._check(lib().fh_pair_glue_device(self._h, d_whole, d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly,

@@ -106,6 +106,43 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   return FH_OK;
 }
 
+template <int NSEG>
+static int launch_pairs(fh_ctx* ctx, const fh_problem* d_whole, const fh_face* d_faces, int n, int max_faces, double r_frac,
+                        double shrink, int max_safe_poly, fh_result* d_wres, fh_problem* d_safe, fh_face* d_sfaces, fh_result* d_sres) {
+  const size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
+  auto kern = fh::solve_pairs_kernel<NSEG>;
+  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+  if (per_cu < 1) per_cu = 1;
+  const int grid = std::min(n, ctx->n_cu * per_cu);
+  int rc;
+  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_PADDED)) != FH_OK) return rc;
+  if (!ctx->d_buf[6]) {
+    if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
+    FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 256, ctx->stream));
+    ctx->ticket_base = 0;
+  }
+  FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (ctx->ev_used + 2 > ctx->ev.size()) {
+    if (ctx->ev.size() >= 8192) ctx->ev_used = 0;
+    else
+      for (int k = 0; k < 2; k++) {
+        hipEvent_t e;
+        FH_HIP(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+      }
+  }
+  hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
+  FH_HIP(hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_whole, d_faces, n, max_faces, ctx->par,
+                     (double*)ctx->d_buf[5], (unsigned long long*)ctx->d_buf[6], ctx->ticket_base, r_frac, shrink, max_safe_poly,
+                     d_wres, d_safe, d_sfaces, d_sres);
+  ctx->ticket_base += (unsigned long long)n + (unsigned long long)grid;
+  FH_HIP(hipGetLastError());
+  FH_HIP(hipEventRecord(e1, ctx->stream));
+  ctx->ev_used += 2;
+  return FH_OK;
+}
+
 extern "C" {
 
 const char* fh_version(void) { return "fasterhip 0.1 gfx950"; }
@@ -368,6 +405,28 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
                      d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces);
   FH_HIP(hipGetLastError());
   return FH_OK;
+}
+
+int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face* d_faces, int n, int max_seg, int max_faces,
+                          double r_frac, double shrink, int max_safe_poly, fh_result* d_whole_results, fh_problem* d_safe,
+                          fh_face* d_safe_faces, fh_result* d_safe_results) {
+  if (!ctx || n < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_whole || !d_whole_results || !d_safe || !d_safe_results) return FH_ERR_ARG;
+  if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
+  if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
+  if (max_faces <= 0 || max_faces > FH_MAX_FACES) max_faces = FH_MAX_FACES;
+  max_faces = (max_faces + 7) & ~7;
+  if (max_seg <= 6)
+    return launch_pairs<6>(ctx, d_whole, d_faces, n, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe, d_safe_faces,
+                           d_safe_results);
+  if (max_seg <= 10)
+    return launch_pairs<10>(ctx, d_whole, d_faces, n, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe, d_safe_faces,
+                            d_safe_results);
+  return launch_pairs<FH_MAX_SEG>(ctx, d_whole, d_faces, n, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe,
+                                  d_safe_faces, d_safe_results);
 }
 
 int fh_timing_reset(fh_ctx* ctx) {

@@ -86,15 +86,8 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
 
 // One wavefront per pair: the scalar sample clock runs once (wave-uniform), the polytope tests and the face copy are
 // lane-parallel over faces with coalesced 32-B rows.
-__global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
-                                                       const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink,
-                                                       int max_safe_poly, fh_problem* __restrict__ safe, fh_face* __restrict__ sfaces) {
-  const int b = blockIdx.x;
-  if (b >= n) return;
-  const int lane = threadIdx.x;
-  const fh_problem& pw = whole[b];
-  const fh_result& rw = wres[b];
-  fh_problem& ps = safe[b];
+__device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, const fh_face* wfaces, double r_frac, double shrink,
+                                     int max_safe_poly, fh_problem& ps, fh_face* sfaces, int lane) {
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
     if (lane == 0) ps.n_seg = 0;
     return;
@@ -155,6 +148,14 @@ __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restr
     ps.n_poly = cnt;
     ps.face_begin = fb;
   }
+}
+
+__global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
+                                                       const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink,
+                                                       int max_safe_poly, fh_problem* __restrict__ safe, fh_face* __restrict__ sfaces) {
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  pair_glue_one(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, safe[b], sfaces, threadIdx.x);
 }
 
 }  // namespace fh

@@ -1410,4 +1410,41 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
   }
 }
 
+// Whole solve -> hand-off -> safe solve of one pair on ONE wavefront, pairs pulled from the ticket counter: the data dependency of
+// Faster::replan (faster.cpp:427 whole genNewTraj, :475 R = X_whole[k], :521-536 safe genNewTraj) is per pair, so nothing has to
+// wait for the stragglers of a batch-wide whole launch before the safe solves start.  Same device functions as solve_kernel and
+// pair_glue_kernel (fh_sample.hip.hpp): results are bit-identical to the three-launch pipeline.  The safe problem record and its
+// face rows are written and then read back by the same wavefront: agent-scope fences order the two through L2.
+template <int NSEG>
+__global__ void __launch_bounds__(64, 2) solve_pairs_kernel(const fh_problem* __restrict__ whole, const fh_face* __restrict__ wfaces,
+                                                         int n_pairs, int max_faces, fh_params par, double* __restrict__ workspace,
+                                                         unsigned long long* __restrict__ ticket, unsigned long long ticket_base,
+                                                         double r_frac, double shrink, int max_safe_poly, fh_result* wres,
+                                                         fh_problem* safe, fh_face* sfaces, fh_result* __restrict__ sres) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Solver<NSEG> sv;
+  sv.carve(smem, max_faces);
+  sv.lane = threadIdx.x;
+  sv.q = 0;
+  sv.qe = 0;
+  double* ws = workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
+  for (;;) {
+    unsigned int b = 0;
+    if (threadIdx.x == 0) b = (unsigned int)min(atomicAdd(ticket, 1ull) - ticket_base, (unsigned long long)n_pairs);
+    b = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+    if (b >= (unsigned int)n_pairs) break;
+    for (int phase = 0; phase < 2; phase++) {  // (one call site: the solver is inlined once)
+      if (phase == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        pair_glue_one(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, safe[b], sfaces, (int)threadIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      }
+      const fh_problem* pr = phase ? &safe[b] : &whole[b];
+      const fh_face* fcs = phase ? sfaces : wfaces;
+      fh_result* out = phase ? &sres[b] : &wres[b];
+      solve_one<NSEG>(sv, *pr, fcs, max_faces, par, ws, *out);
+    }
+  }
+}
+
 }  // namespace fh

@@ -185,6 +185,15 @@ int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_clou
 int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const double* segments, int n_segments,
                        const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* faces, int32_t* counts);
 
+/* Whole solve -> hand-off -> safe solve of every pair in ONE launch: a wavefront takes a pair through fh_solve_batch_device,
+ * fh_pair_glue_device and fh_solve_batch_device back to back (the per-pair dependency of Faster::replan, faster.cpp:427 -> :475 ->
+ * :521-536), so no safe solve waits for the slowest whole solve of the batch.  Arguments and results are those of the three calls
+ * (d_safe holds the safe problem templates on entry, as for fh_pair_glue_device); results are bit-identical to them.  The safe
+ * problems must fit the same max_seg / max_faces bounds as the whole ones. */
+int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face* d_faces, int n, int max_seg, int max_faces,
+                          double r_frac, double shrink, int max_safe_poly, fh_result* d_whole_results, fh_problem* d_safe,
+                          fh_face* d_safe_faces, fh_result* d_safe_results);
+
 int fh_sync(fh_ctx* ctx);
 
 /* Timing of the solve kernel, measured with HIP events recorded around every solve-kernel launch on

@@ -486,3 +486,40 @@ def test_gpu_decomposition_edge_cases(ctx):
     for k in range(3):
         assert np.all(counts[k::3] == counts[k])
         assert np.array_equal(faces["b"][k::3], np.broadcast_to(faces["b"][k], faces["b"][k::3].shape))
+
+
+def test_fused_pair_kernel_equals_three_launches(ctx):
+    """fh_solve_pairs_device (one launch, a wavefront per pair: whole -> hand-off -> safe) against the three-launch pipeline:
+    same device functions, bit-identical whole results, safe problems, safe faces and safe results."""
+    import torch
+
+    B, N = 1536, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=31, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    whole = whole.copy()
+    whole["f_final"][:16] = 1.0  # some whole problems without a solution: the pair ends there (safe n_seg = 0)
+    safe_t = corridor.safe_templates(whole)
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    dev = "cuda:0"
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    d_whole, d_faces = to_dev(whole), to_dev(faces)
+    outs = []
+    for fused in (False, True):
+        d_safe, d_sf = to_dev(safe_t), torch.zeros_like(d_faces)
+        d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros_like(d_wr)
+        if fused:
+            ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(),
+                                   d_sf.data_ptr(), d_sr.data_ptr())
+        else:
+            ctx.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, d_wr.data_ptr())
+            ctx.pair_glue_device(d_whole.data_ptr(), d_wr.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, d_safe.data_ptr(), d_sf.data_ptr())
+            ctx.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, mf, d_sr.data_ptr())
+        ctx.sync()
+        outs.append((d_wr.cpu().numpy().copy(), d_safe.cpu().numpy().copy(), d_sf.cpu().numpy().copy(), d_sr.cpu().numpy().copy()))
+    for a, b, name in zip(outs[0], outs[1], ("whole results", "safe problems", "safe faces", "safe results")):
+        assert np.array_equal(a, b), name
+    sres = outs[1][3].view(abi.result_dtype)
+    assert (sres["solved"] == 1).sum() > B // 2 and (outs[1][1].view(abi.problem_dtype)["n_seg"][:16] == 0).all()
