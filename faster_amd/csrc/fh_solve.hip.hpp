@@ -394,9 +394,26 @@ struct Solver {
     if (lane < NVP)
       for (int c = q_saved; c < q; c++) Q[c * S + lane] = 0.0;  // keep the zero padding beyond the active columns
     FH_SYNC();
+    // the tail and the first 2 KiB of R are requested before the Q copy starts, so that the three round trips overlap
+    const int nr = (q_saved * (q_saved + 1)) / 2, nr2 = (nr + 1) >> 1;
+    const double2* st2 = reinterpret_cast<const double2*>(ws_level);
+    const double2* sr2 = reinterpret_cast<const double2*>(ws_level + SNAP_ROFF);
+    constexpr int TAIL2 = SNAP_TAIL / 2, TAIL_TRIPS = (TAIL2 + 63) / 64;
+    static_assert(SNAP_TAIL % 2 == 0, "the tail is copied 16 B at a time");
+    double2 tail[TAIL_TRIPS];
+#pragma unroll
+    for (int j = 0; j < TAIL_TRIPS; j++) tail[j] = st2[(j * 64 + lane) < TAIL2 ? j * 64 + lane : 0];
+    double2 rr[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) rr[j] = sr2[(j * 64 + lane) < nr2 ? j * 64 + lane : 0];
     copy_in(Q, ws_level + SNAP_QOFF, q_saved * S);
-    copy_in(R, ws_level + SNAP_ROFF, (q_saved * (q_saved + 1)) / 2);
-    copy_in(x, ws_level, SNAP_TAIL);
+#pragma unroll
+    for (int j = 0; j < TAIL_TRIPS; j++)
+      if (j * 64 + lane < TAIL2) reinterpret_cast<double2*>(x)[j * 64 + lane] = tail[j];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      if (j * 64 + lane < nr2) reinterpret_cast<double2*>(R)[j * 64 + lane] = rr[j];
+    if (nr2 > 128) copy_in(R + 256, ws_level + SNAP_ROFF + 256, nr - 256);  // more than 22 active rows
     q = q_saved;
     FH_SYNC();
   }
