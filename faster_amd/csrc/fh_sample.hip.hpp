@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
     if (lane == 0) counts[b] = 0;
     return;
   }
-  const int N = pr.n_seg;
+  const int N = __builtin_amdgcn_readfirstlane(pr.n_seg);
   const double dt = rs.dt, DC = pr.dc;
-  const int size = sample_count(pr, rs);
+  const int size = __builtin_amdgcn_readfirstlane(sample_count(pr, rs));  // wave-uniform: scalar loop counters below
   if (lane == 0) counts[b] = size;
   for (int i = lane; i < N * 12; i += 64) coef[i] = rs.coeff[i / 12][i % 12];
   __syncthreads();
@@ -58,14 +58,21 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
   fh_state* out = states + (size_t)b * (size_t)max_samples;
   double t = 0;
   int interval = 0;
+  double knot = dt * (double)(interval + 1);  // dt_ * (interval + 1) of :133, recomputed only when the interval changes
   for (int base = 0; base < nwrite; base += 64) {
     double my_t = 0;
     int my_int = 0;
-    const int lim = (nwrite - base) < 64 ? (nwrite - base) : 64;
-    for (int j = 0; j < lim; j++) {  // the reference's scalar clock, :131-135
+    const int lim = __builtin_amdgcn_readfirstlane((nwrite - base) < 64 ? (nwrite - base) : 64);
+    for (int j = 0; j < lim; j++) {  // the reference's scalar clock, :131-135: every lane runs it and keeps its own tick
       t = t + DC;
-      if (t > dt * (interval + 1)) interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
-      if (j == lane) { my_t = t; my_int = interval; }
+      if (__ballot(t > knot) != 0ull) {  // wave-uniform; a real (rarely taken) branch, not two selects per tick
+        asm volatile("");
+        interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
+        knot = dt * (double)(interval + 1);
+      }
+      const bool mine = j == lane;
+      my_t = mine ? t : my_t;
+      my_int = mine ? interval : my_int;
     }
     if (lane < lim) {
       fh_state s;
