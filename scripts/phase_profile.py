@@ -5,7 +5,6 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from faster_amd import abi, capi, corridor
-from oracle import pair_glue
 
 names = ["load+dt_init", "trial setup+screen+eq", "states+CP", "scan", "build_g", "project", "backsolve+ratio+update", "add_row",
          "drop_row", "analyze", "snap save", "snap restore"]

@@ -101,3 +101,8 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
                 assert "liboracle" not in text and "faster_oracle" not in text.replace("oracle/faster_oracle.c", ""), fn
+    # the diagnostic scripts are not test infrastructure either
+    for fn in os.listdir(os.path.join(ROOT, "scripts")):
+        if fn.endswith((".py", ".sh")):
+            text = open(os.path.join(ROOT, "scripts", fn), errors="ignore").read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) and "liboracle" not in text, fn

@@ -1,7 +1,7 @@
 """Large randomized GPU-vs-oracle parity sweep (diagnostic; run on the GPU box). Reports every disagreement."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from faster_amd import abi, capi, corridor
 from oracle import oracle
 
