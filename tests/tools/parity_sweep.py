@@ -7,7 +7,7 @@ from oracle import oracle
 
 ctx = capi.Context(0)
 total = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 2026)
 done, bad = 0, 0
 worst_cost, worst_coeff = 0.0, 0.0
 t0 = time.time()
@@ -20,7 +20,7 @@ while done < total and time.time() - t0 < budget_s:
     pch = tuple(range(max(1, pmax - 2), pmax + 1))
     kw = dict(speed=float(rng.uniform(0.5, 4.5)), lateral=float(rng.uniform(0.0, 1.5)), acc0=float(rng.uniform(0, 3)),
               f_inc=float(rng.choice([0.5, 1.0, 1.0, 2.0])), v_max=float(rng.choice([3, 5])), a_max=float(rng.choice([3, 5])), j_max=float(rng.choice([5, 8])))
-    n = 2048 if n_seg * pmax <= 60 else 512
+    n = 2048 if n_seg * pmax <= 60 else (512 if n_seg * pmax <= 80 else 96)  # dense N=15 corridors: exact enumeration is slow on both sides
     force = bool(rng.random() < 0.6)
     pr, faces, _ = corridor.make_batch(n, n_seg, pch, force, int(rng.integers(1 << 30)), **kw)
     if rng.random() < 0.3 and n_seg * pmax <= 40:   # tighter corridors: pull every face 0.3-0.8 m inwards (skipped for
