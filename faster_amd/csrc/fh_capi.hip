@@ -85,7 +85,13 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 256, ctx->stream));
     ctx->ticket_base = 0;
   }
-  FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {  // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it
+    size_t& have = ctx->lds_attr[NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : 2)];
+    if (lds > have) {
+      FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      have = lds;
+    }
+  }
   if (ctx->ev_used + 2 > ctx->ev.size()) {
     if (ctx->ev.size() >= 8192) ctx->ev_used = 0;  // ring: keep the most recent launches only
     else
