@@ -527,3 +527,69 @@ def test_fused_pair_kernel_equals_three_launches(ctx):
         assert np.array_equal(a, b), name
     sres = outs[1][3].view(abi.result_dtype)
     assert (sres["solved"] == 1).sum() > B // 2 and (outs[1][1].view(abi.problem_dtype)["n_seg"][:16] == 0).all()
+
+
+def test_full_size_c4_properties(ctx):
+    """BASELINE config C4 at its full size (32768 whole+safe pairs) through size-independent properties of the model
+    (solverGurobi.cpp:332-407, :217-290): boundary conditions, C2 continuity, box limits at the segment starts, every control
+    point inside the polytope the result assigns its segment to, the reported cost, the factor window, and the hand-off."""
+    import torch
+
+    B, N = 32768, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    d_whole, d_faces, d_safe = _dev(whole), _dev(faces), _dev(corridor.safe_templates(whole))
+    d_sf = torch.zeros_like(d_faces)
+    d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_sr = torch.zeros_like(d_wr)
+    ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(),
+                           d_sf.data_ptr(), d_sr.data_ptr())
+    ctx.sync()
+    wres, sres = d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype)
+    safe, sfaces = d_safe.cpu().numpy().view(abi.problem_dtype), d_sf.cpu().numpy().view(abi.face_dtype)
+    assert wres["solved"].mean() > 0.99 and 0.6 < sres["solved"].mean() < 0.95
+
+    def check(pr, fc, rs, force_final):
+        ok = rs["solved"] == 1
+        p, r = pr[ok], rs[ok]
+        n = len(p)
+        h = r["dt"][:, None, None]
+        c = r["coeff"][:, :N, :].reshape(n, N, 4, 3)                     # [problem, segment, (a, b, c, d), axis]
+        a3, b2, c1, d0 = c[:, :, 0], c[:, :, 1], c[:, :, 2], c[:, :, 3]
+        end = a3 * h**3 + b2 * h**2 + c1 * h + d0
+        vend = 3 * a3 * h**2 + 2 * b2 * h + c1
+        aend = 6 * a3 * h + 2 * b2
+        x0 = p["x0"].reshape(n, 3, 3)
+        scale = 1.0 + np.abs(p["x0"]).max()
+        assert np.abs(d0[:, 0] - x0[:, 0]).max() < 1e-9 * scale and np.abs(c1[:, 0] - x0[:, 1]).max() < 1e-9 and np.abs(2 * b2[:, 0] - x0[:, 2]).max() < 1e-9
+        assert np.abs(end[:, :-1] - d0[:, 1:]).max() < 1e-8 and np.abs(vend[:, :-1] - c1[:, 1:]).max() < 1e-8
+        assert np.abs(aend[:, :-1] - 2 * b2[:, 1:]).max() < 1e-7          # C2 continuity (setDynamicConstraints)
+        xf = p["xf"].reshape(n, 3, 3)
+        assert np.abs(vend[:, -1] - xf[:, 1]).max() < 1e-7 and np.abs(aend[:, -1] - xf[:, 2]).max() < 1e-7
+        if force_final:
+            assert np.abs(end[:, -1] - xf[:, 0]).max() < 1e-7
+        lim = 1e-7
+        assert (np.abs(c1) <= p["v_max"][:, None, None] + lim).all() and (np.abs(2 * b2) <= p["a_max"][:, None, None] + lim).all()
+        assert (np.abs(6 * a3) <= p["j_max"][:, None, None] + lim).all()   # boxes at the segment starts only (setMaxConstraints)
+        cost = ((6 * a3) ** 2).sum(axis=(1, 2))
+        np.testing.assert_allclose(r["cost"], cost, rtol=1e-9, atol=1e-9)
+        assert (r["factor"] >= p["f_init"]).all() and (r["factor"] <= p["f_final"]).all() and (r["trials"] >= 1).all()
+        # control points in the assigned polytope: worst violation over all (problem, segment, control point, face)
+        cps = np.stack([d0, d0 + c1 * h / 3, d0 + 2 * c1 * h / 3 + b2 * h * h / 3, end], axis=2)   # [n, N, 4, 3]
+        q = r["assign"][:, :N].astype(np.int64)
+        assert (q >= 0).all() and (q < p["n_poly"][:, None]).all()
+        f0 = p["face_begin"][:, None] + np.take_along_axis(p["face_off"], q, axis=1)
+        f1 = p["face_begin"][:, None] + np.take_along_axis(p["face_off"], q + 1, axis=1)
+        worst = -np.inf
+        for k in range(int((f1 - f0).max())):
+            live = (f0 + k) < f1
+            idx = np.where(live, f0 + k, 0)
+            val = (fc["a"][idx][:, :, None, :] * cps).sum(axis=3) - fc["b"][idx][:, :, None]
+            worst = max(worst, float(np.where(live[:, :, None], val, -np.inf).max()))
+        assert worst <= 1e-6, worst
+        return ok
+
+    okw = check(whole, faces, wres, True)
+    oks = check(safe, sfaces, sres, False)
+    assert (safe["n_seg"][~okw] == 0).all() and (sres["solved"][~okw] == 0).all()   # no whole trajectory: the pair ends there
+    assert (oks <= okw).all()
