@@ -593,3 +593,23 @@ def test_full_size_c4_properties(ctx):
     oks = check(safe, sfaces, sres, False)
     assert (safe["n_seg"][~okw] == 0).all() and (sres["solved"][~okw] == 0).all()   # no whole trajectory: the pair ends there
     assert (oks <= okw).all()
+
+
+def test_full_size_translation_invariance(ctx):
+    """32768 whole problems and the same problems translated by a fixed vector (positions of x0/xf shifted, b += a.shift): same
+    feasibility, trials and factor; same cost and same polynomial but for the constant term (the model has no absolute frame)."""
+    B, N = 32768, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    shift = np.array([3.25, -1.5, 0.75])
+    w2, f2 = whole.copy(), faces.copy()
+    w2["x0"][:, :3] += shift
+    w2["xf"][:, :3] += shift
+    f2["b"] += f2["a"] @ shift
+    r1, r2 = ctx.solve_batch(whole, faces), ctx.solve_batch(w2, f2)
+    same = (r1["solved"] == r2["solved"]) & (r1["trials"] == r2["trials"]) & (r1["factor"] == r2["factor"])
+    assert same.mean() > 0.9995            # (a feasibility margin below the shift's rounding may flip: none expected, a few tolerated)
+    ok = same & (r1["solved"] == 1)
+    np.testing.assert_allclose(r2["cost"][ok], r1["cost"][ok], rtol=1e-7, atol=1e-9)
+    c1, c2 = r1["coeff"][ok][:, :N].reshape(-1, N, 4, 3), r2["coeff"][ok][:, :N].reshape(-1, N, 4, 3)
+    np.testing.assert_allclose(c2[:, :, :3], c1[:, :, :3], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c2[:, :, 3] - shift, c1[:, :, 3], rtol=0, atol=1e-6)
