@@ -117,3 +117,42 @@ def test_host_class_matches_oracle(tmp_path, oracle, fixture_corridor):
     c = out["whole_concurrent"]
     for k in ("solved", "trials", "factor", "dt", "cost", "n", "first", "last"):
         assert c[k] == w[k], k
+
+
+def _build_decomp_driver():
+    from faster_amd import build as fb
+
+    fb.build_all()
+    exe = os.path.join(ROOT, "tests", "cpp", "test_decomp_hip")
+    src = os.path.join(ROOT, "tests", "cpp", "test_decomp_hip.cpp")
+    deps = [src, fb.HOST_SO, os.path.join(ROOT, "faster_amd", "host", "decomp_hip.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "faster_amd", "host"), src,
+                               "-o", exe, "-L", os.path.join(ROOT, "faster_amd"), "-lsolverhip", "-lfasterhip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
+    return exe
+
+
+def test_device_decomposition_fails_loudly_without_gpu():
+    """DecompHip (the replan's cvxEllipsoidDecomp on the device) has no CPU fallback either."""
+    import json
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([_build_decomp_driver()], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["polytopes"] == 0 and out["error"] == 1
+    assert "DecompHip: device error" in r.stderr
+
+
+@pytest.mark.gpu
+def test_device_decomposition_through_the_host_class():
+    import json
+
+    r = subprocess.run([_build_decomp_driver()], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["polytopes"] == 2 and out["error"] == 0 and all(7 <= n <= 12 for n in out["rows"])
