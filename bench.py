@@ -69,8 +69,8 @@ def measured_valu_insts():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=96, help="timed steps (the end of the timed region drains the pipelines: a longer region is closer to the steady state)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=32768, help="whole+safe pairs per rank per step (C4: 32768)")
     ap.add_argument("--n-seg", type=int, default=10)
     ap.add_argument("--max-poly", type=int, default=6)

@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 24 --warmup 6 --no-cpu"
+BENCH="python $R/bench.py --no-cpu"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 tail -1 $OUT/stats.log
 i=0
