@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--pipeline", choices=["fused", "split"], default="split",
                     help="split: whole launch -> hand-off launch -> safe launch; fused: one launch, each wavefront takes a pair through "
                          "whole solve, hand-off and safe solve (same results)")
-    ap.add_argument("--inflight", type=int, default=8,
+    ap.add_argument("--inflight", type=int, default=12,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     args = ap.parse_args()
 
