@@ -12,7 +12,7 @@ FH_MAX_POLY = 8
 FH_MAX_FACES = 256
 FH_MAX_FACES_POLY = 64
 
-FH_ST_OPTIMAL, FH_ST_INFEASIBLE, FH_ST_NODE_LIMIT, FH_ST_ITER_LIMIT, FH_ST_BAD_INPUT = range(5)
+FH_ST_OPTIMAL, FH_ST_INFEASIBLE, FH_ST_NODE_LIMIT, FH_ST_ITER_LIMIT, FH_ST_BAD_INPUT, FH_ST_INTERRUPTED = range(6)
 
 problem_dtype = np.dtype(
     [
@@ -45,7 +45,7 @@ result_dtype = np.dtype(
         ("status", "<i4"),
         ("nodes", "<i4"),
         ("qp_iters", "<i4"),
-        ("reserved", "<i4"),
+        ("kflops", "<i4"),
         ("factor", "<f8"),
         ("dt", "<f8"),
         ("cost", "<f8"),
@@ -58,13 +58,15 @@ result_dtype = np.dtype(
 state_dtype = np.dtype([("pos", "<f8", (3,)), ("vel", "<f8", (3,)), ("accel", "<f8", (3,)), ("jerk", "<f8", (3,))], align=True)
 
 params_dtype = np.dtype([("feas_tol", "<f8"), ("dep_tol", "<f8"), ("max_nodes", "<i4"), ("max_iters", "<i4"), ("max_work", "<i4"),
-                         ("reserved", "<i4")], align=True)
+                         ("share", "<i4"), ("mip_gap", "<f8"), ("deadline_ms", "<f8")], align=True)
+share_stats_dtype = np.dtype([(k, "<u4") for k in ("donated", "stolen", "queue_full", "records_full", "records_used", "error",
+                                                   "interrupted", "workgroups")], align=True)
 
 assert problem_dtype.itemsize == 264, problem_dtype.itemsize
 assert face_dtype.itemsize == 32
 assert result_dtype.itemsize == 1600, result_dtype.itemsize
 assert state_dtype.itemsize == 96
-assert params_dtype.itemsize == 32
+assert params_dtype.itemsize == 48
 
 
 def default_params():
@@ -74,6 +76,9 @@ def default_params():
     p["max_nodes"] = 100000
     p["max_iters"] = 2000
     p["max_work"] = 0
+    p["share"] = 1
+    p["mip_gap"] = 0.0
+    p["deadline_ms"] = 0.0
     return p
 
 

@@ -7,8 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libfasterhip.so")
 SOURCES = [os.path.join(HERE, "csrc", "fh_capi.hip")]
-DEPS = SOURCES + [os.path.join(HERE, "csrc", "fh_solve.hip.hpp"), os.path.join(HERE, "csrc", "fh_sample.hip.hpp"),
-                  os.path.join(ROOT, "include", "fasterhip.h")]
+import glob  # noqa: E402
+
+DEPS = SOURCES + sorted(glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [os.path.join(ROOT, "include", "fasterhip.h")]
 HOST_SO = os.path.join(HERE, "libsolverhip.so")
 HOST_SOURCES = [os.path.join(HERE, "host", "solver_hip.cpp"), os.path.join(HERE, "host", "decomp_hip.cpp")]
 HOST_DEPS = HOST_SOURCES + [os.path.join(HERE, "host", "solver_hip.hpp"), os.path.join(HERE, "host", "faster_stub.hpp"),

@@ -15,6 +15,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
+    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
@@ -47,6 +48,18 @@ def lib():
         L.fh_set_params.argtypes = [vp, vp]
         L.fh_set_stream.restype = i32
         L.fh_set_stream.argtypes = [vp, vp]
+        L.fh_set_pair_margin.restype = i32
+        L.fh_set_pair_margin.argtypes = [vp, f64]
+        L.fh_request_stop.restype = i32
+        L.fh_request_stop.argtypes = [vp]
+        L.fh_clear_stop.restype = i32
+        L.fh_clear_stop.argtypes = [vp]
+        L.fh_share_stats_read.restype = i32
+        L.fh_share_stats_read.argtypes = [vp, vp]
+        L.fh_share_profile_read.restype = i32
+        L.fh_share_profile_read.argtypes = [vp, vp]
+        L.fh_fp64_peak.restype = i32
+        L.fh_fp64_peak.argtypes = [vp, vp]
         L.fh_solve_batch.restype = i32
         L.fh_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp]
         L.fh_solve_batch_speculative.restype = i32
@@ -115,6 +128,33 @@ class Context:
 
     def sync(self):
         self._check(lib().fh_sync(self._h), "fh_sync")
+
+    def set_pair_margin(self, r_margin):
+        """r_margin >= 0: the synthetic hand-off keeps R strictly inside its safe corridor (see fasterhip.h); < 0: SURVEY 8(d) literal."""
+        self._check(lib().fh_set_pair_margin(self._h, float(r_margin)), "fh_set_pair_margin")
+
+    def request_stop(self):
+        """StopExecution(): callable from any thread while a launch is running."""
+        self._check(lib().fh_request_stop(self._h), "fh_request_stop")
+
+    def clear_stop(self):
+        self._check(lib().fh_clear_stop(self._h), "fh_clear_stop")
+
+    def share_stats(self):
+        """Work-sharing statistics of the most recent solve launch (synchronises)."""
+        st = np.zeros((), dtype=abi.share_stats_dtype)
+        self._check(lib().fh_share_stats_read(self._h, st.ctypes.data_as(ctypes.c_void_p)), "fh_share_stats_read")
+        return {k: int(st[k]) for k in st.dtype.names}
+
+    def share_profile(self):
+        out = np.zeros(16, dtype=np.uint64)
+        self._check(lib().fh_share_profile_read(self._h, abi.ptr(out)), "fh_share_profile_read")
+        return out
+
+    def fp64_peak_tflops(self):
+        out = ctypes.c_double(0.0)
+        self._check(lib().fh_fp64_peak(self._h, ctypes.byref(out)), "fh_fp64_peak")
+        return out.value
 
     def timing_reset(self):
         self._check(lib().fh_timing_reset(self._h), "fh_timing_reset")

@@ -26,11 +26,17 @@ struct fh_ctx {
   fh_params par;
   std::string err;
   // staging buffers of the host-pointer entry points (grown on demand, reused)
-  void* d_buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // slot 5: snapshot workspace, 6: work-sharing control block + ring sequence numbers, 7: decomposition workspace,
+  // 8: task slots of the ring, 9: share records
+  void* d_buf[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
-  unsigned long long ticket_base = 0;  // tickets handed out by all previous solve launches of this context
-  size_t lds_attr[3] = {0, 0, 0};      // largest dynamic-LDS size already set per kernel instantiation
+  size_t lds_attr[6] = {0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
+  unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
+  unsigned int* d_abort = nullptr;          // its device address
+  double pair_margin = -1.0;                // fh_set_pair_margin
+  bool launched = false;                    // a solve launch has been issued since the control block was last checked
+  int last_grid = 0;
 };
 
 #define FH_HIP(call)                                                                            \
@@ -58,7 +64,11 @@ struct DeviceScope {
 
 static int ensure(fh_ctx* ctx, int slot, size_t bytes) {
   if (bytes <= ctx->d_cap[slot]) return FH_OK;
-  if (ctx->d_buf[slot]) FH_HIP(hipFree(ctx->d_buf[slot]));
+  if (ctx->d_buf[slot]) {
+    // a running launch of this context may still use the old buffer (workspace, ring): wait for it before freeing
+    FH_HIP(hipStreamSynchronize(ctx->stream));
+    FH_HIP(hipFree(ctx->d_buf[slot]));
+  }
   ctx->d_buf[slot] = nullptr;
   ctx->d_cap[slot] = 0;
   size_t want = std::max(bytes, (size_t)4096);
@@ -67,26 +77,53 @@ static int ensure(fh_ctx* ctx, int slot, size_t bytes) {
   return FH_OK;
 }
 
-template <int NSEG>
-static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n, int max_faces,
-                        fh_result* d_results) {
-  size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
+// Re-initialises the work-sharing state before EVERY solve launch (ticket, counters, ring head/tail and sequence numbers):
+// nothing persists between launches, so a failed launch cannot poison the next one.
+__global__ void share_init_kernel(fh::ShareCtl* ctl, unsigned long long* seqs) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (unsigned)FH_QCAP) seqs[i] = (unsigned long long)i;
+  if (i < sizeof(fh::ShareCtl) / 4) reinterpret_cast<unsigned int*>(ctl)[i] = 0u;
+}
+
+// One solve launch: NSEG selects the kernel instantiation, PAIRS the whole -> hand-off -> safe unit.
+template <int NSEG, bool PAIRS>
+static int launch_solve(fh_ctx* ctx, fh::SolveArgs ka) {
+  using SV = fh::Solver<NSEG>;
+  const int n = ka.n;
+  size_t lds = SV::lds_bytes(ka.max_faces);
   if (const char* pad = getenv("FH_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
-  auto kern = fh::solve_kernel<NSEG>;
-  // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU), never more than the batch
+  auto kern = fh::solve_kernel<NSEG, PAIRS>;
+  // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU)
   int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
-  const int grid = std::min(n, ctx->n_cu * per_cu);
-  // slot 5: snapshot workspace (one slot per tree level per workgroup), slot 6: the work counter
+  const int resident = ctx->n_cu * per_cu;
+  const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;
+  // small batches get helper workgroups (one per CU) that take over subtrees of hard problems
+  const int grid = share ? std::min(resident, std::max(n, ctx->n_cu)) : std::min(resident, n);
   int rc;
-  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_PADDED)) != FH_OK) return rc;
-  if (!ctx->d_buf[6]) {  // the ticket counter: zeroed once, never reset (see solve_kernel)
-    if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
-    FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 256, ctx->stream));
-    ctx->ticket_base = 0;
-  }
+  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * SV::SNAP_PADDED)) != FH_OK) return rc;
+  const size_t slot_stride = sizeof(fh::TaskHdr) + sizeof(double) * (size_t)SV::SNAP_PADDED;
+  if ((rc = ensure(ctx, 6, 4096 + sizeof(unsigned long long) * FH_QCAP)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 8, slot_stride * FH_QCAP)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 9, sizeof(fh::ShareRec) * FH_NRECS)) != FH_OK) return rc;
+  fh::ShareArgs& sa = ka.sa;
+  sa.ctl = reinterpret_cast<fh::ShareCtl*>(ctx->d_buf[6]);
+  sa.seqs = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(ctx->d_buf[6]) + 4096);
+  sa.slots = reinterpret_cast<unsigned char*>(ctx->d_buf[8]);
+  sa.slot_stride = slot_stride;
+  sa.recs = reinterpret_cast<fh::ShareRec*>(ctx->d_buf[9]);
+  sa.host_abort = ctx->d_abort;
+  sa.deadline_ticks = ctx->par.deadline_ms > 0 ? (unsigned long long)(ctx->par.deadline_ms * 1e5) : 0ull;  // 100 MHz clock
+  sa.enabled = share && grid > 1 ? 1 : 0;
+  sa.total_units = n;
+  sa.max_hungry = 2 * ctx->n_cu;  // two pollers per CU: enough hands for the tail, little traffic on the control line
+  sa.min_nodes = 16;
+  if (const char* mh = getenv("FH_DEBUG_MAX_HUNGRY")) sa.max_hungry = atoi(mh);  // experiments only
+  if (const char* mn = getenv("FH_DEBUG_MIN_NODES")) sa.min_nodes = atoi(mn);
+  ka.par = ctx->par;
+  ka.workspace = (double*)ctx->d_buf[5];
   {  // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it
-    size_t& have = ctx->lds_attr[NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : 2)];
+    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : 2)) + (PAIRS ? 3 : 0)];
     if (lds > have) {
       FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       have = lds;
@@ -101,57 +138,35 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
         ctx->ev.push_back(e);
       }
   }
+  hipLaunchKernelGGL(share_init_kernel, dim3((FH_QCAP + 255) / 256), dim3(256), 0, ctx->stream, sa.ctl, sa.seqs);
+  FH_HIP(hipGetLastError());
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, n, max_faces, ctx->par,
-                     (double*)ctx->d_buf[5], (unsigned long long*)ctx->d_buf[6], ctx->ticket_base, d_results);
-  ctx->ticket_base += (unsigned long long)n + (unsigned long long)grid;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, ka);
   FH_HIP(hipGetLastError());
   FH_HIP(hipEventRecord(e1, ctx->stream));
   ctx->ev_used += 2;
+  ctx->launched = true;
+  ctx->last_grid = grid;
   return FH_OK;
 }
 
-template <int NSEG>
-static int launch_pairs(fh_ctx* ctx, const fh_problem* d_whole, const fh_face* d_faces, int n, int max_faces, double r_frac,
-                        double shrink, int max_safe_poly, fh_result* d_wres, fh_problem* d_safe, fh_face* d_sfaces, fh_result* d_sres) {
-  const size_t lds = fh::Solver<NSEG>::lds_bytes(max_faces);
-  auto kern = fh::solve_pairs_kernel<NSEG>;
-  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-  if (per_cu < 1) per_cu = 1;
-  const int grid = std::min(n, ctx->n_cu * per_cu);
-  int rc;
-  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * fh::Solver<NSEG>::SNAP_PADDED)) != FH_OK) return rc;
-  if (!ctx->d_buf[6]) {
-    if ((rc = ensure(ctx, 6, 256)) != FH_OK) return rc;
-    FH_HIP(hipMemsetAsync(ctx->d_buf[6], 0, 256, ctx->stream));
-    ctx->ticket_base = 0;
+// after the stream has been synchronised: did the last solve launch report a protocol failure?
+static int check_share_error(fh_ctx* ctx) {
+  if (!ctx->launched || !ctx->d_buf[6]) return FH_OK;
+  ctx->launched = false;
+  fh::ShareCtl h;
+  FH_HIP(hipMemcpy(&h, ctx->d_buf[6], sizeof(h), hipMemcpyDeviceToHost));
+  if (h.error) {
+    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(h.error) + "); results of the launch are incomplete";
+    return FH_ERR_DEVICE;
   }
-  FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (ctx->ev_used + 2 > ctx->ev.size()) {
-    if (ctx->ev.size() >= 8192) ctx->ev_used = 0;
-    else
-      for (int k = 0; k < 2; k++) {
-        hipEvent_t e;
-        FH_HIP(hipEventCreate(&e));
-        ctx->ev.push_back(e);
-      }
-  }
-  hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
-  FH_HIP(hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_whole, d_faces, n, max_faces, ctx->par,
-                     (double*)ctx->d_buf[5], (unsigned long long*)ctx->d_buf[6], ctx->ticket_base, r_frac, shrink, max_safe_poly,
-                     d_wres, d_safe, d_sfaces, d_sres);
-  ctx->ticket_base += (unsigned long long)n + (unsigned long long)grid;
-  FH_HIP(hipGetLastError());
-  FH_HIP(hipEventRecord(e1, ctx->stream));
-  ctx->ev_used += 2;
   return FH_OK;
 }
 
 extern "C" {
 
-const char* fh_version(void) { return "fasterhip 0.1 gfx950"; }
+const char* fh_version(void) { return "fasterhip 0.2 gfx950"; }
 
 void fh_default_params(fh_params* p) {
   if (!p) return;
@@ -160,7 +175,9 @@ void fh_default_params(fh_params* p) {
   p->max_nodes = 100000;
   p->max_iters = 2000;
   p->max_work = 0;
-  p->reserved = 0;
+  p->share = 1;
+  p->mip_gap = 0.0;
+  p->deadline_ms = 0.0;
 }
 
 int fh_create(fh_ctx** out, int device) {
@@ -194,14 +211,20 @@ int fh_create(fh_ctx** out, int device) {
   ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   FH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
+  // the stop word lives in mapped, coherent host memory: StopExecution() is a plain store from any host thread
+  FH_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_abort), 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *ctx->h_abort = 0u;
+  FH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_abort), ctx->h_abort, 0));
   return FH_OK;
 }
 
 void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
-    for (int i = 0; i < 8; i++)
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 10; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
+    if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   }
@@ -213,13 +236,101 @@ const char* fh_last_error(const fh_ctx* ctx) { return ctx ? ctx->err.c_str() : "
 int fh_set_params(fh_ctx* ctx, const fh_params* p) {
   if (!ctx || !p) return FH_ERR_ARG;
   if (!(p->feas_tol > 0) || !(p->dep_tol > 0) || p->max_nodes < 1 || p->max_iters < 1 || p->max_work < 0) return FH_ERR_ARG;
+  if (!(p->mip_gap >= 0) || !(p->mip_gap < 1) || !(p->deadline_ms >= 0) || !std::isfinite(p->deadline_ms)) return FH_ERR_ARG;
   ctx->par = *p;
   return FH_OK;
 }
 
 int fh_set_stream(fh_ctx* ctx, void* hip_stream) {
   if (!ctx) return FH_ERR_ARG;
-  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  hipStream_t next = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  if (next != ctx->stream && ctx->device >= 0 && ctx->stream) {
+    // one work queue / workspace per context: launches on the old stream must be over before the new stream may use them
+    DeviceScope device_scope(ctx);
+    FH_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->stream = next;
+  return FH_OK;
+}
+
+int fh_set_pair_margin(fh_ctx* ctx, double r_margin) {
+  if (!ctx || !(r_margin == r_margin)) return FH_ERR_ARG;
+  ctx->pair_margin = r_margin < 0 ? -1.0 : r_margin;
+  return FH_OK;
+}
+
+int fh_request_stop(fh_ctx* ctx) {
+  if (!ctx) return FH_ERR_ARG;
+  if (ctx->device < 0 || !ctx->h_abort) return FH_ERR_DEVICE;
+  __atomic_store_n(ctx->h_abort, 1u, __ATOMIC_RELEASE);
+  return FH_OK;
+}
+
+int fh_clear_stop(fh_ctx* ctx) {
+  if (!ctx) return FH_ERR_ARG;
+  if (ctx->device < 0 || !ctx->h_abort) return FH_ERR_DEVICE;
+  __atomic_store_n(ctx->h_abort, 0u, __ATOMIC_RELEASE);
+  return FH_OK;
+}
+
+// diagnostic builds (-DFH_SHARE_PROFILE): the 16 profile words of the last launch (ticks of the 100 MHz clock / counts)
+int fh_share_profile_read(fh_ctx* ctx, unsigned long long* out16) {
+  if (!ctx || !out16) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (!ctx->d_buf[6]) return FH_ERR_ARG;
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  fh::ShareCtl h;
+  FH_HIP(hipMemcpy(&h, ctx->d_buf[6], sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; i++) { out16[i] = h.prof[i]; out16[8 + i] = h.prof2[i]; }
+  return FH_OK;
+}
+
+int fh_share_stats_read(fh_ctx* ctx, fh_share_stats* out) {
+  if (!ctx || !out) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  std::memset(out, 0, sizeof(*out));
+  if (!ctx->d_buf[6]) return FH_OK;
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  fh::ShareCtl h;
+  FH_HIP(hipMemcpy(&h, ctx->d_buf[6], sizeof(h), hipMemcpyDeviceToHost));
+  out->donated = h.donated; out->stolen = h.stolen; out->queue_full = h.q_full; out->records_full = h.rec_full;
+  out->records_used = std::min<unsigned>(h.rec_next, FH_NRECS); out->error = h.error; out->interrupted = h.interrupted;
+  out->workgroups = (uint32_t)ctx->last_grid;
+  ctx->launched = false;
+  if (h.error) {
+    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(h.error) + ")";
+    return FH_ERR_DEVICE;
+  }
+  return FH_OK;
+}
+
+int fh_fp64_peak(fh_ctx* ctx, double* tflops) {
+  if (!ctx || !tflops) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  int rc;
+  const int blocks = ctx->n_cu * 8, threads = 256, iters = 20000;
+  if ((rc = ensure(ctx, 3, sizeof(double) * (size_t)blocks * threads)) != FH_OK) return rc;
+  hipEvent_t a, b;
+  FH_HIP(hipEventCreate(&a));
+  FH_HIP(hipEventCreate(&b));
+  double best = 0;
+  for (int rep = 0; rep < 4; rep++) {  // first repetition warms up clocks and code
+    FH_HIP(hipEventRecord(a, ctx->stream));
+    hipLaunchKernelGGL(fh::fp64_peak_kernel, dim3((unsigned)blocks), dim3(threads), 0, ctx->stream, (double*)ctx->d_buf[3], iters, 1.0);
+    FH_HIP(hipGetLastError());
+    FH_HIP(hipEventRecord(b, ctx->stream));
+    FH_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    FH_HIP(hipEventElapsedTime(&ms, a, b));
+    const double fl = 2.0 * 8.0 * (double)iters * (double)blocks * threads;
+    if (rep > 0 && ms > 0) best = std::max(best, fl / (ms * 1e-3) / 1e12);
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *tflops = best;
   return FH_OK;
 }
 
@@ -228,7 +339,7 @@ int fh_sync(fh_ctx* ctx) {
   if (ctx->device < 0) return FH_ERR_DEVICE;
   DeviceScope device_scope(ctx);
   FH_HIP(hipStreamSynchronize(ctx->stream));
-  return FH_OK;
+  return check_share_error(ctx);
 }
 
 int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, int n, int max_seg,
@@ -241,9 +352,12 @@ int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_fa
   if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
   if (max_faces <= 0 || max_faces > FH_MAX_FACES) max_faces = FH_MAX_FACES;
   max_faces = (max_faces + 7) & ~7;
-  if (max_seg <= 6) return launch_solve<6>(ctx, d_problems, d_faces, n, max_faces, d_results);
-  if (max_seg <= 10) return launch_solve<10>(ctx, d_problems, d_faces, n, max_faces, d_results);
-  return launch_solve<FH_MAX_SEG>(ctx, d_problems, d_faces, n, max_faces, d_results);
+  fh::SolveArgs ka;
+  std::memset(&ka, 0, sizeof(ka));
+  ka.problems = d_problems; ka.faces = d_faces; ka.results = d_results; ka.n = n; ka.max_faces = max_faces;
+  if (max_seg <= 6) return launch_solve<6, false>(ctx, ka);
+  if (max_seg <= 10) return launch_solve<10, false>(ctx, ka);
+  return launch_solve<FH_MAX_SEG, false>(ctx, ka);
 }
 
 int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
@@ -281,7 +395,7 @@ int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces
   if (rc != FH_OK) return rc;
   FH_HIP(hipMemcpyAsync(results, ctx->d_buf[2], sizeof(fh_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   FH_HIP(hipStreamSynchronize(ctx->stream));
-  return FH_OK;
+  return check_share_error(ctx);
 }
 
 int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
@@ -297,7 +411,7 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
     std::vector<double> factors;
     size_t next = 0;
     bool done = false, passthrough = false;
-    long long nodes = 0, iters = 0;
+    long long nodes = 0, iters = 0, kflops = 0;
   };
   std::vector<Search> search((size_t)n);
   for (int i = 0; i < n; i++) {
@@ -344,6 +458,7 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
           const fh_result& r = sub_res[k];
           s.nodes += r.nodes;
           s.iters += r.qp_iters;
+          s.kflops += r.kflops;
           s.next++;
           const bool last = s.next == s.factors.size();
           if (r.solved || r.status == FH_ST_BAD_INPUT || last) {
@@ -351,6 +466,7 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
             results[i].trials = r.status == FH_ST_BAD_INPUT ? 0 : (int32_t)s.next;
             results[i].nodes = (int32_t)s.nodes;
             results[i].qp_iters = (int32_t)s.iters;
+            results[i].kflops = (int32_t)std::min<long long>(s.kflops, 0x7fffffffLL);
             s.done = true;
           }
         }
@@ -408,7 +524,7 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
   if (!d_whole || !d_whole_results || !d_safe) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
   hipLaunchKernelGGL(fh::pair_glue_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole,
-                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces);
+                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, ctx->pair_margin, d_safe, d_safe_faces);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
@@ -425,14 +541,14 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
   if (max_faces <= 0 || max_faces > FH_MAX_FACES) max_faces = FH_MAX_FACES;
   max_faces = (max_faces + 7) & ~7;
-  if (max_seg <= 6)
-    return launch_pairs<6>(ctx, d_whole, d_faces, n, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe, d_safe_faces,
-                           d_safe_results);
-  if (max_seg <= 10)
-    return launch_pairs<10>(ctx, d_whole, d_faces, n, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe, d_safe_faces,
-                            d_safe_results);
-  return launch_pairs<FH_MAX_SEG>(ctx, d_whole, d_faces, n, max_faces, r_frac, shrink, max_safe_poly, d_whole_results, d_safe,
-                                  d_safe_faces, d_safe_results);
+  fh::SolveArgs ka;
+  std::memset(&ka, 0, sizeof(ka));
+  ka.problems = d_whole; ka.faces = d_faces; ka.results = d_whole_results; ka.n = n; ka.max_faces = max_faces;
+  ka.safe = d_safe; ka.sfaces = d_safe_faces; ka.sres = d_safe_results;
+  ka.r_frac = r_frac; ka.shrink = shrink; ka.max_safe_poly = max_safe_poly; ka.r_margin = ctx->pair_margin;
+  if (max_seg <= 6) return launch_solve<6, true>(ctx, ka);
+  if (max_seg <= 10) return launch_solve<10, true>(ctx, ka);
+  return launch_solve<FH_MAX_SEG, true>(ctx, ka);
 }
 
 int fh_timing_reset(fh_ctx* ctx) {

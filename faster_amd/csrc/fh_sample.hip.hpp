@@ -93,8 +93,13 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
 
 // One wavefront per pair: the scalar sample clock runs once (wave-uniform), the polytope tests and the face copy are
 // lane-parallel over faces with coalesced 32-B rows.
+// r_margin < 0: SURVEY.md 8(d) to the letter — every polytope of the safe corridor is the whole one shrunk by `shrink`, starting at
+// the first shrunk polytope that contains R (else the least violated one: R may then lie outside its own corridor and the safe
+// problem is infeasible for every factor).  r_margin >= 0: FASTER decomposes the safe corridor around R (faster.cpp:475-499: R is the
+// first vertex of JPS_safe), so R is strictly inside its first polytope: the corridor starts at the first polytope that contains R
+// and no face of that polytope is pulled closer to R than r_margin (faces R already touches stay where they are).
 __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, const fh_face* wfaces, double r_frac, double shrink,
-                                     int max_safe_poly, fh_problem& ps, fh_face* sfaces, int lane) {
+                                     int max_safe_poly, double r_margin, fh_problem& ps, fh_face* sfaces, int lane) {
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
     if (lane == 0) ps.n_seg = 0;
     return;
@@ -118,7 +123,10 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
     ps.x0[3 + lane] = R.vel[lane];
     ps.x0[6 + lane] = R.accel[lane];
   }
-  // first polytope (shrunk) that contains R, else the least violated one
+  const bool keep_r = r_margin >= 0.0;
+  const double test_shrink = keep_r ? 0.0 : shrink;  // which polytope holds R: the original one / the shrunk one
+  const double slack_ok = keep_r ? 1e-7 : 0.0;       // R is a point of the whole trajectory: inside its polytope up to the solver tolerance
+  // first polytope that contains R, else the least violated one
   const int P = pw.n_poly;
   const int fb = pw.face_begin;
   int start = 0;
@@ -129,11 +137,11 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
     for (int f = pw.face_off[p] + lane; f < pw.face_off[p + 1]; f += 64) {
       const fh_face fc = wfaces[fb + f];
       const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      worst = fmax(worst, fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - shrink * nr));
+      worst = fmax(worst, fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - test_shrink * nr));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
-    if (worst <= 0) { start = p; found = true; }
+    if (worst <= slack_ok) { start = p; found = true; }
     else if (worst < best) { best = worst; start = p; }
   }
   int cnt = P - start;
@@ -141,10 +149,16 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
   if (P == 0) cnt = 0;
   const int src0 = P ? pw.face_off[start] : 0;
   const int total = P ? pw.face_off[start + cnt] - src0 : 0;
+  const int first_end = P ? pw.face_off[start + 1] - src0 : 0;  // rows of the polytope that holds R
   for (int f = lane; f < total; f += 64) {
     fh_face fc = wfaces[fb + src0 + f];
     const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-    fc.b -= shrink * nr;
+    double b = fc.b - shrink * nr;
+    if (keep_r && f < first_end) {
+      const double ar = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2];
+      b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
+    }
+    fc.b = b;
     sfaces[fb + f] = fc;
   }
   if (lane <= FH_MAX_POLY) {
@@ -159,10 +173,11 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
 
 __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
                                                        const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink,
-                                                       int max_safe_poly, fh_problem* __restrict__ safe, fh_face* __restrict__ sfaces) {
+                                                       int max_safe_poly, double r_margin, fh_problem* __restrict__ safe,
+                                                       fh_face* __restrict__ sfaces) {
   const int b = blockIdx.x;
   if (b >= n) return;
-  pair_glue_one(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, safe[b], sfaces, threadIdx.x);
+  pair_glue_one(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, r_margin, safe[b], sfaces, threadIdx.x);
 }
 
 }  // namespace fh

@@ -1,0 +1,193 @@
+// fh_share.hip.hpp — device-scope work sharing between the persistent workgroups of the solve kernels (gfx950).
+//
+// Why: one genNewTraj() is a sequence of branch-and-bound trees (one per factor trial).  Almost all of them have a handful of
+// nodes, a few have 10^2..10^4, and a tree explored by ONE wavefront pins that wavefront for milliseconds while the other
+// ~2000 resident wavefronts have run out of problems (round-1 profile: 7.7 / 16.2 ms per launch for ~3 ms of bulk work).
+// Gurobi explores one tree with all its threads behind m.optimize() (/root/reference/faster/src/solverGurobi.cpp:566,
+// Threads = 0, faster/param/faster.yaml:41); this file is the counterpart: a wavefront that has run out of fresh problems
+// takes over untried sibling subtrees of a tree that is still being explored elsewhere.
+//
+// Protocol (/opt/skills/guides/cdna_hip_programming.md G16, form R1): EVERY word another workgroup may read is written with an
+// 8-byte agent-scope store (write-through, `sc1`) and read with an agent-scope load (served by L2, never by a stale L1 line);
+// a producer drains its stores (`s_waitcnt vmcnt(0)`) before it raises the flag / sequence number / counter that publishes
+// them.  No release fence is used anywhere: `buffer_wbl2` would write back the whole XCD's dirty L2 — megabytes of other
+// workgroups' node snapshots — on every hand-off (measured: a 32768-problem launch went from 8 ms to 170 ms).
+//   * ShareCtl        one per context: ticket counter, hand-off counters, units done, error word;
+//   * hand-off ring   a workgroup that runs out of problems draws a WAIT TICKET t (one atomic add) and from then on polls only
+//                     its own word seqs[t % FH_QCAP] — no shared hot word, no compare-and-swap storm when a frame appears
+//                     (the first version let every poller race for a queue head: a 32768-problem launch became 2-3x slower).
+//                     A donor publishes frame number p = q_tail only while p < wait_ticket, so every published frame has a
+//                     committed taker, and a taker whose frame never comes leaves when all units are done.  A frame is the
+//                     parent node's dual active-set state (the same snapshot block the owner keeps per tree level), the
+//                     ordered list of untried children, the partial assignment and the DFS key of the parent;
+//   * ShareRec        one per problem that has given work away: incumbent (cost, DFS key, jerks, assignment) under a spin
+//                     lock, the number of outstanding parts of the current trial's tree, accumulated statistics.
+// Nobody ever waits for anybody: the part that brings `pending` to zero continues the problem (next factor trial, or the
+// final result), whichever workgroup that is.  Results do not depend on who explored what: the optimum of a trial is the
+// lexicographic minimum of (cost, DFS key) over all leaves, which is what the sequential depth-first search returns (it
+// keeps the FIRST leaf of minimal cost), and the jerks of a leaf depend only on the path from the root (every node
+// continues from a bit-exact copy of its parent's factorisation).
+//
+// Every spin is bounded (FH_SPIN_LIMIT / a wall-clock watchdog): a protocol failure raises ShareCtl::error, all workers
+// leave, and the host reports FH_ERR_DEVICE instead of hanging the device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fh {
+
+#define FH_QCAP 1024          // task slots in the ring (power of two)
+#define FH_NRECS 4096         // share records per launch (problems that gave work away)
+#define FH_SPIN_LIMIT (1u << 22)
+#define FH_WATCHDOG_TICKS (20ull * 100000000ull)  // 20 s of the 100 MHz s_memrealtime clock: a hungry worker gives up
+
+struct ShareCtl {
+  // ---- line 0: polled by hungry workers; zeroed before every launch ----
+  unsigned int done;         // units (problems, or pairs) whose final result has been written
+  unsigned int error;        // != 0: protocol failure / watchdog, everybody leaves
+  unsigned int interrupted;  // a worker has seen the host's abort word / the deadline (sticky)
+  unsigned int pad0[13];
+  // ---- line 1: zeroed before every launch ----
+  unsigned long long ticket;  // next fresh unit
+  unsigned int rec_next;      // share records handed out
+  unsigned int donated, stolen, q_full, rec_full, lock_spins, max_fill;  // statistics
+  unsigned int pad1[7];
+  // ---- line 2: the hand-off counters (zeroed before every launch; written only when a worker runs out of problems or a frame
+  // is published, read by the busy workers every few nodes) ----
+  unsigned long long wait_ticket;  // wait tickets drawn: takers committed to frame numbers 0 .. wait_ticket-1
+  unsigned long long q_tail;       // frames published (or being published): always <= wait_ticket
+  unsigned long long pad2[6];
+  // ---- line 3: -DFH_SHARE_PROFILE builds only: 100 MHz ticks spent in / number of [0,1] look_around, [2,3] donate,
+  // [4,5] waiting for a frame (successful waits), [6,7] copying a frame out of its slot ----
+  unsigned long long prof[8];
+  // ---- line 4: [0,1] staging + trial set-up of a taken frame until its first node, [2,3] searching taken frames (ticks, nodes),
+  // [4,5] finish_part (ticks, count), [6] ticks of workers between "tickets exhausted" and leaving, [7] workers that left ----
+  unsigned long long prof2[8];
+};
+static_assert(sizeof(ShareCtl) == 320, "five 64-byte lines");
+
+struct ShareRec {  // 512 B
+  unsigned int lock;
+  int pending;                    // outstanding parts of the current trial's tree (the owner's part + frames given away)
+  unsigned long long inc_cost;    // incumbent cost as double bits (+inf: none); costs are >= 0, so the bit patterns order like the values
+  unsigned long long inc_key;     // DFS key of the incumbent leaf
+  int nodes, iters;               // accumulated by finished parts (all trials of the problem)
+  unsigned int limit, pad0;       // FH_ST_* limit status of the current trial (0: none)
+  unsigned long long flops;       // accumulated flop estimate
+  double x[48];
+  unsigned long long assign_lo, assign_hi;  // incumbent assignment, one byte per segment
+  unsigned int pad[16];
+};
+static_assert(sizeof(ShareRec) == 512, "share record layout");
+
+// A task = 32 header words + the snapshot block.  Header words (all 8 bytes, written write-through by one lane):
+enum { TH_REC_B = 0,      // rec | b << 32
+       TH_PHASE_DEPTH,    // phase | depth0 << 32
+       TH_KEY,            // DFS key of the parent
+       TH_H, TH_F, TH_BASE,   // doubles: step of the trial, its factor, max(dt_initial, 2 DC)
+       TH_TRIALS_SEG,     // trials | seg << 32
+       TH_CNT_NEXT,       // cnt | next << 32
+       TH_Q_QE,           // q_saved | qe << 32
+       TH_ORDER, TH_ASSIGN_LO, TH_ASSIGN_HI,
+       TH_WORDS = 32 };
+struct TaskHdr {
+  unsigned long long w[TH_WORDS];
+};
+static_assert(sizeof(TaskHdr) == 256, "task header layout");
+
+struct ShareArgs {
+  ShareCtl* ctl;
+  unsigned long long* seqs;   // [FH_QCAP] Vyukov sequence numbers, seqs[i] = i after fh_create
+  unsigned char* slots;       // [FH_QCAP] x slot_stride bytes: TaskHdr + snapshot
+  unsigned long long slot_stride;
+  ShareRec* recs;             // [FH_NRECS]
+  const unsigned int* host_abort;  // mapped host word written by StopExecution(); may be null
+  unsigned long long deadline_ticks;  // s_memrealtime ticks (100 MHz) after which workers stop; 0 = none
+  int enabled;                // 0: no frames are given away (workers leave when the tickets are exhausted)
+  int total_units;
+  int max_hungry;             // at most this many workgroups poll the queue; the others leave when the tickets are exhausted
+  int min_nodes;              // a problem gives work away only after this many branch-and-bound nodes (all trials so far): small trees
+                              // are cheaper to finish than to hand over (a hop costs about as much as 2-3 nodes)
+};
+
+#define FH_AGENT __HIP_MEMORY_SCOPE_AGENT
+#ifdef FH_SHARE_PROFILE
+#define FH_SP_T0() const unsigned long long sp_t0__ = __builtin_amdgcn_s_memrealtime()
+#define FH_SP_ADD(arr, slot, extra)                                                                                          \
+  do {                                                                                                                      \
+    if (threadIdx.x == 0) {                                                                                                 \
+      __hip_atomic_fetch_add(&sa.ctl->arr[slot], __builtin_amdgcn_s_memrealtime() - sp_t0__, __ATOMIC_RELAXED, FH_AGENT);   \
+      __hip_atomic_fetch_add(&sa.ctl->arr[(slot) + 1], (unsigned long long)(extra), __ATOMIC_RELAXED, FH_AGENT);            \
+    }                                                                                                                       \
+  } while (0)
+#else
+#define FH_SP_T0()
+#define FH_SP_ADD(arr, slot, extra)
+#endif
+template <typename T>
+__device__ __forceinline__ T ald(T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, FH_AGENT); }
+template <typename T>
+__device__ __forceinline__ void ast(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, FH_AGENT); }
+template <typename T>
+__device__ __forceinline__ T aadd(T* p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, FH_AGENT); }
+
+// producer side of a hand-off: the write-through stores of this wavefront issued so far have reached L2 / the fabric
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// consumer side, once per hand-off: drops this CU's L1 lines (plain loads of data another workgroup wrote and released, e.g. the
+// safe problem of a pair); does not touch L2
+__device__ __forceinline__ void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// 8-byte write-through store / L1-bypassing load of shared payload
+__device__ __forceinline__ void wt_store(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, FH_AGENT);
+}
+__device__ __forceinline__ void wt_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, FH_AGENT); }
+__device__ __forceinline__ double cc_load(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, FH_AGENT));
+}
+__device__ __forceinline__ unsigned long long cc_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, FH_AGENT); }
+
+__device__ __forceinline__ unsigned long long wall_ticks() { return __builtin_amdgcn_s_memrealtime(); }
+
+// ---- the hand-off ring.  All functions are called by ONE lane. ----
+// seqs[i] == p      : slot i is free for frame number p (p % FH_QCAP == i)
+// seqs[i] == p + 1  : frame p is in the slot, payload complete
+// seqs[i] == p + FH_QCAP : the taker of frame p has copied it out; the slot is free for frame p + FH_QCAP
+// Reserve the next frame number for writing — ONE attempt: ~0ull if no uncommitted taker is waiting, the ring is full, or
+// another donor took the number (when the fresh problems run out, every busy workgroup sees the new takers at its next
+// look-around: a retry loop here made ~2000 donors hammer q_tail for 512 numbers, 600 us per donation).
+__device__ inline unsigned long long q_reserve(const ShareArgs& sa) {
+  const unsigned long long pos = ald(&sa.ctl->q_tail);
+  if (pos >= ald(&sa.ctl->wait_ticket)) return ~0ull;              // nobody is waiting for frame `pos`
+  if (ald(&sa.seqs[pos & (FH_QCAP - 1)]) != pos) return ~0ull;     // slot not released yet (ring full) or the number is gone
+  unsigned long long expect = pos;
+  if (__hip_atomic_compare_exchange_strong(&sa.ctl->q_tail, &expect, pos + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) return pos;
+  return ~0ull;
+}
+// after the payload has been written and drained
+__device__ __forceinline__ void q_publish(const ShareArgs& sa, unsigned long long pos) { ast(&sa.seqs[pos & (FH_QCAP - 1)], pos + 1); }
+// has frame number `pos` (this taker's wait ticket) arrived?
+__device__ __forceinline__ bool q_arrived(const ShareArgs& sa, unsigned long long pos) { return ald(&sa.seqs[pos & (FH_QCAP - 1)]) == pos + 1; }
+// after the payload has been read completely
+__device__ __forceinline__ void q_release(const ShareArgs& sa, unsigned long long pos) { ast(&sa.seqs[pos & (FH_QCAP - 1)], pos + FH_QCAP); }
+
+__device__ __forceinline__ TaskHdr* slot_hdr(const ShareArgs& sa, unsigned long long pos) {
+  return reinterpret_cast<TaskHdr*>(sa.slots + (pos & (FH_QCAP - 1)) * sa.slot_stride);
+}
+__device__ __forceinline__ double* slot_snap(const ShareArgs& sa, unsigned long long pos) {
+  return reinterpret_cast<double*>(sa.slots + (pos & (FH_QCAP - 1)) * sa.slot_stride + sizeof(TaskHdr));
+}
+
+// ---- incumbent lock of a share record (one lane) ----
+__device__ inline bool rec_lock(const ShareArgs& sa, ShareRec* r) {
+  for (unsigned spin = 0; spin < FH_SPIN_LIMIT; spin++) {
+    unsigned int expect = 0u;
+    if (__hip_atomic_compare_exchange_strong(&r->lock, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) return true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  ast(&sa.ctl->error, 3u);
+  return false;
+}
+// (the holder drains its write-through stores first)
+__device__ __forceinline__ void rec_unlock(ShareRec* r) { __hip_atomic_store(&r->lock, 0u, __ATOMIC_RELAXED, FH_AGENT); }
+
+}  // namespace fh

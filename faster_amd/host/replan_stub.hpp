@@ -325,6 +325,7 @@ public:
       keep_first(JPS_safe, par_.max_poly_safe);
       Mpos = JPS_safe.back();
       l_constraints_safe_ = to_solver_constraints(decompose_(JPS_safe, unknown_and_occupied_, par_.drone_radius, par_.z_ground));
+      if (l_constraints_safe_.empty()) { L.stage = 3; return false; }  // failed (device) decomposition: no safe corridor, as for the whole one
       if (l_constraints_safe_.back().inside(fhstub::Vec3(G.x, G.y, G.z))) Mpos = G;
       state M;
       M.setPos(Mpos.x, Mpos.y, Mpos.z);

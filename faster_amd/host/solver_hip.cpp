@@ -16,14 +16,19 @@ SolverHip::~SolverHip() {
 }
 
 bool SolverHip::ensureContext() {
-  if (ctx_ && device_rc_ != FH_ERR_DEVICE) return true;
-  if (ctx_) return false;  // creation already failed once: do not retry on every replan
-  device_rc_ = fh_create(&ctx_, -1);
-  if (device_rc_ != FH_OK) {
+  // creation status and per-call status are separate: a transient error of one solve (device_rc_) must not disable the
+  // solver object for good, and a failed creation is not retried on every replan
+  if (create_failed_) return false;
+  if (ctx_) return true;
+  const int rc = fh_create(&ctx_, -1);
+  if (rc != FH_OK) {
+    create_failed_ = true;
+    device_rc_ = rc;
     device_err_ = ctx_ ? fh_last_error(ctx_) : "fh_create failed";
     std::fprintf(stderr, "SolverHip: %s\n", device_err_.c_str());
     return false;
   }
+  if (cb_.should_terminate_) fh_request_stop(ctx_);  // StopExecution() came before the first solve
   return true;
 }
 
@@ -58,12 +63,16 @@ void SolverHip::setXf(state& data) {
 
 void SolverHip::setPolytopes(std::vector<LinearConstraint3D> polytopes) { polytopes_ = polytopes; }
 
-void SolverHip::StopExecution() {
+void SolverHip::StopExecution() {  // may be called from another thread while genNewTraj() is inside the device launch
   cb_.should_terminate_ = true;
+  if (ctx_ && !create_failed_) fh_request_stop(ctx_);  // the kernels poll this word between branch-and-bound nodes
   std::printf("Activated flag to stop execution\n");
 }
 
-void SolverHip::ResetToNormalState() { cb_.should_terminate_ = false; }
+void SolverHip::ResetToNormalState() {
+  cb_.should_terminate_ = false;
+  if (ctx_ && !create_failed_) fh_clear_stop(ctx_);
+}
 
 void SolverHip::resetX() {  // solverGurobi.cpp:382-388
   int size = (int)((int)(N_)*dt_ / DC);
@@ -119,7 +128,7 @@ void SolverHip::absorb(const fh_result& r) {
 }
 
 int SolverHip::solveProblems(const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n, fh_result* results) {
-  if (!ensureContext()) return device_rc_ != FH_OK ? device_rc_ : FH_ERR_DEVICE;
+  if (!ensureContext()) return FH_ERR_DEVICE;
   // concurrent_factors_ <= 1: the sequential line search inside one wavefront; otherwise the same search, `width` factors at a time
   const int rc = fh_solve_batch_speculative(ctx_, problems, faces, n_faces, n, concurrent_factors_, results);
   if (rc != FH_OK) device_err_ = fh_last_error(ctx_);
@@ -128,7 +137,7 @@ int SolverHip::solveProblems(const fh_problem* problems, const fh_face* faces, i
 
 int SolverHip::sampleProblems(const fh_problem* problems, const fh_result* results, int n, int max_samples, fh_state* states,
                               int32_t* counts) {
-  if (!ensureContext()) return device_rc_ != FH_OK ? device_rc_ : FH_ERR_DEVICE;
+  if (!ensureContext()) return FH_ERR_DEVICE;
   const int rc = fh_sample_batch(ctx_, problems, results, n, max_samples, states, counts);
   if (rc != FH_OK) device_err_ = fh_last_error(ctx_);
   return rc;
@@ -141,7 +150,7 @@ bool SolverHip::genNewTraj() {  // solverGurobi.cpp:426-477 for one solver objec
   std::memset(&last_, 0, sizeof(last_));
   if (factor_initial_ < 1) std::printf("factor_initial_ is less than one, it doesn't make sense\n");  // :438-441
   if (cb_.should_terminate_) {  // the factor loop is not entered (:445); flag cleared at the end (:474)
-    cb_.should_terminate_ = false;
+    ResetToNormalState();
     return false;
   }
   if (polytopes_.size() > (size_t)FH_MAX_POLY) {
@@ -154,6 +163,7 @@ bool SolverHip::genNewTraj() {  // solverGurobi.cpp:426-477 for one solver objec
   fh_result r;
   device_rc_ = solveProblems(&pr, faces.empty() ? nullptr : faces.data(), (int64_t)faces.size(), 1, &r);
   runtime_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (cb_.should_terminate_) ResetToNormalState();  // a StopExecution() during the solve: `cb_.should_terminate_ = false` (:474)
   if (device_rc_ != FH_OK) {
     std::fprintf(stderr, "SolverHip::genNewTraj: device error %d: %s\n", device_rc_, device_err_.c_str());
     return false;
@@ -176,7 +186,7 @@ std::vector<bool> SolverHip::genNewTrajBatch(const std::vector<SolverHip*>& solv
     std::memset(&s->last_, 0, sizeof(s->last_));
     if (s->factor_initial_ < 1) std::printf("factor_initial_ is less than one, it doesn't make sense\n");  // :438-441
     if (s->cb_.should_terminate_) {  // the factor loop is not entered (:445); flag cleared at the end (:474)
-      s->cb_.should_terminate_ = false;
+      s->ResetToNormalState();
       continue;
     }
     if (s->polytopes_.size() > (size_t)FH_MAX_POLY) {
@@ -198,7 +208,7 @@ std::vector<bool> SolverHip::genNewTrajBatch(const std::vector<SolverHip*>& solv
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (size_t k = 0; k < who.size(); k++) {
     SolverHip* s = solvers[who[k]];
-    s->device_rc_ = rc;
+    s->device_rc_ = rc;  // per-call status only: the followers' own contexts are untouched
     s->runtime_ms_ = ms;
     if (rc != FH_OK) {
       s->device_err_ = lead->ctx_ ? fh_last_error(lead->ctx_) : "no context";

@@ -101,6 +101,7 @@ protected:
   int verbose_ = 0;
 
   fh_ctx* ctx_ = nullptr;
+  bool create_failed_ = false;  // fh_create failed once: every later call reports it without retrying
   fh_result last_;
   int device_rc_ = FH_OK;
   std::string device_err_;

@@ -35,7 +35,9 @@ enum {
   FH_ST_INFEASIBLE = 1,  /* every factor in the window was infeasible   (reference: genNewTraj()==false) */
   FH_ST_NODE_LIMIT = 2,  /* branch-and-bound node cap hit (treated as not solved)                    */
   FH_ST_ITER_LIMIT = 3,  /* active-set iteration cap hit  (treated as not solved, cf. GRB_NUMERIC)   */
-  FH_ST_BAD_INPUT = 4    /* sizes out of range / non-finite input                                    */
+  FH_ST_BAD_INPUT = 4,   /* sizes out of range / non-finite input                                    */
+  FH_ST_INTERRUPTED = 5  /* fh_request_stop() or the deadline ended the search (reference: GRB_INTERRUPTED after
+                            mycallback::abort(), solverGurobi.cpp:15-28, :643-646); treated as not solved */
 };
 
 /* return codes of the entry points */
@@ -84,7 +86,7 @@ typedef struct fh_result {
   int32_t status;    /* FH_ST_*                                                         */
   int32_t nodes;     /* branch-and-bound nodes evaluated over all trials (diagnostic)   */
   int32_t qp_iters;  /* active-set iterations over all trials (diagnostic)              */
-  int32_t reserved;
+  int32_t kflops;    /* FP64 flop estimate of the solve in thousands, saturating (diagnostic; DESIGN.md roofline) */
   double factor;     /* factor_that_worked_ (valid iff solved)                          */
   double dt;         /* dt_ of the last trial                                           */
   double cost;       /* objective: sum_t sum_axis (6 a)^2  (solverGurobi.cpp:113-119)   */
@@ -101,8 +103,19 @@ typedef struct fh_params {
   int32_t max_iters;  /* per QP active-set iteration cap              (default 2000)         */
   int32_t max_work;   /* per PROBLEM cap on active-set iterations over all trials and nodes; 0 = unlimited (default).
                          The reference sets no Gurobi TimeLimit; a real-time caller can bound the worst case here:
-                         a problem that exceeds it ends with FH_ST_ITER_LIMIT, solved = 0.                          */
-  int32_t reserved;
+                         a problem that exceeds it ends with FH_ST_ITER_LIMIT, solved = 0.  A work cap couples the
+                         nodes of a problem, so problems are then solved by one wavefront each (no work sharing).   */
+  int32_t share;      /* 1 (default): wavefronts that run out of problems take over untried subtrees of the branch-and-bound
+                         trees still being explored (Gurobi explores one tree with all its threads, Threads = 0,
+                         faster/param/faster.yaml:41); results are identical to share = 0 (one wavefront per problem);
+                         nodes / qp_iters / kflops then count the work actually done by all wavefronts.  max_nodes and
+                         max_iters apply per wavefront in a shared tree.                                              */
+  double mip_gap;     /* 0 (default): the exact optimum over all assignments.  > 0: a node is pruned when its lower bound is
+                         within this relative gap of the incumbent (Gurobi's MIPGap, default 1e-4, which the reference
+                         leaves untouched); the result may then depend on exploration order, so work sharing is off.   */
+  double deadline_ms; /* 0 (default): none.  > 0: wall-clock budget of a launch, measured on the device from the start of
+                         each workgroup; problems not finished by then end with FH_ST_INTERRUPTED (the replan period of
+                         the reference is 10 ms, faster/param/faster.yaml:5; Gurobi TimeLimit is not set there).         */
 } fh_params;
 
 /* One sample of fillX(): pos, vel, accel, jerk (faster_types.hpp:79-165 `state`, yaw/dyaw unused
@@ -121,8 +134,35 @@ void fh_destroy(fh_ctx* ctx);
 const char* fh_last_error(const fh_ctx* ctx);
 void fh_default_params(fh_params* p);
 int fh_set_params(fh_ctx* ctx, const fh_params* p);
-/* Kernels run on this stream (hipStream_t as void*); NULL => the context's own stream. */
+/* Kernels run on this stream (hipStream_t as void*); NULL => the context's own stream.
+ * A context owns ONE work queue, ticket counter and branch-and-bound workspace: at most one of its launches may be in
+ * flight at a time.  Launches issued through one context are ordered on its stream; switching streams synchronises with
+ * the previous one.  Use one context per concurrent pipeline (as bench.py does). */
 int fh_set_stream(fh_ctx* ctx, void* hip_stream);
+
+/* Cooperative cancellation (SolverGurobi::StopExecution / ResetToNormalState, solverGurobi.cpp:30-39; the reference polls
+ * its flag inside Gurobi callbacks, :15-28).  fh_request_stop() may be called from ANY thread while a launch of the context
+ * is running: it raises a word in mapped host memory that the workgroups poll between branch-and-bound nodes and when they
+ * draw a problem; problems not finished by then report FH_ST_INTERRUPTED, solved = 0.  The request stays raised (later
+ * launches return immediately with FH_ST_INTERRUPTED results) until fh_clear_stop(). */
+int fh_request_stop(fh_ctx* ctx);
+int fh_clear_stop(fh_ctx* ctx);
+
+/* Work-sharing statistics of the most recent solve launch of the context (synchronises with it): frames given to the queue,
+ * frames taken from it, donations refused because the queue / the record pool was full, workgroups launched.  Also the place
+ * where a failed launch (watchdog, protocol error) is reported: returns FH_ERR_DEVICE and poisons nothing — the next launch
+ * re-initialises the queue. */
+typedef struct fh_share_stats {
+  uint32_t donated, stolen, queue_full, records_full, records_used, error, interrupted, workgroups;
+} fh_share_stats;
+int fh_share_stats_read(fh_ctx* ctx, fh_share_stats* out);
+/* Diagnostic builds only (-DFH_SHARE_PROFILE, scripts/share_diag.py): 16 words of in-kernel timers of the last launch (100 MHz
+ * ticks / counts: look-around, donate, wait, frame copy, frame set-up, frame search, finish_part, idle tail).  All zero otherwise. */
+int fh_share_profile_read(fh_ctx* ctx, unsigned long long* out16);
+
+/* Measured FP64 vector-FMA peak of the device (independent v_fma_f64 chains, no memory traffic), in TFLOP/s — the
+ * denominator of the compute roofline.  Runs a ~10 ms kernel on the context stream and synchronises. */
+int fh_fp64_peak(fh_ctx* ctx, double* tflops);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 /* Batch of genNewTraj() calls, inputs/outputs in HOST memory (copies in/out, synchronous).
@@ -168,6 +208,12 @@ int fh_sample_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_r
  * d_faces).  Everything else in d_safe[i] (n_seg, bounds, dc, factor window, force_final_pos, xf) is left
  * as the caller prepared it.  Unsolved whole problems mark the safe problem with n_seg = 0 (skipped:
  * its result reports FH_ST_BAD_INPUT).  Device pointers, asynchronous on the context stream. */
+/* How the synthetic hand-off treats R (applies to fh_pair_glue_device and fh_solve_pairs_device of this context).
+ * r_margin < 0 (default): SURVEY.md 8(d) to the letter, as described above — R may end up outside its shrunk corridor (22 % of the
+ * C4 pairs: those safe problems are infeasible for every factor, which FASTER never poses).  r_margin >= 0: as in FASTER, where the
+ * safe corridor is decomposed around R (faster.cpp:475-499), the corridor starts at the first polytope of the whole corridor that
+ * contains R, and no face of that polytope is pulled closer to R than r_margin metres; the following polytopes are shrunk as before. */
+int fh_set_pair_margin(fh_ctx* ctx, double r_margin);
 int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results,
                         const fh_face* d_faces, int n, double r_frac, double shrink, int max_safe_poly,
                         fh_problem* d_safe, fh_face* d_safe_faces);
@@ -177,7 +223,7 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
  * cloud: per segment the rows [a | b] of its polytope (separating planes of the inflated obstacle points found by DecompUtil's
  * LineSegment3D::dilate, the 6 faces of the local bounding box, the ground plane -z <= -z_ground), oriented around the segment
  * midpoint.  cloud_xyz: [n_cloud][3]; segments: [n_segments][6] = p1, p2; faces: [n_segments][max_faces]; counts[i] = rows of
- * segment i, or -1 if it needs more than max_faces rows or has more than 1024 obstacle points inside its local box.
+ * segment i, or -1 if it needs more than max_faces rows or has more than 16384 obstacle points inside its local box.
  * local_bbox must be positive (FASTER uses (2, 2, 1)).  The host version copies in and out and synchronises. */
 int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_segments, int n_segments,
                               const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* d_faces,

@@ -584,7 +584,8 @@ static void bnb_node(bnb_ctx* B, int8_t* assign) {
   int me, mi;
   if (build_rows(M, assign, B->eq, &me, B->in, &mi)) return;
   double x[NV_MAX], cost;
-  int st = gi_solve(M->n, me, B->eq, mi, B->in, &M->par, B->best_cost, x, &cost, &B->iters);
+  /* mip_gap = 0 (default): exact.  > 0: Gurobi's MIPGap rule, a node within the relative gap of the incumbent is pruned */
+  int st = gi_solve(M->n, me, B->eq, mi, B->in, &M->par, B->best_cost * (1.0 - M->par.mip_gap), x, &cost, &B->iters);
   if (st == 3) {
     B->limit = FH_ST_ITER_LIMIT;
     return;
@@ -872,7 +873,9 @@ void orc_default_params(fh_params* p) {
   p->max_nodes = 100000;
   p->max_iters = 2000;
   p->max_work = 0;
-  p->reserved = 0;
+  p->share = 1;
+  p->mip_gap = 0.0;
+  p->deadline_ms = 0.0;
 }
 
 size_t orc_sizeof_problem(void) { return sizeof(fh_problem); }

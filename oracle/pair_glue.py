@@ -8,7 +8,8 @@ from faster_amd import abi
 from . import oracle
 
 
-def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_poly=3):
+def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_poly=3, r_margin=-1.0):
+    keep_r = r_margin >= 0
     safe = safe_templates.copy()
     sfaces = np.zeros_like(faces)
     for i in range(len(whole)):
@@ -28,8 +29,8 @@ def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_po
             f0, f1 = fb + pw["face_off"][p], fb + pw["face_off"][p + 1]
             A, b = faces["a"][f0:f1], faces["b"][f0:f1]
             nr = np.sqrt((A * A).sum(axis=1))
-            worst = np.max(A @ R["pos"] - (b - shrink * nr)) if f1 > f0 else -np.inf
-            if worst <= 0:
+            worst = np.max(A @ R["pos"] - (b - (0.0 if keep_r else shrink) * nr)) if f1 > f0 else -np.inf
+            if worst <= (1e-7 if keep_r else 0.0):
                 start, found = p, True
                 break
             if worst < best:
@@ -44,7 +45,11 @@ def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_po
             m = f1 - f0
             sfaces["a"][fb + o: fb + o + m] = faces["a"][f0:f1]
             nr = np.sqrt((faces["a"][f0:f1] ** 2).sum(axis=1))
-            sfaces["b"][fb + o: fb + o + m] = faces["b"][f0:f1] - shrink * nr
+            bb = faces["b"][f0:f1] - shrink * nr
+            if keep_r and p == 0:  # no face of the polytope that holds R is pulled closer to R than r_margin
+                ar = faces["a"][f0:f1] @ R["pos"]
+                bb = np.maximum(bb, np.maximum(np.minimum(faces["b"][f0:f1], ar + r_margin * nr), ar + 1e-6 * nr))
+            sfaces["b"][fb + o: fb + o + m] = bb
             o += m
             off.append(o)
         off += [o] * (abi.FH_MAX_POLY + 1 - len(off))
