@@ -87,7 +87,7 @@ __global__ void share_init_kernel(fh::ShareCtl* ctl, unsigned long long* seqs) {
 
 // One solve launch: NSEG selects the kernel instantiation, PAIRS the whole -> hand-off -> safe unit.
 template <int NSEG, bool PAIRS>
-static int launch_solve(fh_ctx* ctx, fh::SolveArgs ka) {
+static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, fh_result* d_results, fh::SolveArgs ka) {
   using SV = fh::Solver<NSEG>;
   const int n = ka.n;
   size_t lds = SV::lds_bytes(ka.max_faces);
@@ -116,7 +116,10 @@ static int launch_solve(fh_ctx* ctx, fh::SolveArgs ka) {
   sa.deadline_ticks = ctx->par.deadline_ms > 0 ? (unsigned long long)(ctx->par.deadline_ms * 1e5) : 0ull;  // 100 MHz clock
   sa.enabled = share && grid > 1 ? 1 : 0;
   sa.total_units = n;
-  sa.max_hungry = 2 * ctx->n_cu;  // two pollers per CU: enough hands for the tail, little traffic on the control line
+  // Waiting workgroups.  Measured on C4 (32768 pairs per launch): 16 of them shorten a launch as much as 64 or 512 do (the tail is
+  // bound by its critical path — the sequential factor trials of the hardest problem — not by hands), and every waiter holds
+  // LDS that another launch of the same device could use (12 launches in flight: 7.4 M pairs/s with 16, 7.0 M with 64, 5.9 M with 256).
+  sa.max_hungry = std::max(8, ctx->n_cu / 16);
   sa.min_nodes = 16;
   if (const char* mh = getenv("FH_DEBUG_MAX_HUNGRY")) sa.max_hungry = atoi(mh);  // experiments only
   if (const char* mn = getenv("FH_DEBUG_MIN_NODES")) sa.min_nodes = atoi(mn);
@@ -142,7 +145,7 @@ static int launch_solve(fh_ctx* ctx, fh::SolveArgs ka) {
   FH_HIP(hipGetLastError());
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, ka);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, d_results, ka);
   FH_HIP(hipGetLastError());
   FH_HIP(hipEventRecord(e1, ctx->stream));
   ctx->ev_used += 2;
@@ -354,10 +357,10 @@ int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_fa
   max_faces = (max_faces + 7) & ~7;
   fh::SolveArgs ka;
   std::memset(&ka, 0, sizeof(ka));
-  ka.problems = d_problems; ka.faces = d_faces; ka.results = d_results; ka.n = n; ka.max_faces = max_faces;
-  if (max_seg <= 6) return launch_solve<6, false>(ctx, ka);
-  if (max_seg <= 10) return launch_solve<10, false>(ctx, ka);
-  return launch_solve<FH_MAX_SEG, false>(ctx, ka);
+  ka.n = n; ka.max_faces = max_faces;
+  if (max_seg <= 6) return launch_solve<6, false>(ctx, d_problems, d_faces, d_results, ka);
+  if (max_seg <= 10) return launch_solve<10, false>(ctx, d_problems, d_faces, d_results, ka);
+  return launch_solve<FH_MAX_SEG, false>(ctx, d_problems, d_faces, d_results, ka);
 }
 
 int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,
@@ -543,12 +546,12 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   max_faces = (max_faces + 7) & ~7;
   fh::SolveArgs ka;
   std::memset(&ka, 0, sizeof(ka));
-  ka.problems = d_whole; ka.faces = d_faces; ka.results = d_whole_results; ka.n = n; ka.max_faces = max_faces;
+  ka.n = n; ka.max_faces = max_faces;
   ka.safe = d_safe; ka.sfaces = d_safe_faces; ka.sres = d_safe_results;
   ka.r_frac = r_frac; ka.shrink = shrink; ka.max_safe_poly = max_safe_poly; ka.r_margin = ctx->pair_margin;
-  if (max_seg <= 6) return launch_solve<6, true>(ctx, ka);
-  if (max_seg <= 10) return launch_solve<10, true>(ctx, ka);
-  return launch_solve<FH_MAX_SEG, true>(ctx, ka);
+  if (max_seg <= 6) return launch_solve<6, true>(ctx, d_whole, d_faces, d_whole_results, ka);
+  if (max_seg <= 10) return launch_solve<10, true>(ctx, d_whole, d_faces, d_whole_results, ka);
+  return launch_solve<FH_MAX_SEG, true>(ctx, d_whole, d_faces, d_whole_results, ka);
 }
 
 int fh_timing_reset(fh_ctx* ctx) {

@@ -44,9 +44,10 @@ namespace fh {
 struct ShareCtl {
   // ---- line 0: polled by hungry workers; zeroed before every launch ----
   unsigned int done;         // units (problems, or pairs) whose final result has been written
-  unsigned int error;        // != 0: protocol failure / watchdog, everybody leaves
-  unsigned int interrupted;  // a worker has seen the host's abort word / the deadline (sticky)
-  unsigned int pad0[13];
+  unsigned int pad00;
+  unsigned int error;        // != 0: protocol failure / watchdog, everybody leaves        } one aligned 8-byte pair: the busy
+  unsigned int interrupted;  // a worker has seen the host's abort word / the deadline    } workers read both with one load
+  unsigned int pad0[12];
   // ---- line 1: zeroed before every launch ----
   unsigned long long ticket;  // next fresh unit
   unsigned int rec_next;      // share records handed out
@@ -54,9 +55,9 @@ struct ShareCtl {
   unsigned int pad1[7];
   // ---- line 2: the hand-off counters (zeroed before every launch; written only when a worker runs out of problems or a frame
   // is published, read by the busy workers every few nodes) ----
-  unsigned long long wait_ticket;  // wait tickets drawn: takers committed to frame numbers 0 .. wait_ticket-1
-  unsigned long long q_tail;       // frames published (or being published): always <= wait_ticket
-  unsigned long long pad2[6];
+  unsigned int wait_ticket;  // wait tickets drawn: takers committed to frame numbers 0 .. wait_ticket-1   } one aligned 8-byte
+  unsigned int q_tail;       // frames published (or being published): always <= wait_ticket            } pair, read with one load
+  unsigned long long pad2[7];
   // ---- line 3: -DFH_SHARE_PROFILE builds only: 100 MHz ticks spent in / number of [0,1] look_around, [2,3] donate,
   // [4,5] waiting for a frame (successful waits), [6,7] copying a frame out of its slot ----
   unsigned long long prof[8];
@@ -156,11 +157,12 @@ __device__ __forceinline__ unsigned long long wall_ticks() { return __builtin_am
 // another donor took the number (when the fresh problems run out, every busy workgroup sees the new takers at its next
 // look-around: a retry loop here made ~2000 donors hammer q_tail for 512 numbers, 600 us per donation).
 __device__ inline unsigned long long q_reserve(const ShareArgs& sa) {
-  const unsigned long long pos = ald(&sa.ctl->q_tail);
-  if (pos >= ald(&sa.ctl->wait_ticket)) return ~0ull;              // nobody is waiting for frame `pos`
-  if (ald(&sa.seqs[pos & (FH_QCAP - 1)]) != pos) return ~0ull;     // slot not released yet (ring full) or the number is gone
-  unsigned long long expect = pos;
-  if (__hip_atomic_compare_exchange_strong(&sa.ctl->q_tail, &expect, pos + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) return pos;
+  const unsigned long long both = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
+  const unsigned int waiters = (unsigned int)both, pos = (unsigned int)(both >> 32);
+  if (pos >= waiters) return ~0ull;                                                   // nobody is waiting for frame `pos`
+  if (ald(&sa.seqs[pos & (FH_QCAP - 1)]) != (unsigned long long)pos) return ~0ull;    // slot not released yet (ring full) or the number is gone
+  unsigned int expect = pos;
+  if (__hip_atomic_compare_exchange_strong(&sa.ctl->q_tail, &expect, pos + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) return pos;
   return ~0ull;
 }
 // after the payload has been written and drained

@@ -258,7 +258,8 @@ __device__ inline double min_pos_root_quad(double c2, double c1, double c0) {
   }
   return best;
 }
-__device__ inline double dt_initial(const fh_problem& pr) {
+template <class PR>
+__device__ inline double dt_initial(const PR& pr) {
   float mx = 0.f;
   for (int i = 0; i < 3; i++) {
     const double dx = pr.xf[i] - pr.x0[i];
@@ -439,7 +440,8 @@ struct Solver {
   }
 
   // ---- per trial: jerk-free states and row-norm table for step h ----
-  __device__ void setup_trial(const fh_problem& pr) {
+  template <class PR>
+  __device__ void setup_trial(const PR& pr) {
     {  // zero-jerk propagation of x0 to the start of segment tt = lane / 3 (same recurrence, step by step, as the oracle)
       const int tt = lane / 3, i = lane - 3 * tt;
       const bool on = lane < 3 * NT;
@@ -995,19 +997,23 @@ struct Solver {
   __device__ int qp_run(double ub, bool tie, int max_iters, int& iters, double& cost) {
     int it = 0;
     bind_assignment();
+    const int q0 = q;
     const int st = qp_loop(ub, tie, max_iters, it, cost);
     iters += it;
+    // FP64 flop estimate of this active-set run (useful lanes only; reported as fh_result.kflops), once per node so that the
+    // iteration loop carries no bookkeeping (counting per iteration cost 3 % of the throughput).  Per outer iteration (at most
+    // it + 1 of them): states / control points (3(N+1) lanes x (5N + 9), 4N lanes x 12), the row scan (3N x 6 box rows, 7 per
+    // corridor row and control point) and the row normal (4n).  Per inner iteration, with the mean number of active rows
+    // qa = (q_before + q_after) / 2: the two Gram-Schmidt sweeps (4 n qa; a re-orthogonalisation is not counted), the
+    // back-substitution (qa^2 - qe^2), the step (3n + 4 qa) and the update of the factors (n + qa).
+    const int qa = (q0 + q) >> 1;
+    flops += (unsigned long long)(unsigned)(it + 1) * (unsigned)(3 * (N + 1) * (5 * N + 9) + 48 * N + 18 * N + 7 * rows4 + 4 * n) +
+             (unsigned long long)(unsigned)it * (unsigned)(4 * n * qa + qa * qa - qe * qe + 4 * n + 5 * qa);
     return st;
   }
-  // FP64 flop estimate (useful lanes only; reported as fh_result.kflops): per outer iteration the states / control points
-  // (3(N+1) lanes x 5N + 9, 4N lanes x 12), the row scan (3N x 6 box, 7 per corridor row and control point) and the row
-  // normal (4n); per inner iteration the two Gram-Schmidt sweeps (4nq, twice when re-orthogonalised: counted once), the
-  // back-substitution (q^2 - qe^2), the step (3n + 4q) and the rank-one update of the factors (n + q).
   __device__ int qp_loop(double ub, bool tie, int max_iters, int& it, double& cost) {
-    const unsigned fl_outer = (unsigned)(3 * (N + 1) * (5 * N + 9) + 48 * N + 18 * N + 7 * rows4 + 4 * n);
     for (;;) {
       { FH_T0(); compute_states(); FH_T1(2); }
-      flops += fl_outer;
       int id;
       double vp;
       {
@@ -1032,7 +1038,6 @@ struct Solver {
       double up = 0;
       for (;;) {  // until row `id` is active
         if (++it > max_iters) return 3;
-        flops += (unsigned)(4 * n * q + q * q - qe * qe + 4 * n + 5 * q);
         double dc, zi, zz, rc;
         { FH_T0(); zz = project(gg, dc, zi); FH_T1(5); }
         FH_T0();
@@ -1059,7 +1064,6 @@ struct Solver {
           break;
         }
         FH_SYNC();
-        flops += (unsigned)(6 * (n + q) * (q - 1 - kb));
         { FH_T0(); drop_row(kb); FH_T1(8); }
       }
     }
@@ -1075,7 +1079,8 @@ struct Solver {
   // ---- exact screening on jerk-independent indicator rows (same rule as the oracle's screen_constant_rows):
   // control points 0..2 of segment 0 depend on x0 and h only; with the final position forced, control points
   // 1..3 of the last segment depend on xf and h only.  One lane per polytope. ----
-  __device__ void screen_constant_rows(const fh_problem& pr) {
+  template <class PR>
+  __device__ void screen_constant_rows(const PR& pr) {
     allowed_first = allowed_last = 0xffffffffu;
     if (P == 0) return;
     // one lane per face row (all polytopes side by side), six wave-uniform points per row; a violated row marks its polytope
@@ -1112,7 +1117,8 @@ struct Solver {
   }
 
   // ---- leaf test / branching choice for the node just solved. returns branch segment or -1 (leaf) ----
-  __device__ int analyze(const fh_problem& pr) {
+  template <class PR>
+  __device__ int analyze(const PR& pr) {
     if (P == 0) {
       if (lane < N) fullassign[lane] = -1;
       FH_SYNC();
@@ -1250,12 +1256,15 @@ struct Solver {
     int flags = 0;
     if (lane == 0) {
       const unsigned long long t_start = ((unsigned long long)(unsigned)tb[TB_T0 + 1] << 32) | (unsigned)tb[TB_T0];
-      const unsigned int err = ald(&sa.ctl->error), intr = ald(&sa.ctl->interrupted);
-      const unsigned long long tail = ald(&sa.ctl->q_tail), waiters = ald(&sa.ctl->wait_ticket);
-      unsigned int stop = err | intr;
+      // two 8-byte loads: {error, interrupted} and {wait_ticket, q_tail}
+      const unsigned long long ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
+      const unsigned long long wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
+      const unsigned int waiters = (unsigned int)wt, tail = (unsigned int)(wt >> 32);
+      unsigned int stop = (unsigned int)ei | (unsigned int)(ei >> 32);
       if (!stop) {
         if (sa.deadline_ticks && wall_ticks() - t_start > sa.deadline_ticks) stop = 2u;
-        else if (sa.host_abort && __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stop = 1u;
+        else if (sa.host_abort && (blockIdx.x & 31u) == 0u &&  // one workgroup in 32 reads the host's word (a PCIe round trip),
+                 __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stop = 1u;  // everybody reads ctl->interrupted
         if (stop) ast(&sa.ctl->interrupted, stop);
       }
       if (stop) flags = 1;
@@ -1365,9 +1374,10 @@ struct Solver {
     unsigned long long pos = ~0ull;
     int state = 0;  // 1: got a frame, 2: leave
     if (lane == 0) {
-      const unsigned long long waiters = ald(&sa.ctl->wait_ticket), tail = ald(&sa.ctl->q_tail);
-      if (waiters >= tail + (unsigned long long)sa.max_hungry) state = 2;  // enough idle hands already (no ticket drawn: free to go)
-      else pos = aadd(&sa.ctl->wait_ticket, 1ull);                         // committed to frame number `pos` from here on
+      const unsigned long long wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
+      const unsigned int waiters = (unsigned int)wt, tail = (unsigned int)(wt >> 32);
+      if (waiters >= tail + (unsigned int)sa.max_hungry) state = 2;  // enough idle hands already (no ticket drawn: free to go)
+      else pos = (unsigned long long)aadd(&sa.ctl->wait_ticket, 1u);    // committed to frame number `pos` from here on
     }
     state = uniform_i32(state);
     if (state == 2) return false;
@@ -1378,6 +1388,9 @@ struct Solver {
         if (q_arrived(sa, pos)) state = 1;
         else if ((round & 7u) == 7u) {
           const unsigned int done = ald(&sa.ctl->done), err = ald(&sa.ctl->error);
+          if (!err && !ald(&sa.ctl->interrupted) && sa.host_abort && (blockIdx.x & 31u) == 0u &&
+              __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+            ast(&sa.ctl->interrupted, 1u);  // (an idle workgroup relays the host's stop request to the busy ones)
           if (err || done >= (unsigned)sa.total_units) state = 2;  // no frame will be published any more
           else if (wall_ticks() - t0 > FH_WATCHDOG_TICKS) { ast(&sa.ctl->error, 4u); state = 2; }
         }
@@ -1436,7 +1449,8 @@ struct Solver {
   }
 
   // The frame taken from the queue (stack level 0, tb[]) becomes current: problem staged, trial set up for its step.
-  __device__ void install_frame(const fh_problem& pr, const ShareArgs& sa, double& best_cost) {
+  template <class PR>
+  __device__ void install_frame(const PR& pr, const ShareArgs& sa, double& best_cost) {
     screen_constant_rows(pr);  // allowed_first / allowed_last of this trial
     qe = uniform_i32(tb[TB_QE]);
     q = 0;  // (LDS factors are all zero after init_problem: nothing to clear when the snapshot is restored)
@@ -1516,7 +1530,8 @@ struct Solver {
 
   // ---- MIQP for one dt: depth-first branch and bound.  entry 0: from the root; entry 1: from the frame installed as
   // stack level 0 (install_frame).  returns FH_ST_* (OPTIMAL / INFEASIBLE refer to what THIS worker saw) ----
-  __device__ int search(const fh_problem& pr, const fh_params& par, const ShareArgs& sa, double* __restrict__ ws, int entry,
+  template <class PR>
+  __device__ int search(const PR& pr, const fh_params& par, const ShareArgs& sa, double* __restrict__ ws, int entry,
                         double& best_cost, int& nodes, int& iters) {
     int depth = 0;
     int status_limit = 0;
@@ -1596,12 +1611,17 @@ struct Solver {
       if (local_nodes >= par.max_nodes) { status_limit = FH_ST_NODE_LIMIT; break; }
       if (par.max_work > 0 && iters >= par.max_work) { status_limit = FH_ST_ITER_LIMIT; break; }
       local_nodes++;
-      if ((local_nodes & (FH_LOOK_EVERY - 1)) == 0) {
-        const int fl = look_around(sa);
+      // a tree that is already shared looks around twice as often, and a taker looks before its first node (it hands the other
+      // children of its frame on at once if more takers are waiting)
+      if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (entry == 1 && local_nodes == 1)) {
+        int fl = look_around(sa);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }
         // somebody is out of work: a problem that has proved hard (it already has a share record, or sa.min_nodes nodes so far)
-        // gives its shallowest open frame away.  (sa.enabled is 0 with a work cap or a MIP gap.)
-        if ((fl & 2) && depth > 0 && (rec >= 0 || nodes + local_nodes >= sa.min_nodes)) donate(sa, ws, depth, best_cost);
+        // gives its shallowest open frames away (at most two per look).  (sa.enabled is 0 with a work cap or a MIP gap.)
+        if ((fl & 2) && depth > 0 && (rec >= 0 || nodes + local_nodes >= sa.min_nodes)) {
+          donate(sa, ws, depth, best_cost);
+          if (rec >= 0 && (look_around(sa) & 2)) donate(sa, ws, depth, best_cost);
+        }
       }
       if (rec >= 0) {  // shared tree: other workers' leaves prune here too
         const double gc = uniform_f64(bits_f64(ald(&(sa.recs + rec)->inc_cost)));
@@ -1652,7 +1672,8 @@ struct Solver {
   }
 };
 
-__device__ inline bool bad_input(const fh_problem& pr, int nseg_cap, int face_cap) {
+template <class PR>
+__device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
   if (pr.n_seg < 1 || pr.n_seg > nseg_cap || pr.n_poly < 0 || pr.n_poly > FH_MAX_POLY) return true;
   if (pr.face_off[0] != 0 || pr.face_begin < 0) return true;
   for (int p = 0; p < pr.n_poly; p++) {
@@ -1676,8 +1697,8 @@ __device__ inline bool bad_input(const fh_problem& pr, int nseg_cap, int face_ca
 // One problem (= one genNewTraj call), from the root of its first trial (entry 0) or from a frame of one of its trees taken
 // from the queue (entry 1), until its final result is written (returns true) or until the tree this worker contributed to is
 // still being explored elsewhere (returns false: the worker that finishes the last part continues the problem).
-template <int NSEG>
-__device__ bool run_problem(Solver<NSEG>& sv, const fh_problem& pr, const fh_face* __restrict__ gfaces, int max_faces,
+template <int NSEG, class PR>
+__device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
                             const fh_params& par, const ShareArgs& sa, double* __restrict__ ws, int entry, bool interrupted,
                             fh_result& res) {
   const int lane = sv.lane;
@@ -1843,10 +1864,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const fh_problem& pr, const fh_fac
   return true;
 }
 
-struct SolveArgs {
-  const fh_problem* problems;  // whole problems of a pair launch
-  const fh_face* faces;
-  fh_result* results;
+struct SolveArgs {  // (the problem / face / result arrays are separate `__restrict__` kernel parameters: scalar loads)
   int n, max_faces;
   fh_params par;
   double* workspace;
@@ -1869,7 +1887,8 @@ struct SolveArgs {
 // for the stragglers of a batch-wide whole launch before the safe solves start.  The safe problem record and its face rows are
 // written and read back through L2 inside the launch (possibly by another workgroup): agent-scope fences order the two.
 template <int NSEG, bool PAIRS>
-__global__ void __launch_bounds__(64, 2) solve_kernel(SolveArgs ka) {
+__global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
+                                                   fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Solver<NSEG> sv;
   sv.carve(smem, ka.max_faces);
@@ -1880,7 +1899,6 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(SolveArgs ka) {
   double* ws = ka.workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   if (threadIdx.x == 0) sv.tb_put64(sv.TB_T0, wall_ticks());
   bool tickets_left = true;
-  unsigned draws = 0;
 #ifdef FH_SHARE_PROFILE
   unsigned long long sp_dry__ = 0;
 #endif
@@ -1891,15 +1909,17 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(SolveArgs ka) {
       unsigned int b = 0, intr = 0;
       if (threadIdx.x == 0) {
         b = (unsigned int)min(aadd(&sa.ctl->ticket, 1ull), (unsigned long long)ka.n);
-        intr = ald(&sa.ctl->interrupted) | ald(&sa.ctl->error);
-        if (!intr && b < (unsigned)ka.n) {  // the host's stop word costs a PCIe read: every 8th draw
+        {
+          const unsigned long long ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
+          intr = (unsigned int)ei | (unsigned int)(ei >> 32);
+        }
+        if (!intr && b < (unsigned)ka.n) {  // the host's stop word costs a PCIe read: one workgroup in 32 polls it, with every draw
           const unsigned long long t_start = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
           if (sa.deadline_ticks && wall_ticks() - t_start > sa.deadline_ticks) intr = 2u;
-          else if (sa.host_abort && (draws & 7u) == 0u && __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) intr = 1u;
+          else if (sa.host_abort && (blockIdx.x & 31u) == 0u && __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) intr = 1u;
           if (intr) ast(&sa.ctl->interrupted, intr);
         }
       }
-      draws++;
       b = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
       interrupted = __builtin_amdgcn_readfirstlane((int)intr) != 0;
       if (b >= (unsigned int)ka.n) {
@@ -1919,21 +1939,33 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(SolveArgs ka) {
       unit = uniform_i32(sv.tb[sv.TB_B]);
       phase = uniform_i32(sv.tb[sv.TB_PHASE]);
     }
+    // (wave-uniform by construction; said explicitly because the divergence analysis loses it across this loop nest and would keep
+    // these — and every address derived from them — in vector registers)
+    entry = uniform_i32(entry);
+    unit = uniform_i32(unit);
+    phase = uniform_i32(phase);
+    interrupted = uniform_i32(interrupted ? 1 : 0) != 0;
     for (;;) {  // the problems of the unit (a pair has two)
       bool finished;
       if constexpr (PAIRS) {
-        const fh_problem* pr = phase ? &ka.safe[unit] : &ka.problems[unit];
-        const fh_face* fcs = phase ? ka.sfaces : ka.faces;
-        fh_result* out = phase ? &ka.sres[unit] : &ka.results[unit];
-        finished = run_problem<NSEG>(sv, *pr, fcs, ka.max_faces, ka.par, sa, ws, entry, interrupted, *out);
+        const fh_problem* pr = phase ? &ka.safe[unit] : &problems[unit];
+        const fh_face* fcs = phase ? ka.sfaces : faces;
+        fh_result* out = phase ? &ka.sres[unit] : &results[unit];
+        finished = run_problem<NSEG, fh_problem>(sv, *pr, fcs, ka.max_faces, ka.par, sa, ws, entry, interrupted, *out);
       } else {
-        finished = run_problem<NSEG>(sv, ka.problems[unit], ka.faces, ka.max_faces, ka.par, sa, ws, entry, interrupted, ka.results[unit]);
+        // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
+        // the uniform loads on the scalar unit (s_load) although the kernel contains fences and atomics, after which the
+        // compiler no longer treats `const __restrict__` global memory as unclobbered (132 vector loads instead of 28 scalar ones).
+        typedef const __attribute__((address_space(4))) fh_problem const_problem;
+        const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(problems + unit));  // (provably wave-uniform)
+        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ws, entry, interrupted,
+                                                    results[unit]);
       }
       if (!finished) break;  // the unit continues in another workgroup
       if constexpr (PAIRS) {
         if (phase == 0) {
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-          pair_glue_one(ka.problems[unit], ka.results[unit], ka.faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.safe[unit],
+          pair_glue_one(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.safe[unit],
                         ka.sfaces, (int)threadIdx.x);
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
           phase = 1;

@@ -15,6 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 PMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 REPS = 4
+MARGIN = float(os.environ.get("PAIR_MARGIN", "-1"))
 whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=N, p_choices=tuple(range(2, PMAX + 1)))
 safe_t = corridor.safe_templates(whole)
 mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
@@ -48,6 +49,7 @@ for mode in ("share0", "share1"):
     par = abi.default_params()
     par["share"] = 0 if mode == "share0" else 1
     ctx.set_params(par)
+    ctx.set_pair_margin(MARGIN)
     d_safe = to_dev(safe_t)
     d_sf = torch.zeros_like(d_faces)
     d_wr = torch.zeros(B * RES, dtype=torch.uint8, device=dev)
@@ -78,6 +80,8 @@ for mode in ("share0", "share1"):
                                                    us(pf[12], pf[13]) + us(pf[14], pf[15])))
     for name, r in (("whole", wr), ("safe", sr)):
         it = r["qp_iters"].astype(np.float64)
+        top = np.argsort(-it)[:6]
+        print("   %s hardest: %s" % (name, ", ".join("it %d nodes %d trials %d solved %d" % (r["qp_iters"][i], r["nodes"][i], r["trials"][i], r["solved"][i]) for i in top)))
         print("   %s: solved %.4f iters mean %.1f p99 %.0f p99.9 %.0f max %.0f | nodes mean %.2f max %d | trials mean %.2f | kflops mean %.1f" % (
             name, r["solved"].mean(), it.mean(), np.percentile(it, 99), np.percentile(it, 99.9), it.max(), r["nodes"].mean(), r["nodes"].max(),
             r["trials"].mean(), r["kflops"].mean()))

@@ -551,7 +551,13 @@ def test_fused_pair_kernel_equals_three_launches(ctx):
         ctx.sync()
         outs.append((d_wr.cpu().numpy().copy(), d_safe.cpu().numpy().copy(), d_sf.cpu().numpy().copy(), d_sr.cpu().numpy().copy()))
     for a, b, name in zip(outs[0], outs[1], ("whole results", "safe problems", "safe faces", "safe results")):
-        assert np.array_equal(a, b), name
+        if name.endswith("results"):  # (the work counters depend on which wavefronts shared a tree)
+            ra, rb = a.view(abi.result_dtype), b.view(abi.result_dtype)
+            for f in abi.result_dtype.names:
+                if f not in ("nodes", "qp_iters", "kflops"):
+                    assert np.array_equal(ra[f], rb[f]), (name, f)
+        else:
+            assert np.array_equal(a, b), name
     sres = outs[1][3].view(abi.result_dtype)
     assert (sres["solved"] == 1).sum() > B // 2 and (outs[1][1].view(abi.problem_dtype)["n_seg"][:16] == 0).all()
 
