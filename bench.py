@@ -3,13 +3,23 @@
 
 One "step" = one pass of the hot path over one batch of synthetic corridor problems:
     whole-trajectory solve (genNewTraj, N=10, <=6 polytopes)  ->  device-side whole->safe hand-off
-    (R = mid sample of the whole trajectory, safe corridor = <=3 shrunk polytopes)  ->  safe-trajectory solve.
-Inputs are resident in HBM before the timed region.  Each rank owns its own batch (independent problems,
-weak scaling, no data-path collective); with N>1 ranks the per-pair result summaries are all-gathered over
-RCCL after each step (the "batch gather" of SURVEY.md §8(e)).
+    (R = mid sample of the whole trajectory, safe corridor = <=3 polytopes around R)  ->  safe-trajectory solve.
+Inputs are resident in HBM before the timed region.
+
+Multi-GPU (one process per GPU, torch.distributed over RCCL):
+  --scaling weak   (default) every rank owns its own batch of --pairs pairs; after each step the complete fh_result blocks of
+                   all ranks are gathered on rank 0 (RCCL send/recv over xGMI);
+  --scaling strong ONE batch of --pairs pairs (BASELINE config 4: 32768) is sharded over the ranks in contiguous blocks
+                   (faster_amd/shard.py) and the complete fh_result blocks are all-gathered, so every rank ends a step with
+                   the results of the whole batch.
+There is no data-path collective inside a step: problems are independent and a pair never leaves its GPU.
 
 Usage (driver contract):  python bench.py --gpus N --steps K --warmup W
 N>1 is launched by torch.distributed.run (one rank per GPU).  Prints ONE JSON line on rank 0.
+
+Besides the timed region (K steps, `--inflight` independent pipelines) the N=1 run measures, outside the timed region:
+a single batch alone on the GPU (`roofline.solo`: no overlap between launches), the PCIe-inclusive host-pointer path
+(`e2e_with_copies`), the FP64 flop rate against the measured FP64 FMA peak (`roofline.compute`) and the CPU baseline.
 """
 import argparse
 import json
@@ -24,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; 6.29e12 measured copy)
+FP64_VECTOR_SPEC_TFLOPS = 78.6  # AMD datasheet; the measured FMA peak is what `roofline.compute` divides by
 
 
 def algorithmic_bytes(problems, n_seg_out):
@@ -35,7 +46,7 @@ def algorithmic_bytes(problems, n_seg_out):
     return reads + writes
 
 
-def measured_traffic():
+def measured_traffic(kernel_prefix):
     """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
     in separate runs by scripts/profile_round.sh, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes)."""
     import glob
@@ -43,27 +54,32 @@ def measured_traffic():
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
         try:
-            t = json.load(open(f)).get("_hbm_traffic_per_launch_bytes")
+            d = json.load(open(f))
+            t = d.get("_hbm_traffic_per_launch_bytes")
+            k = d.get("_kernel", "")
         except Exception:
             t = None
-        if t:
+        if t and (not k or k.startswith(kernel_prefix)):
             best = (t["total"], os.path.basename(f))
     return best
 
 
-def measured_valu_insts():
-    """VALU wave-instructions per launch of solve_kernel<10> from the committed SQ_INSTS_VALU pass (profiles/r*_pmc_summary.json)."""
-    import glob
-
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by a cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
         try:
-            v = json.load(open(f))["fh::solve_kernel<10>"]["SQ_INSTS_VALU"]["mean_per_dispatch"]
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, q // p))
         except Exception:
-            v = None
-        if v:
-            best = float(v)
-    return best
+            pass
+    return n
 
 
 def main():
@@ -71,20 +87,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96, help="timed steps (the end of the timed region drains the pipelines: a longer region is closer to the steady state)")
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--pairs", type=int, default=32768, help="whole+safe pairs per rank per step (C4: 32768)")
+    ap.add_argument("--pairs", type=int, default=32768, help="whole+safe pairs per step: per rank (weak scaling) or in total (strong); C4: 32768")
     ap.add_argument("--n-seg", type=int, default=10)
     ap.add_argument("--max-poly", type=int, default=6)
     ap.add_argument("--min-poly", type=int, default=2)
     ap.add_argument("--workload", choices=["c4", "c5"], default="c4",
                     help="c4 (default, the metric's configuration): synthetic corridors; c5: Monte-Carlo forest, corridors from the "
                          "voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes (BASELINE config 5)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--r-margin", type=float, default=0.05,
+                    help="hand-off keeps R at least this far inside its safe corridor (FASTER decomposes the safe corridor around R); "
+                         "negative: SURVEY.md 8(d) to the letter (R may fall outside the shrunk corridor)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pipeline", choices=["fused", "split"], default="split",
-                    help="split: whole launch -> hand-off launch -> safe launch; fused: one launch, each wavefront takes a pair through "
-                         "whole solve, hand-off and safe solve (same results)")
-    ap.add_argument("--inflight", type=int, default=12,
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the timed region (solo launch, copies, flop rate)")
+    ap.add_argument("--pipeline", choices=["fused", "split"], default="fused",
+                    help="fused: one launch per step, each unit of work is a pair taken through whole solve, hand-off and safe solve; "
+                         "split: whole launch -> hand-off launch -> safe launch (same results)")
+    ap.add_argument("--inflight", type=int, default=4,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
+    ap.add_argument("--no-share", action="store_true", help="one wavefront per problem (fh_params.share = 0)")
     args = ap.parse_args()
 
     # more hardware queues than the HIP default (4) so that the in-flight pipelines really run concurrently
@@ -109,53 +131,71 @@ def main():
 
     from faster_amd import abi, capi, corridor, shard
 
-    B, N = args.pairs, args.n_seg
+    N = args.n_seg
+    strong = args.scaling == "strong" and world > 1
+    seed = 3 if strong else 3 + 1000 * rank
     if args.workload == "c5":
         from faster_amd import build as fb, frontend
 
         fb.build_frontend()
         N = args.n_seg = 15
         args.max_poly = 8
-        whole, faces, finfo = frontend.forest_batch(B, seed=5 + 1000 * rank, n_seg=N, max_poly=8)
-        B = len(whole)  # pairs without a path are dropped
+        whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8)
     else:
-        whole, faces, _ = corridor.whole_batch(B, seed=3 + 1000 * rank, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
+        whole, faces, _ = corridor.whole_batch(args.pairs, seed=seed, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
+    total_pairs = len(whole)  # (c5: pairs without a path are dropped)
+    if strong:  # one batch for the whole job: this rank's contiguous block of it
+        whole, faces = shard.shard_batch(whole, faces, rank, world)
+    B = len(whole)
+    per_rank = -(-total_pairs // world) if strong else B
     safe_t = corridor.safe_templates(whole)
-    max_faces = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    max_faces = int(whole["face_off"][np.arange(B), whole["n_poly"]].max()) if B else 8
+    if world > 1:  # one kernel instantiation / LDS carve on every rank
+        mf = torch.tensor([max_faces], device=dev)
+        dist.all_reduce(mf, op=dist.ReduceOp.MAX)
+        max_faces = int(mf.item())
 
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
     d_whole, d_faces = to_dev(whole), to_dev(faces)
     RES = abi.result_dtype.itemsize
-    res_words = RES // 8
+    par = abi.default_params()
+    if args.no_share:
+        par["share"] = 0
 
     # `--inflight` independent pipelines, each with its own solver context, HIP stream and output buffers: step i runs on
-    # pipeline i % inflight, so the straggler problems of one step (a single hard MIQP can take milliseconds) overlap the
-    # bulk of the next step instead of idling the GPU.  Every step still does the complete work on the complete batch.
+    # pipeline i % inflight, so the straggler problems of one step overlap the bulk of the next step.  Every step does the
+    # complete work on the complete batch.
     class Pipe:
         pass
 
-    pipes = []
-    for _ in range(max(1, args.inflight)):
+    def make_pipe(r_margin):
         pp = Pipe()
         pp.stream = torch.cuda.Stream(device=dev)
         pp.ctx = capi.Context(local_rank)
         pp.ctx.set_stream(pp.stream.cuda_stream)
+        pp.ctx.set_params(par)
+        pp.ctx.set_pair_margin(r_margin)
         pp.d_safe = to_dev(safe_t)
         pp.d_sfaces = torch.zeros_like(d_faces)
-        pp.d_wres = torch.zeros(B * RES, dtype=torch.uint8, device=dev)
+        pp.d_wres = torch.zeros(per_rank * RES, dtype=torch.uint8, device=dev)  # (strong: padded to the largest shard)
         pp.d_sres = torch.zeros_like(pp.d_wres)
-        pp.gather = torch.zeros((world, B, 2), dtype=torch.float64, device=dev) if world > 1 else None
-        pipes.append(pp)
+        pp.gather = None
+        if world > 1:
+            if strong:
+                pp.gather = [torch.zeros(world * per_rank * RES, dtype=torch.uint8, device=dev) for _ in range(2)]
+            elif rank == 0:
+                pp.gather = [[torch.zeros(per_rank * RES, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
+        return pp
+
+    pipes = [make_pipe(args.r_margin) for _ in range(max(1, args.inflight))]
     torch.cuda.synchronize()
     step_no = [0]
 
-    def step():
-        pp = pipes[step_no[0] % len(pipes)]
-        step_no[0] += 1
+    def run_step(pp, fused):
         c = pp.ctx
-        if args.pipeline == "fused":
+        if fused:
             c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, 0.5, 0.2, 3, pp.d_wres.data_ptr(),
                                  pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), pp.d_sres.data_ptr())
         else:
@@ -163,9 +203,14 @@ def main():
             c.pair_glue_device(d_whole.data_ptr(), pp.d_wres.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, pp.d_safe.data_ptr(),
                                pp.d_sfaces.data_ptr())
             c.solve_batch_device(pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), B, N, max_faces, pp.d_sres.data_ptr())
-        if world > 1:  # batch gather of the per-pair summaries (whole cost, safe cost) over RCCL/xGMI
+
+    def step():
+        pp = pipes[step_no[0] % len(pipes)]
+        step_no[0] += 1
+        run_step(pp, args.pipeline == "fused")
+        if world > 1:  # the batch gather: complete fh_result blocks over RCCL/xGMI
             with torch.cuda.stream(pp.stream):
-                shard.gather_step_summaries(dist, pp.d_wres, pp.d_sres, B, pp.gather.view(world * B, 2))
+                shard.gather_result_blocks(dist, pp.d_wres, pp.d_sres, pp.gather, strong, rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -193,21 +238,25 @@ def main():
 
     kernel_ms = np.concatenate([pp.ctx.timing_read() for pp in pipes])
     last = pipes[(step_no[0] - 1) % len(pipes)]
-    wres = last.d_wres.cpu().numpy().view(abi.result_dtype)
-    sres = last.d_sres.cpu().numpy().view(abi.result_dtype)
+    share_stats = last.ctx.share_stats()
+    wres = last.d_wres.cpu().numpy().view(abi.result_dtype)[:B]
+    sres = last.d_sres.cpu().numpy().view(abi.result_dtype)[:B]
     safe_h = last.d_safe.cpu().numpy().view(abi.problem_dtype)
     sfaces_h = last.d_sfaces.cpu().numpy().view(abi.face_dtype)
 
     if rank == 0:
-        pairs_total = world * B * args.steps
+        fused = args.pipeline == "fused"
+        kname = "fh::solve_kernel<%d, %s>" % (10 if N <= 10 else 16, "true" if fused else "false")
+        pairs_total = (total_pairs if strong else world * B) * args.steps
         value = pairs_total / elapsed
-        # roofline of the dominant kernel (solve_kernel<10>, two launches per step: whole, safe)
         bytes_whole = algorithmic_bytes(whole, N)
         active = safe_h["n_seg"] > 0
         bytes_safe = algorithmic_bytes(safe_h[active], N) + 24 * int((~active).sum())
-        bytes_per_launch = 0.5 * (bytes_whole + bytes_safe)
+        launches_per_step = 1 if fused else 2
+        bytes_per_launch = (bytes_whole + bytes_safe) / launches_per_step
         avg_ms = float(np.mean(kernel_ms)) if len(kernel_ms) else float("nan")
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9  # GB/s
+        traffic = measured_traffic(kname) or (None, None)
         out = {
             "metric": "trajectory solves/sec (whole+safe pairs) at N=%d, deg=3" % N,
             "value": value,
@@ -217,45 +266,56 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("C4: %d whole+safe paired solves per GPU per step (N=%d segments, deg=3, <=%d polytopes whole / <=3 safe), "
-                             "synthetic corridors (faster_amd/corridor.py seed 3)" % (B, N, args.max_poly)) if args.workload == "c4" else
-                            ("C5: %d whole+safe paired solves per GPU per step in a random forest (20x20x3 m, 0.1 trees/m^2), corridors from "
-                             "the voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes" % B),
+                "workload": ("C4: %d whole+safe paired solves per %s per step (N=%d segments, deg=3, <=%d polytopes whole / <=3 safe), "
+                             "synthetic corridors (faster_amd/corridor.py seed 3), hand-off keeps R >= %.2f m inside its safe corridor"
+                             % (args.pairs, "job" if strong else "GPU", N, args.max_poly, args.r_margin)) if args.workload == "c4" else
+                            ("C5: %d whole+safe paired solves per %s per step in a random forest (20x20x3 m, 0.1 trees/m^2), corridors from "
+                             "the voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes" % (total_pairs, "job" if strong else "GPU")),
                 "pairs_per_gpu": B,
+                "pipeline": args.pipeline,
                 "pipelines_in_flight": len(pipes),
-                "parallelism": "batch-sharded x%d, RCCL all_gather of result summaries" % world if world > 1 else "single GPU",
+                "work_sharing": bool(par["share"]),
+                "parallelism": ("one batch sharded x%d (contiguous blocks), RCCL all_gather of fh_result blocks" % world if strong else
+                                "batch per GPU x%d, RCCL gather of fh_result blocks on rank 0" % world) if world > 1 else "single GPU",
                 "whole_solved_frac": float(wres["solved"].mean()),
                 "safe_solved_frac": float(sres["solved"].mean()),
                 "mean_bnb_nodes_whole": float(wres["nodes"].mean()),
                 "mean_bnb_nodes_safe": float(sres["nodes"].mean()),
                 "mean_qp_iters_per_pair": float(wres["qp_iters"].mean() + sres["qp_iters"].mean()),
                 "mean_trials_per_pair": float(wres["trials"].mean() + sres["trials"].mean()),
+                "share_stats_last_launch": share_stats,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fh::solve_kernel<10>",
+                "kernel": kname,
                 "achieved": achieved,
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / (HBM_PEAK / 1e9),
-                "traffic": (measured_traffic() or (None, None))[0],
-                "traffic_source": (measured_traffic() or (None, None))[1],
+                "traffic": traffic[0],
+                "traffic_source": traffic[1],
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": int(len(kernel_ms)),
                 "pipelines_in_flight": len(pipes),
                 "aggregate_achieved": (bytes_whole + bytes_safe) * args.steps / elapsed / 1e9,
-                "issue_side": issue_side(measured_valu_insts(), elapsed / args.steps / 2.0) if args.workload == "c4" and N == 10 else None,
-                "note": "latency/FP64-ALU bound by construction (SURVEY.md 8(d)): ~4-7 KB compulsory HBM bytes per pair; launches of "
-                        "different pipelines overlap, so per-launch durations include time shared with other launches "
-                        "(aggregate_achieved = all algorithmic bytes of the timed region / wall time)",
+                "note": "the path is FP64-ALU / latency bound by construction (SURVEY.md 8(d): ~4-7 KB compulsory HBM bytes per pair); "
+                        "with several pipelines in flight a launch's duration includes time shared with other launches — `solo` is the "
+                        "same launch alone on the GPU, `compute` the FP64 flop rate against the measured FP64 FMA peak",
             },
         }
+        if world == 1 and not args.no_extra:
+            out["roofline"]["solo"], solo_res = solo_leg(torch, pipes[0], run_step, fused, B, bytes_per_launch, launches_per_step)
+            out["roofline"]["compute"] = compute_leg(torch, dev, pipes[0], whole, faces, solo_res, N, max_faces,
+                                                     out["roofline"]["solo"]["step_ms_median"], elapsed / args.steps, to_dev)
+            out["e2e_with_copies"] = e2e_leg(torch, dev, pipes[0], whole, faces, safe_t, B, N, max_faces)
+            if args.workload == "c4":
+                out["config"]["safe_solved_frac_literal_8d"] = literal_leg(make_pipe, run_step, fused, abi, B)
         if not args.no_cpu and world == 1:  # the CPU baseline is a property of the host: reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(whole, faces, safe_h, sfaces_h, args.cpu_seconds)
         print(json.dumps(out))
@@ -266,24 +326,135 @@ def main():
         pp.ctx.close()
 
 
-def issue_side(valu_insts, launch_s):
-    """What actually bounds the kernel: wave64 VALU instructions occupy a 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at
-    2.4 GHz.  launch_s = steady-state time per launch (two solve launches per step).  Reported next to the contract's HBM figures."""
-    if not valu_insts:
-        return None
-    busy = valu_insts * 4.0 / (256 * 4 * 2.4e9) / launch_s
-    return {"valu_wave_insts_per_launch": valu_insts, "steady_state_ms_per_launch": 1e3 * launch_s, "valu_pipes_busy_frac": busy,
-            "source": "SQ_INSTS_VALU of the committed PMC pass x 4 cycles / (1024 SIMDs x 2.4 GHz)"}
+def solo_leg(torch, pp, run_step, fused, B, bytes_per_launch, launches_per_step, reps=7):
+    """One batch alone on the GPU (no other launch in flight): median of `reps` fenced steps.  The per-launch HBM roofline
+    fraction from these durations is not confounded by overlap."""
+    import numpy as np
+
+    from faster_amd import abi
+
+    step_ms, launch_ms = [], []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        pp.ctx.timing_reset()
+        t = time.perf_counter()
+        run_step(pp, fused)
+        pp.ctx.sync()
+        step_ms.append(1e3 * (time.perf_counter() - t))
+        launch_ms.append(list(pp.ctx.timing_read()))
+    launch = np.median(np.array(launch_ms), axis=0)
+    med = float(np.median(step_ms))
+    res = (pp.d_wres.cpu().numpy().view(abi.result_dtype)[:B].copy(), pp.d_sres.cpu().numpy().view(abi.result_dtype)[:B].copy())
+    mean_launch = float(np.mean(launch))
+    ach = bytes_per_launch / (mean_launch * 1e-3) / 1e9
+    return {"step_ms_median": med, "launch_ms_median": [float(x) for x in launch], "repetitions": reps, "pairs_per_s": B / (med * 1e-3),
+            "achieved": ach, "frac": ach / (HBM_PEAK / 1e9), "unit": "GB/s"}, res
+
+
+def compute_leg(torch, dev, pp, whole, faces, solo_res, N, max_faces, solo_step_ms, steady_step_s, to_dev):
+    """FP64 flop rate.  executed = the kernel's own count of the FP64 flops of every active-set iteration it ran
+    (fh_result.kflops: useful lanes only, formula in fh_solve.hip.hpp qp_run); useful = the flops of ONE fixed-assignment QP at the
+    winning factor with the winning assignment (the reference-equivalent minimal work of a trial), times the trials of the problem,
+    measured by solving every solved problem again with its binaries pinned (fh_problem.pin) and the factor window shrunk to the
+    winning factor.  peak = measured FP64 FMA rate of this device (fh_fp64_peak)."""
+    import numpy as np
+
+    from faster_amd import abi
+
+    wres, sres = solo_res
+    executed = 1e3 * (float(wres["kflops"].astype(np.float64).sum()) + float(sres["kflops"].astype(np.float64).sum()))
+    # pinned re-solve of the whole problems (the safe problems live on the device: their records are read back)
+    safe_h = pp.d_safe.cpu().numpy().view(abi.problem_dtype).copy()
+    sfaces_h = pp.d_sfaces.cpu().numpy().view(abi.face_dtype).copy()
+    useful = 0.0
+    for probs, fcs, res in ((whole, faces, wres), (safe_h, sfaces_h, sres)):
+        ok = (res["solved"] == 1) & (probs["n_seg"] > 0)
+        if not ok.any():
+            continue
+        p = probs[ok].copy()
+        r = res[ok]
+        p["f_init"] = r["factor"]
+        p["f_final"] = r["factor"]
+        a = r["assign"].astype(np.int64)
+        pins = np.zeros(len(p), dtype=np.uint64)
+        for t in range(N):
+            pins |= (np.where((a[:, t] >= 0) & (p["n_poly"] > 0), a[:, t] + 1, 0).astype(np.uint64) << np.uint64(4 * t))
+        p["pin"][:, 0] = (pins & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        p["pin"][:, 1] = (pins >> np.uint64(32)).astype(np.uint32)
+        d_p, d_f = to_dev(p), to_dev(fcs)
+        d_r = torch.zeros(len(p) * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+        pp.ctx.solve_batch_device(d_p.data_ptr(), d_f.data_ptr(), len(p), N, max_faces, d_r.data_ptr())
+        pp.ctx.sync()
+        one = d_r.cpu().numpy().view(abi.result_dtype)
+        useful += 1e3 * float((one["kflops"].astype(np.float64) * r["trials"]).sum())
+    peak = pp.ctx.fp64_peak_tflops()
+    ach_solo = executed / (solo_step_ms * 1e-3) / 1e12
+    ach_steady = executed / steady_step_s / 1e12
+    return {"executed_flops_per_step": executed, "useful_flops_per_step": useful, "useful_over_executed": useful / executed if executed else None,
+            "achieved_tflops": ach_steady, "achieved_tflops_solo": ach_solo, "useful_tflops": useful / steady_step_s / 1e12,
+            "measured_peak_tflops": peak, "spec_peak_tflops": FP64_VECTOR_SPEC_TFLOPS, "frac": ach_steady / peak if peak else None,
+            "frac_solo": ach_solo / peak if peak else None, "unit": "TFLOP/s",
+            "note": "executed: FP64 flops of all active-set iterations (useful lanes; a wave64 FP64 instruction occupies the SIMD for the full "
+                    "wavefront, so lane utilisation — 30 of 64 lanes for N=10 — is not in this figure); useful: one fixed-assignment QP per trial"}
+
+
+def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5):
+    """PCIe-inclusive rate: problems and faces start in pinned host memory, both result arrays end there (never `value`)."""
+    import numpy as np
+
+    from faster_amd import abi
+
+    RES = abi.result_dtype.itemsize
+
+    def pinned(a):
+        t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).pin_memory()
+        return t
+
+    h_whole, h_faces, h_safe = pinned(whole), pinned(faces), pinned(safe_t)
+    h_wres = torch.zeros(B * RES, dtype=torch.uint8).pin_memory()
+    h_sres = torch.zeros(B * RES, dtype=torch.uint8).pin_memory()
+    d_whole = torch.empty_like(h_whole, device=dev)
+    d_faces = torch.empty_like(h_faces, device=dev)
+    ms = []
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        with torch.cuda.stream(pp.stream):
+            d_whole.copy_(h_whole, non_blocking=True)
+            d_faces.copy_(h_faces, non_blocking=True)
+            pp.d_safe.copy_(h_safe, non_blocking=True)
+            pp.ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, 0.5, 0.2, 3, pp.d_wres.data_ptr(),
+                                      pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), pp.d_sres.data_ptr())
+            h_wres.copy_(pp.d_wres[: B * RES], non_blocking=True)
+            h_sres.copy_(pp.d_sres[: B * RES], non_blocking=True)
+        pp.stream.synchronize()
+        ms.append(1e3 * (time.perf_counter() - t))
+    ms = ms[1:]
+    med = float(np.median(ms))
+    nbytes = h_whole.numel() + h_faces.numel() + h_safe.numel() + 2 * B * RES
+    return {"step_ms_median": med, "repetitions": reps, "pairs_per_s": B / (med * 1e-3), "bytes_over_pcie_per_step": int(nbytes),
+            "note": "one batch at a time: H2D problems+faces+safe templates, fused pair launch, D2H both result arrays; pinned host memory"}
+
+
+def literal_leg(make_pipe, run_step, fused, abi, B):
+    """The same step with the hand-off of SURVEY.md 8(d) taken to the letter (R may lie outside its shrunk corridor)."""
+    pp = make_pipe(-1.0)
+    run_step(pp, fused)
+    pp.ctx.sync()
+    frac = float(pp.d_sres.cpu().numpy().view(abi.result_dtype)[:B]["solved"].mean())
+    pp.ctx.close()
+    return frac
 
 
 def cpu_baseline(whole, faces, safe, sfaces, target_s):
     """The CPU oracle (oracle/faster_oracle.c, kind "port": Gurobi is absent) timed on a bounded sample of the SAME pairs:
-    all host cores via OpenMP over problems, repeated until about `target_s` seconds of wall time have been spent.  Also
-    reports the single-thread rate on a smaller sample.  Reported baseline only."""
+    OpenMP over problems on the cores this process may use (affinity mask, cgroup quota), repeated until about `target_s`
+    seconds of wall time have been spent.  Also the single-thread rate and the rate on 8 threads (how the port scales).
+    Reported baseline only."""
     from oracle import oracle as orc
 
     orc.build()
-    cores = min(os.cpu_count() or 1, orc.max_threads())
+    cores = max(1, min(host_cores(), orc.max_threads()))
 
     def run(k, threads):
         t = time.perf_counter()
@@ -295,16 +466,20 @@ def cpu_baseline(whole, faces, safe, sfaces, target_s):
 
     k1 = min(512, len(whole))
     t1 = run(k1, 1)                       # single thread
+    k8 = min(4096, len(whole))
+    run(min(len(whole), 4096), cores)     # warm up the thread pool
+    t8 = run(k8, min(8, cores))
     k = len(whole)
-    run(min(k, 4096), cores)              # warm up the thread pool
     passes, spent = 0, 0.0
     while spent < target_s and passes < 64:
         spent += run(k, cores)
         passes += 1
     return {"value": passes * k / spent, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": "%d passes over the %d pairs of rank 0 (whole + safe solves), CPU restatement oracle/faster_oracle.c with OpenMP "
-                      "over problems on %d threads; NOT Gurobi (absent)" % (passes, k, cores),
-            "seconds": spent, "single_thread_value": k1 / t1, "single_thread_sample": "%d pairs" % k1}
+                      "over problems on %d threads (os.sched_getaffinity / cgroup quota; os.cpu_count() = %d); NOT Gurobi (absent)"
+                      % (passes, k, cores, os.cpu_count() or 0),
+            "seconds": spent, "single_thread_value": k1 / t1, "single_thread_sample": "%d pairs" % k1,
+            "eight_thread_value": k8 / t8, "scaling_vs_one_thread": (passes * k / spent) / (k1 / t1)}
 
 
 if __name__ == "__main__":

@@ -18,6 +18,8 @@ SYMBOLS = [
     "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device",
+    "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin",
+    "fh_pool_solve_batch", "fh_pool_solve_pairs",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
 
@@ -80,6 +82,22 @@ def lib():
         L.fh_decompose_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, f64, f64, i32, vp, vp]
         L.fh_sync.restype = i32
         L.fh_sync.argtypes = [vp]
+        L.fh_pool_create.restype = i32
+        L.fh_pool_create.argtypes = [ctypes.POINTER(vp), vp, i32]
+        L.fh_pool_destroy.restype = None
+        L.fh_pool_destroy.argtypes = [vp]
+        L.fh_pool_size.restype = i32
+        L.fh_pool_size.argtypes = [vp]
+        L.fh_pool_last_error.restype = ctypes.c_char_p
+        L.fh_pool_last_error.argtypes = [vp]
+        L.fh_pool_set_params.restype = i32
+        L.fh_pool_set_params.argtypes = [vp, vp]
+        L.fh_pool_set_pair_margin.restype = i32
+        L.fh_pool_set_pair_margin.argtypes = [vp, f64]
+        L.fh_pool_solve_batch.restype = i32
+        L.fh_pool_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp]
+        L.fh_pool_solve_pairs.restype = i32
+        L.fh_pool_solve_pairs.argtypes = [vp, vp, vp, i64, i32, vp, f64, f64, i32, vp, vp, i32, vp, vp]
         L.fh_timing_reset.restype = i32
         L.fh_timing_reset.argtypes = [vp]
         L.fh_timing_read.restype = i32
@@ -89,6 +107,65 @@ def lib():
         L.fh_version.restype = ctypes.c_char_p
         _LIB = L
     return _LIB
+
+
+class Pool:
+    """ONE batch sharded over several devices of a node (fh_pool_*): contiguous blocks, host scatter, gather of fh_result blocks."""
+
+    def __init__(self, devices=None):
+        self._h = ctypes.c_void_p()
+        dev = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        rc = lib().fh_pool_create(ctypes.byref(self._h), None if dev is None else abi.ptr(dev), 0 if dev is None else len(dev))
+        if rc != 0:
+            msg = lib().fh_pool_last_error(self._h).decode() if self._h else "fh_pool_create failed"
+            if self._h:
+                lib().fh_pool_destroy(self._h)
+                self._h = None
+            raise FasterHipError("fh_pool_create: rc=%d %s" % (rc, msg))
+
+    def close(self):
+        if self._h:
+            lib().fh_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return lib().fh_pool_size(self._h)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FasterHipError("%s: rc=%d %s" % (what, rc, lib().fh_pool_last_error(self._h).decode()))
+
+    def set_params(self, params):
+        p = np.ascontiguousarray(params).reshape(1)
+        self._check(lib().fh_pool_set_params(self._h, abi.ptr(p)), "fh_pool_set_params")
+
+    def set_pair_margin(self, r_margin):
+        self._check(lib().fh_pool_set_pair_margin(self._h, float(r_margin)), "fh_pool_set_pair_margin")
+
+    def solve_batch(self, problems, faces, root=0, d_results_root=None):
+        problems = np.ascontiguousarray(problems)
+        faces = np.ascontiguousarray(faces)
+        res = np.zeros(problems.shape[0], dtype=abi.result_dtype)
+        self._check(lib().fh_pool_solve_batch(self._h, abi.ptr(problems), abi.ptr(faces) if faces.shape[0] else None, faces.shape[0],
+                                              problems.shape[0], abi.ptr(res), root, d_results_root), "fh_pool_solve_batch")
+        return res
+
+    def solve_pairs(self, whole, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_poly=3, root=0, d_whole_root=None, d_safe_root=None):
+        whole = np.ascontiguousarray(whole)
+        faces = np.ascontiguousarray(faces)
+        safe_templates = np.ascontiguousarray(safe_templates)
+        wres = np.zeros(whole.shape[0], dtype=abi.result_dtype)
+        sres = np.zeros(whole.shape[0], dtype=abi.result_dtype)
+        self._check(lib().fh_pool_solve_pairs(self._h, abi.ptr(whole), abi.ptr(faces) if faces.shape[0] else None, faces.shape[0],
+                                              whole.shape[0], abi.ptr(safe_templates), r_frac, shrink, max_safe_poly, abi.ptr(wres),
+                                              abi.ptr(sres), root, d_whole_root, d_safe_root), "fh_pool_solve_pairs")
+        return wres, sres
 
 
 class Context:

@@ -49,6 +49,31 @@ def all_gather_rows(dist, local, per_rank):
     return out
 
 
+def gather_result_blocks(dist, whole_results, safe_results, gather, strong, rank):
+    """The per-step "batch gather" of bench.py: complete `fh_result` blocks, not summaries.
+    whole_results / safe_results: uint8 tensors of this rank's per_rank records (a shorter shard is padded to per_rank).
+    strong (one batch sharded over the ranks): all_gather, gather = [whole_out, safe_out], each world*per_rank records — every
+    rank ends the step with the results of the whole batch (row r*per_rank + i = problem shard_range(r)[0] + i).
+    weak (a batch per rank): gather on rank 0, gather = [[per-rank buffers], [per-rank buffers]] there, None elsewhere.
+    Device tensors with the nccl backend = RCCL over xGMI; CPU tensors with gloo in the tests.  Runs on the current stream."""
+    if strong:
+        dist.all_gather_into_tensor(gather[0], whole_results)
+        dist.all_gather_into_tensor(gather[1], safe_results)
+    else:
+        dist.gather(whole_results, gather_list=gather[0] if rank == 0 else None, dst=0)
+        dist.gather(safe_results, gather_list=gather[1] if rank == 0 else None, dst=0)
+    return gather
+
+
+def unpad_gathered(blocks, n, world, dtype):
+    """[world*per_rank] records gathered from contiguous shards -> the n records of the original batch, in order."""
+    import numpy as np
+
+    per = -(-n // world)
+    rec = np.asarray(blocks).view(dtype)
+    return np.concatenate([rec[r * per: r * per + (shard_range(n, r, world)[1] - shard_range(n, r, world)[0])] for r in range(world)])
+
+
 def gather_step_summaries(dist, whole_results, safe_results, n, out):
     """The per-step "batch gather" of bench.py: every rank contributes (whole cost, safe cost) of its n pairs; `out` is
     [world*n, 2].  whole_results / safe_results are uint8 tensors holding n `fh_result` records (device tensors with the

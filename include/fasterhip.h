@@ -242,6 +242,32 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
 
 int fh_sync(fh_ctx* ctx);
 
+/* ---- one batch over several GPUs of a node ---------------------------------------------------------------
+ * The reference is a single process on one CPU; its replacement for many independent start/goal/corridor problems shards ONE
+ * batch over the devices of a node: device g of G solves the contiguous block [g*ceil(n/G), min(n, (g+1)*ceil(n/G))) (a
+ * whole+safe pair never leaves its device), reading its block straight from the caller's host arrays (asynchronous H2D on its
+ * own stream — the scatter needs no collective) and returning complete fh_result blocks.  Results are identical to the
+ * single-device entry points (the problems are independent).  `devices`: n_devices HIP device indices (NULL: 0..n_devices-1;
+ * n_devices <= 0: all visible devices; the same index may appear more than once — each entry gets its own context and stream).
+ * No CPU fallback: FH_ERR_DEVICE without a device. */
+typedef struct fh_pool fh_pool;
+int fh_pool_create(fh_pool** out, const int* devices, int n_devices);
+void fh_pool_destroy(fh_pool* pool);
+int fh_pool_size(const fh_pool* pool);
+const char* fh_pool_last_error(const fh_pool* pool);
+int fh_pool_set_params(fh_pool* pool, const fh_params* p);
+int fh_pool_set_pair_margin(fh_pool* pool, double r_margin);
+/* fh_solve_batch over the pool (host pointers, synchronous).  The result blocks are gathered into `results` (host, may be NULL)
+ * and/or into `d_results_root`, n records in the memory of pool device number `root`, with peer copies over xGMI
+ * (hipMemcpyPeerAsync) — for a consumer that lives on that GPU.  At least one destination must be given. */
+int fh_pool_solve_batch(fh_pool* pool, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n, fh_result* results,
+                        int root, fh_result* d_results_root);
+/* whole solve -> hand-off -> safe solve of n pairs over the pool (fh_solve_pairs_device per block; safe_templates as d_safe of
+ * fh_pair_glue_device).  Both result arrays are gathered like fh_pool_solve_batch's. */
+int fh_pool_solve_pairs(fh_pool* pool, const fh_problem* whole, const fh_face* faces, int64_t n_faces, int n,
+                        const fh_problem* safe_templates, double r_frac, double shrink, int max_safe_poly, fh_result* whole_results,
+                        fh_result* safe_results, int root, fh_result* d_whole_results_root, fh_result* d_safe_results_root);
+
 /* Timing of the solve kernel, measured with HIP events recorded around every solve-kernel launch on
  * the context stream (the same stream the kernel runs on).  fh_timing_reset() forgets recorded launches;
  * fh_timing_read() synchronises with the last recorded launch and writes the duration (ms) of up to

@@ -40,8 +40,24 @@ else:  # uneven shards: pad to the common size as bench.py's equal per-rank batc
     shard.gather_step_summaries(dist, wt, wt, per, out)
     mine = out[rank * per: rank * per + len(res)].numpy()
     assert np.array_equal(mine[:, 0], res["cost"]) and np.array_equal(mine[:, 1], res["cost"])
+# complete fh_result blocks, as bench.py gathers them: all_gather (strong scaling, one sharded batch) and gather on rank 0 (weak)
+pad = np.zeros(per, dtype=abi.result_dtype); pad[: len(res)] = res
+blk = torch.from_numpy(pad.view(np.uint8).reshape(-1).copy())
+RES = abi.result_dtype.itemsize
+g_strong = [torch.zeros(world * per * RES, dtype=torch.uint8) for _ in range(2)]
+shard.gather_result_blocks(dist, blk, blk, g_strong, True, rank)
+g_weak = [[torch.zeros(per * RES, dtype=torch.uint8) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+shard.gather_result_blocks(dist, blk, blk, g_weak, False, rank)
+full = oracle.solve_batch(pr, faces, threads=2)
+everything = shard.unpad_gathered(g_strong[0].numpy(), len(pr), world, abi.result_dtype)
+for f in abi.result_dtype.names:   # EVERY rank holds the results of the whole batch, identical to the 1-way run
+    assert np.array_equal(everything[f], full[f]), ("all_gather", f)
+assert np.array_equal(g_strong[0].numpy(), g_strong[1].numpy())
 if rank == 0:
-    full = oracle.solve_batch(pr, faces, threads=2)
+    weak = shard.unpad_gathered(torch.cat(g_weak[1]).numpy(), len(pr), world, abi.result_dtype)
+    for f in abi.result_dtype.names:
+        assert np.array_equal(weak[f], full[f]), ("gather", f)
+if rank == 0:
     got = np.concatenate([g[r * per: r * per + (shard.shard_range(len(pr), r, world)[1] - shard.shard_range(len(pr), r, world)[0])].numpy() for r in range(world)])
     assert got.shape[0] == len(pr)
     assert np.array_equal(got, shard.summaries(full)), "sharded results differ from the single-process run"
@@ -70,7 +86,7 @@ def test_shard_batch_rebases_faces():
         assert np.array_equal(fa["b"][a["face_begin"][i]: a["face_begin"][i] + n], faces["b"][g0: g0 + n])
 
 
-def test_two_rank_gloo_sharding(tmp_path, oracle):
+def _run_world(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     s = socket.socket()
@@ -78,10 +94,19 @@ def test_two_rank_gloo_sharding(tmp_path, oracle):
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert "GLOO_OK" in outs[0][0]
+
+
+def test_two_rank_gloo_sharding(tmp_path, oracle):
+    _run_world(tmp_path, 2)
+
+
+def test_four_rank_gloo_sharding(tmp_path, oracle):
+    """37 problems over 4 ranks: shards of 10, 10, 10, 7 — the gathered fh_result blocks equal the 1-way run record for record."""
+    _run_world(tmp_path, 4)

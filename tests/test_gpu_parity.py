@@ -443,7 +443,7 @@ def test_gpu_decomposition_matches_host_frontend(ctx):
     assert np.all(counts == -1)
 
 
-def test_concurrent_factor_search_is_the_sequential_rule(ctx):
+def test_concurrent_factor_search_is_the_sequential_rule(ctx, oracle):
     """the line search run `width` factors at a time returns the sequential first-feasible result bit
     for bit (factor_that_worked_ semantics of solverGurobi.cpp:445-467), incl. unsolved, empty-window and bad records."""
     whole, faces, _ = corridor.whole_batch(96, seed=21, n_seg=10, p_choices=(2, 3, 4, 5, 6))
@@ -457,6 +457,7 @@ def test_concurrent_factor_search_is_the_sequential_rule(ctx):
     pr["f_inc"][51] = 0.0                       # bad window
     seq = ctx.solve_batch(pr, fc)
     assert (seq["solved"] == 1).sum() > 60 and (seq["solved"] == 0).sum() > 8 and seq["trials"].max() >= 4
+    compare(seq, oracle.solve_batch(pr, fc))   # the sequential rule itself is the oracle's (edge-case windows included)
     # the work counters (nodes, qp_iters, kflops) depend on who explored what when subtrees are shared between wavefronts:
     # everything genNewTraj() leaves behind is compared in the default mode, the counters as well with one wavefront per problem
     results = [n for n in abi.result_dtype.names if n not in ("nodes", "qp_iters", "kflops")]

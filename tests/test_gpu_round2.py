@@ -1,0 +1,314 @@
+"""GPU tests added in round 2 (all through the C ABI): oracle comparison at BASELINE's full C4 size, the device decomposition
+against the numpy restatement directly, the closed loop against the oracle-backed run, a slice of the randomized parity sweep
+(including the tight, mostly infeasible region), one batch over a pool of devices, cooperative cancellation and the deadline."""
+import json
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from faster_amd import abi, capi, corridor
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RESULT_FIELDS = [n for n in abi.result_dtype.names if n not in ("nodes", "qp_iters", "kflops")]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch  # noqa: F401  (torch first: one HIP runtime in the process)
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def compare(got, ref, cost_rtol=1e-7, coeff_atol=1e-6):
+    assert np.array_equal(got["solved"], ref["solved"]), np.nonzero(got["solved"] != ref["solved"])
+    assert np.array_equal(got["trials"], ref["trials"])
+    assert np.array_equal(got["factor"], ref["factor"]) and np.array_equal(got["dt"], ref["dt"])
+    assert np.array_equal(got["status"], ref["status"])
+    ok = ref["solved"] == 1
+    np.testing.assert_allclose(got["cost"][ok], ref["cost"][ok], rtol=cost_rtol, atol=1e-9)
+    np.testing.assert_allclose(got["coeff"][ok], ref["coeff"][ok], rtol=0, atol=coeff_atol)
+    return ok
+
+
+def test_full_size_c4_subsample_against_oracle(ctx, oracle):
+    """BASELINE config C4 at its full size (32768 whole+safe pairs, both hand-off variants) in ONE fused launch; a random
+    subsample of 4096 pairs — whole problem, the hand-off record the device wrote, and the safe problem built from it — is
+    compared with the oracle (the full batch would take the CPU minutes)."""
+    import torch
+
+    from oracle import pair_glue
+
+    B, N = 32768, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    tmpl = corridor.safe_templates(whole)
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    dev = "cuda:0"
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    d_whole, d_faces = to_dev(whole), to_dev(faces)
+    idx = np.sort(np.random.default_rng(5).choice(B, 4096, replace=False))
+    for margin in (0.05, -1.0):
+        ctx.set_pair_margin(margin)
+        d_safe, d_sf = to_dev(tmpl), torch.zeros_like(d_faces)
+        d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros_like(d_wr)
+        ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(),
+                               d_sf.data_ptr(), d_sr.data_ptr())
+        ctx.sync()
+        wres = d_wr.cpu().numpy().view(abi.result_dtype)
+        sres = d_sr.cpu().numpy().view(abi.result_dtype)
+        safe = d_safe.cpu().numpy().view(abi.problem_dtype)
+        sfaces = d_sf.cpu().numpy().view(abi.face_dtype)
+        wref = oracle.solve_batch(whole[idx], faces)
+        compare(wres[idx], wref)
+        # the hand-off records of the subsample against the host restatement driven by the ORACLE's whole results
+        safe_ref, sfaces_ref = pair_glue.glue(whole[idx], wref, faces, tmpl[idx], 0.5, 0.2, 3, r_margin=margin)
+        assert np.array_equal(safe["n_seg"][idx], safe_ref["n_seg"]) and np.array_equal(safe["n_poly"][idx], safe_ref["n_poly"])
+        np.testing.assert_allclose(safe["x0"][idx], safe_ref["x0"], rtol=0, atol=1e-9)
+        live = safe_ref["n_seg"] > 0
+        sub = np.nonzero(live)[0][:2048]
+        sref = oracle.solve_batch(safe[idx][sub], sfaces)   # the device-written safe problems, solved by the oracle
+        ok = compare(sres[idx][sub], sref)
+        assert ok.mean() > 0.6
+        if margin >= 0:  # R strictly inside its corridor: the first polytope contains x0
+            s = safe[idx][sub]
+            for k in range(0, len(s), 97):
+                f0 = s["face_begin"][k]
+                n0 = s["face_off"][k][1]
+                assert np.all(sfaces["a"][f0:f0 + n0] @ s["x0"][k][:3] < sfaces["b"][f0:f0 + n0])
+    ctx.set_pair_margin(-1.0)
+
+
+def test_gpu_decomposition_against_numpy_restatement(ctx):
+    """fh_decompose_batch against oracle/decomp_oracle.py DIRECTLY (not through the host front-end): polytopes as sets of rows."""
+    from oracle import decomp_oracle
+
+    key = lambda M: M[np.lexsort(np.round(M, 7).T[::-1])]
+    rng = np.random.default_rng(17)
+    total = 0
+    for scene in range(5):
+        path = np.cumsum(np.vstack([rng.uniform(-3, 3, 3) * [1, 1, 0] + [0, 0, 1.2], rng.uniform(0.8, 2.5, (4, 1)) * (rng.normal(size=(4, 3)) * [1, 1, 0.2])]), axis=0)
+        path[:, 2] = np.clip(path[:, 2], 0.6, 2.4)
+        cloud = rng.uniform(path.min(0) - 2.5, path.max(0) + 2.5, size=(700, 3))
+        keep = np.ones(len(cloud), bool)
+        for a, b in zip(path[:-1], path[1:]):
+            t = np.clip(((cloud - a) @ (b - a)) / ((b - a) @ (b - a)), 0, 1)
+            keep &= np.linalg.norm(cloud - (a + t[:, None] * (b - a)), axis=1) > 0.45
+        cloud = cloud[keep]
+        segs = np.hstack([path[:-1], path[1:]])
+        faces, counts = ctx.decompose_batch(cloud, segs, drone_radius=0.05, z_ground=0.0, max_faces=64)
+        ref = decomp_oracle.decompose_path(path, cloud, 0.05, 0.0)
+        for i, (A, b) in enumerate(ref):
+            assert counts[i] == len(b), (scene, i, counts[i], len(b))
+            got = np.column_stack([faces["a"][i, :counts[i]], faces["b"][i, :counts[i]]])
+            np.testing.assert_allclose(key(got), key(np.column_stack([A, b])), atol=1e-9)
+            total += 1
+    assert total == 20
+
+
+def test_closed_loop_log_equals_oracle_backed_run():
+    """N2: the closed loop driven by SolverHip on the GPU produces the same log as the run in which the two C-ABI calls are
+    answered by the oracle (same seed): every counter equal, every metric equal to 1e-6."""
+    from test_replan_stub import build
+
+    exe = build()
+    logs = {}
+    for mode, arg in (("gpu", "-"), ("oracle", os.path.join(ROOT, "oracle", "liboracle.so"))):
+        r = subprocess.run([exe, mode, arg, "1"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        logs[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    g, o = logs["gpu"], logs["oracle"]
+    assert g.keys() == o.keys()
+    for k in g:
+        if isinstance(g[k], (int, list)) and not isinstance(g[k], bool) and all(isinstance(v, int) for v in (g[k] if isinstance(g[k], list) else [g[k]])):
+            assert g[k] == o[k], (k, g[k], o[k])
+        else:
+            np.testing.assert_allclose(g[k], o[k], rtol=0, atol=1e-6, err_msg=k)
+
+
+def test_parity_sweep_slice(ctx, oracle):
+    """~40 s of the randomized sweep of tests/tools/parity_sweep.py (N in {3..15}, P <= 8, whole / safe, bounds, increments),
+    INCLUDING tightened corridors with N*P > 40 (mostly infeasible: the exact search has no incumbent to prune with)."""
+    rng = np.random.default_rng(2027)
+    t0 = time.time()
+    done = tight_big = 0
+    cfg = 0
+    while time.time() - t0 < 40.0 or tight_big < 2:
+        cfg += 1
+        n_seg = int(rng.choice([3, 5, 6, 8, 10, 12, 15]))
+        pmax = int(rng.integers(1, 9))
+        if cfg in (2, 5):  # make sure the tight many-segments-times-many-polytopes region is visited
+            n_seg, pmax = (10, 6) if cfg == 2 else (12, 5)
+        pch = tuple(range(max(1, pmax - 2), pmax + 1))
+        kw = dict(speed=float(rng.uniform(0.5, 4.5)), lateral=float(rng.uniform(0.0, 1.5)), acc0=float(rng.uniform(0, 3)),
+                  f_inc=float(rng.choice([0.5, 1.0, 1.0, 2.0])), v_max=float(rng.choice([3, 5])), a_max=float(rng.choice([3, 5])),
+                  j_max=float(rng.choice([5, 8])))
+        tight = rng.random() < 0.3 or cfg in (2, 5)
+        big = n_seg * pmax > 40
+        n = (24 if big and tight else 768) if n_seg * pmax <= 60 else (192 if n_seg * pmax <= 80 else 48)
+        force = bool(rng.random() < 0.6)
+        pr, faces, _ = corridor.make_batch(n, n_seg, pch, force, int(rng.integers(1 << 30)), **kw)
+        if tight:
+            faces = faces.copy()
+            faces["b"] -= rng.uniform(0.3, 0.6)
+            tight_big += 1 if big else 0
+        got = ctx.solve_batch(pr, faces)
+        ref = oracle.solve_batch(pr, faces)
+        compare(got, ref)
+        done += n
+        if time.time() - t0 > 150:
+            break
+    assert done >= 1000 and tight_big >= 2
+
+
+def test_pool_shards_equal_one_way(ctx):
+    """ONE batch over a pool of devices (fh_pool_*): contiguous blocks, host scatter, gather of complete fh_result blocks into
+    the host array and, with peer copies, into the root device's memory.  The box has one GPU, so the pool names it three
+    times (three contexts, three streams, three shards of 37: 13 + 13 + 11): the partition / rebasing / gather logic is the
+    same as with three devices, and the results equal the one-way run record for record."""
+    import torch
+
+    pr, faces, _ = corridor.whole_batch(37, seed=4, n_seg=10, p_choices=(2, 3, 4, 5))
+    one = ctx.solve_batch(pr, faces)
+    pool = capi.Pool([0, 0, 0])
+    assert pool.size() == 3
+    d_root = torch.zeros(37 * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    got = pool.solve_batch(pr, faces, root=1, d_results_root=d_root.data_ptr())
+    torch.cuda.synchronize()
+    on_root = d_root.cpu().numpy().view(abi.result_dtype)
+    for f in RESULT_FIELDS:
+        assert np.array_equal(got[f], one[f]), f
+        assert np.array_equal(on_root[f], one[f]), ("root", f)
+    # pairs: whole -> hand-off -> safe per block
+    tmpl = corridor.safe_templates(pr)
+    pool.set_pair_margin(0.05)
+    w, s = pool.solve_pairs(pr, faces, tmpl)
+    pool1 = capi.Pool([0])
+    pool1.set_pair_margin(0.05)
+    w1, s1 = pool1.solve_pairs(pr, faces, tmpl)
+    for f in RESULT_FIELDS:
+        assert np.array_equal(w[f], one[f]) and np.array_equal(w1[f], one[f]), f
+        assert np.array_equal(s[f], s1[f]), ("safe", f)
+    assert s["solved"].sum() > 10
+    # a pool smaller than the batch count and larger than it
+    for devs, n in (([0, 0], 1), ([0, 0, 0, 0], 3)):
+        p2 = capi.Pool(devs)
+        g2 = p2.solve_batch(pr[:n], faces)
+        for f in RESULT_FIELDS:
+            assert np.array_equal(g2[f], one[f][:n]), f
+        p2.close()
+    pool.close()
+    pool1.close()
+
+
+def hard_problems(n=64, seed=77):
+    """Dense N=15 / P=8 corridors pulled 0.76 m inwards with 19 factor trials: mostly infeasible.  Most are rejected at once; a
+    few need 1e4-1e5 branch-and-bound nodes per trial (exact enumeration without an incumbent): the batch (64, seed 77) holds
+    one with 2.5e5 nodes in total."""
+    pr, faces, _ = corridor.whole_batch(n, seed=seed, n_seg=15, p_choices=(8,), f_inc=0.5)
+    faces = faces.copy()
+    faces["b"] -= 0.76
+    return pr, faces
+
+
+def test_stop_request_from_another_thread():
+    """a12: SolverGurobi::StopExecution() is meant to be called from another thread while m.optimize() runs (solverGurobi.cpp:15-39).
+    fh_request_stop() raises a word in mapped host memory; the workgroups poll it between branch-and-bound nodes."""
+    import torch  # noqa: F401
+
+    c = capi.Context(0)
+    pr, faces = hard_problems(n=64)       # contains a problem with 2.5e5 nodes: 3.8 s with work sharing, 38 s on one wavefront
+    out = {}
+
+    def run():
+        t = time.perf_counter()
+        out["res"] = c.solve_batch(pr, faces)
+        out["t_end"] = time.perf_counter()
+        out["dur"] = out["t_end"] - t
+
+    th = threading.Thread(target=run)
+    th.start()
+    time.sleep(0.25)                      # the launch is well under way
+    assert th.is_alive(), "the hard batch finished before it could be cancelled: make it harder"
+    t_stop = time.perf_counter()
+    c.request_stop()
+    th.join(timeout=30)
+    assert not th.is_alive()
+    latency = out["t_end"] - t_stop
+    res = out["res"]
+    assert (res["status"] == abi.FH_ST_INTERRUPTED).sum() >= 1 and np.all(res["solved"][res["status"] == abi.FH_ST_INTERRUPTED] == 0)
+    print("stop latency %.3f ms (launch had run %.0f ms)" % (1e3 * latency, 1e3 * (out["dur"] - latency)))
+    assert latency < 0.02, latency        # measured ~1 ms: poll every 2-4 nodes + D2H of the results
+    # the request stays raised: the next launch returns at once with every problem interrupted ...
+    t = time.perf_counter()
+    again = c.solve_batch(pr, faces)
+    assert time.perf_counter() - t < 0.05 and np.all(again["status"] == abi.FH_ST_INTERRUPTED)
+    # ... until it is cleared (ResetToNormalState)
+    c.clear_stop()
+    easy, efaces, _ = corridor.whole_batch(64, seed=5)
+    r = c.solve_batch(easy, efaces)
+    assert r["solved"].sum() > 50 and not np.any(r["status"] == abi.FH_ST_INTERRUPTED)
+    c.close()
+
+
+def test_deadline():
+    """fh_params.deadline_ms: a wall-clock budget for a launch (the reference's replan period is 10 ms, faster.yaml:5)."""
+    import torch  # noqa: F401
+
+    c = capi.Context(0)
+    par = abi.default_params()
+    par["deadline_ms"] = 10.0
+    c.set_params(par)
+    pr, faces = hard_problems(n=64)
+    easy, efaces, _ = corridor.whole_batch(256, seed=6)
+    allpr, allfaces = corridor.concat([(easy, efaces), (pr, faces)])
+    c.solve_batch(easy, efaces)           # (first launch: allocations)
+    t = time.perf_counter()
+    res = c.solve_batch(allpr, allfaces)
+    dur = time.perf_counter() - t
+    assert dur < 0.05, dur                # 10 ms budget + copies, not the seconds the hard problems would take
+    assert res["solved"][:256].sum() > 200                       # the easy ones were done long before the deadline
+    assert (res["status"][256:] == abi.FH_ST_INTERRUPTED).sum() >= 1
+    par["deadline_ms"] = 0.0
+    c.set_params(par)
+    r = c.solve_batch(easy, efaces)
+    assert not np.any(r["status"] == abi.FH_ST_INTERRUPTED)
+    c.close()
+
+
+def test_solver_hip_stop_execution_from_another_thread(tmp_path):
+    """The same through the C++ class: SolverHip::StopExecution() from another thread during genNewTraj() (tests/cpp/test_stop.cpp)."""
+    from faster_amd import build as fb
+
+    fb.build_all()
+    exe = os.path.join(ROOT, "tests", "cpp", "test_stop")
+    src = exe + ".cpp"
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(fb.HOST_SO)):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "faster_amd", "host"), src,
+                               "-o", exe, "-L", os.path.join(ROOT, "faster_amd"), "-lsolverhip", "-lfasterhip", "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
+    pr, faces = hard_problems(n=64)
+    probe = capi.Context(0)
+    hardest = int(np.argmax(probe.solve_batch(pr, faces)["nodes"]))   # (the 2.5e5-node problem: seconds even with 256 helpers)
+    probe.close()
+    p = pr[hardest]
+    lines = ["15 0.01 5 5 8 0.5", " ".join(repr(float(v)) for v in p["x0"]), " ".join(repr(float(v)) for v in p["xf"][:3]), str(int(p["n_poly"]))]
+    for k in range(int(p["n_poly"])):
+        f0, f1 = p["face_begin"] + p["face_off"][k], p["face_begin"] + p["face_off"][k + 1]
+        lines.append(str(f1 - f0))
+        for f in range(f0, f1):
+            lines.append("%r %r %r %r" % (float(faces["a"][f][0]), float(faces["a"][f][1]), float(faces["a"][f][2]), float(faces["b"][f])))
+    sc = tmp_path / "hard.txt"
+    sc.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=180)
+    print(r.stdout[-600:])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "STOP_OK" in r.stdout
