@@ -1251,7 +1251,7 @@ struct Solver {
   // Every FH_LOOK_EVERY-th node of a tree the worker looks around: has the host (StopExecution, another thread) or the deadline
   // asked to stop (a12, solverGurobi.cpp:15-39: the reference polls its flag in a Gurobi callback)?  Is somebody out of work?
   // returns bit 0: stop, bit 1: a worker without work is waiting for a frame
-  __device__ int look_around(const ShareArgs& sa) {
+  __device__ int look_around(const ShareArgs& sa, int local_nodes) {
     FH_SP_T0();
     int flags = 0;
     if (lane == 0) {
@@ -1263,8 +1263,8 @@ struct Solver {
       unsigned int stop = (unsigned int)ei | (unsigned int)(ei >> 32);
       if (!stop) {
         if (sa.deadline_ticks && wall_ticks() - t_start > sa.deadline_ticks) stop = 2u;
-        else if (sa.host_abort && (blockIdx.x & 31u) == 0u &&  // one workgroup in 32 reads the host's word (a PCIe round trip),
-                 __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stop = 1u;  // everybody reads ctl->interrupted
+        else if (sa.host_abort && (local_nodes & 15) == 0 &&  // the host's word costs a PCIe round trip: every 16th node of a tree
+                 __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stop = 1u;  // (everybody reads ctl->interrupted)
         if (stop) ast(&sa.ctl->interrupted, stop);
       }
       if (stop) flags = 1;
@@ -1388,7 +1388,7 @@ struct Solver {
         if (q_arrived(sa, pos)) state = 1;
         else if ((round & 7u) == 7u) {
           const unsigned int done = ald(&sa.ctl->done), err = ald(&sa.ctl->error);
-          if (!err && !ald(&sa.ctl->interrupted) && sa.host_abort && (blockIdx.x & 31u) == 0u &&
+          if (!err && !ald(&sa.ctl->interrupted) && sa.host_abort &&
               __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
             ast(&sa.ctl->interrupted, 1u);  // (an idle workgroup relays the host's stop request to the busy ones)
           if (err || done >= (unsigned)sa.total_units) state = 2;  // no frame will be published any more
@@ -1614,13 +1614,13 @@ struct Solver {
       // a tree that is already shared looks around twice as often, and a taker looks before its first node (it hands the other
       // children of its frame on at once if more takers are waiting)
       if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (entry == 1 && local_nodes == 1)) {
-        int fl = look_around(sa);
+        int fl = look_around(sa, local_nodes);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }
         // somebody is out of work: a problem that has proved hard (it already has a share record, or sa.min_nodes nodes so far)
         // gives its shallowest open frames away (at most two per look).  (sa.enabled is 0 with a work cap or a MIP gap.)
         if ((fl & 2) && depth > 0 && (rec >= 0 || nodes + local_nodes >= sa.min_nodes)) {
           donate(sa, ws, depth, best_cost);
-          if (rec >= 0 && (look_around(sa) & 2)) donate(sa, ws, depth, best_cost);
+          if (rec >= 0 && (look_around(sa, 1) & 2)) donate(sa, ws, depth, best_cost);
         }
       }
       if (rec >= 0) {  // shared tree: other workers' leaves prune here too

@@ -248,10 +248,13 @@ def test_stop_request_from_another_thread():
     assert (res["status"] == abi.FH_ST_INTERRUPTED).sum() >= 1 and np.all(res["solved"][res["status"] == abi.FH_ST_INTERRUPTED] == 0)
     print("stop latency %.3f ms (launch had run %.0f ms)" % (1e3 * latency, 1e3 * (out["dur"] - latency)))
     assert latency < 0.02, latency        # measured ~1 ms: poll every 2-4 nodes + D2H of the results
-    # the request stays raised: the next launch returns at once with every problem interrupted ...
+    # the request stays raised: the next launch returns at once — problems that a workgroup had drawn before the word was seen
+    # (one workgroup in 32 polls it) still finish if they take no time, the expensive ones are interrupted ...
     t = time.perf_counter()
     again = c.solve_batch(pr, faces)
-    assert time.perf_counter() - t < 0.05 and np.all(again["status"] == abi.FH_ST_INTERRUPTED)
+    assert time.perf_counter() - t < 0.05
+    assert (again["status"] == abi.FH_ST_INTERRUPTED).sum() >= 8 and again["status"][np.argmax(res["nodes"])] == abi.FH_ST_INTERRUPTED
+    assert np.all(again["nodes"][again["status"] != abi.FH_ST_INTERRUPTED] < 64)
     # ... until it is cleared (ResetToNormalState)
     c.clear_stop()
     easy, efaces, _ = corridor.whole_batch(64, seed=5)
