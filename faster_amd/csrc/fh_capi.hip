@@ -121,6 +121,10 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // LDS that another launch of the same device could use (12 launches in flight: 7.4 M pairs/s with 16, 7.0 M with 64, 5.9 M with 256).
   sa.max_hungry = std::max(8, ctx->n_cu / 16);
   sa.min_nodes = 16;
+  sa.backlog = 0;  // measured on C4: 16 / 64 / 256 pending frames cost 13-25 % at every number of launches in flight (hop overhead in the bulk)
+  sa.giant_nodes = 64;
+  if (const char* bl = getenv("FH_DEBUG_BACKLOG")) sa.backlog = atoi(bl);
+  if (const char* gn = getenv("FH_DEBUG_GIANT")) sa.giant_nodes = atoi(gn);
   if (const char* mh = getenv("FH_DEBUG_MAX_HUNGRY")) sa.max_hungry = atoi(mh);  // experiments only
   if (const char* mn = getenv("FH_DEBUG_MIN_NODES")) sa.min_nodes = atoi(mn);
   ka.par = ctx->par;

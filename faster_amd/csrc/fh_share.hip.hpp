@@ -20,13 +20,13 @@
 //                     committed taker, and a taker whose frame never comes leaves when all units are done.  A frame is the
 //                     parent node's dual active-set state (the same snapshot block the owner keeps per tree level), the
 //                     ordered list of untried children, the partial assignment and the DFS key of the parent;
-//   * ShareRec        one per problem that has given work away: incumbent (cost, DFS key, jerks, assignment) under a spin
-//                     lock, the number of outstanding parts of the current trial's tree, accumulated statistics.
-// Nobody ever waits for anybody: the part that brings `pending` to zero continues the problem (next factor trial, or the
-// final result), whichever workgroup that is.  Results do not depend on who explored what: the optimum of a trial is the
-// lexicographic minimum of (cost, DFS key) over all leaves, which is what the sequential depth-first search returns (it
-// keeps the FIRST leaf of minimal cost), and the jerks of a leaf depend only on the path from the root (every node
-// continues from a bit-exact copy of its parent's factorisation).
+//   * ShareRec        one per problem that has given work away: incumbent (trial, cost, DFS key, jerks, assignment) under a
+//                     spin lock, the number of outstanding parts of the problem's tree, accumulated statistics.
+// Nobody ever waits for anybody: the part that brings `pending` to zero writes the problem's result, whichever workgroup that
+// is.  Results do not depend on who explored what: the answer is the lexicographic minimum of (trial, cost, DFS key) over all
+// leaves — the first factor with a feasible trajectory, its cheapest leaf, and among equally cheap leaves the first in
+// depth-first order, which is what the sequential search returns — and the jerks of a leaf depend only on the path from the
+// root of its trial (every node continues from a bit-exact copy of its parent's factorisation).
 //
 // Every spin is bounded (FH_SPIN_LIMIT / a wall-clock watchdog): a protocol failure raises ShareCtl::error, all workers
 // leave, and the host reports FH_ERR_DEVICE instead of hanging the device.
@@ -67,22 +67,41 @@ struct ShareCtl {
 };
 static_assert(sizeof(ShareCtl) == 320, "five 64-byte lines");
 
+// The incumbent of a shared problem is ordered by (factor trial, cost, DFS key): genNewTraj() returns the FIRST factor of the
+// window with a feasible trajectory (solverGurobi.cpp:445-446), so a leaf of an earlier trial beats every leaf of a later one, and
+// the trials of a problem that has proved hard may run at the same time (the trial loop is the outermost level of the tree).
+// Lock-free readers prune with one monotonically decreasing word, the RANK = trial << 51 | (cost bits rounded UP) >> 13: a
+// rounded-up cost can only prune less; exact (cost, key) comparisons are made under the lock.
+#define FH_RANK_SHIFT 51
+#define FH_RANK_NONE (~0ull)
+__device__ __forceinline__ unsigned long long rank_pack(int trial, double cost) {
+  const unsigned long long b = ((unsigned long long)__double_as_longlong(cost) + 0x1fffull) >> 13;
+  return ((unsigned long long)(unsigned)trial << FH_RANK_SHIFT) | b;
+}
+__device__ __forceinline__ int rank_trial(unsigned long long r) { return (int)(r >> FH_RANK_SHIFT); }
+__device__ __forceinline__ double rank_cost_up(unsigned long long r) {
+  return __longlong_as_double((long long)((r & ((1ull << FH_RANK_SHIFT) - 1ull)) << 13));
+}
+
 struct ShareRec {  // 512 B
   unsigned int lock;
-  int pending;                    // outstanding parts of the current trial's tree (the owner's part + frames given away)
-  unsigned long long inc_cost;    // incumbent cost as double bits (+inf: none); costs are >= 0, so the bit patterns order like the values
-  unsigned long long inc_key;     // DFS key of the incumbent leaf
-  int nodes, iters;               // accumulated by finished parts (all trials of the problem)
-  unsigned int limit, pad0;       // FH_ST_* limit status of the current trial (0: none)
+  int pending;                    // outstanding parts of the problem's tree (the owner's part + frames given away, of every trial)
+  unsigned long long inc_rank;    // FH_RANK_NONE: no feasible leaf yet
+  unsigned long long inc_cost;    // exact cost of the incumbent (double bits), its DFS key, its factor and step: under the lock
+  unsigned long long inc_key;
+  double inc_f, inc_h;
+  int nodes, iters;               // accumulated by finished parts
+  unsigned int last_status, pad0; // status to report if no factor is feasible: FH_ST_INTERRUPTED, or a limit hit in the LAST trial
   unsigned long long flops;       // accumulated flop estimate
+  unsigned long long limited;     // bit min(t, 63): a wavefront hit a node / iteration limit in trial t (its leaves cannot win)
   double x[48];
   unsigned long long assign_lo, assign_hi;  // incumbent assignment, one byte per segment
-  unsigned int pad[16];
+  unsigned int pad[8];
 };
 static_assert(sizeof(ShareRec) == 512, "share record layout");
 
 // A task = 32 header words + the snapshot block.  Header words (all 8 bytes, written write-through by one lane):
-enum { TH_REC_B = 0,      // rec | b << 32
+enum { TH_REC_B = 0,      // rec | b << 32 (rec = -1: empty frame)
        TH_PHASE_DEPTH,    // phase | depth0 << 32
        TH_KEY,            // DFS key of the parent
        TH_H, TH_F, TH_BASE,   // doubles: step of the trial, its factor, max(dt_initial, 2 DC)
@@ -90,6 +109,8 @@ enum { TH_REC_B = 0,      // rec | b << 32
        TH_CNT_NEXT,       // cnt | next << 32
        TH_Q_QE,           // q_saved | qe << 32
        TH_ORDER, TH_ASSIGN_LO, TH_ASSIGN_HI,
+       TH_KIND,           // 0: a stack frame of a branch-and-bound tree (snapshot follows); 1: the remaining factor trials of a problem,
+                          //    starting with trial number `trials` - 1 at factor TH_F (no snapshot: a trial starts from its root)
        TH_WORDS = 32 };
 struct TaskHdr {
   unsigned long long w[TH_WORDS];
@@ -109,6 +130,10 @@ struct ShareArgs {
   int max_hungry;             // at most this many workgroups poll the queue; the others leave when the tickets are exhausted
   int min_nodes;              // a problem gives work away only after this many branch-and-bound nodes (all trials so far): small trees
                               // are cheaper to finish than to hand over (a hop costs about as much as 2-3 nodes)
+  int backlog;                // frames that may be published AHEAD of the takers: a problem that has proved hard does not have to wait
+                              // for the fresh problems to run out before it gets help — every workgroup looks for a pending frame
+                              // before it draws its next problem (the hard problems started early otherwise finish last, alone)
+  int giant_nodes;            // ... but only a problem that has already needed this many nodes publishes ahead of the takers
 };
 
 #define FH_AGENT __HIP_MEMORY_SCOPE_AGENT
@@ -159,7 +184,7 @@ __device__ __forceinline__ unsigned long long wall_ticks() { return __builtin_am
 __device__ inline unsigned long long q_reserve(const ShareArgs& sa) {
   const unsigned long long both = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
   const unsigned int waiters = (unsigned int)both, pos = (unsigned int)(both >> 32);
-  if (pos >= waiters) return ~0ull;                                                   // nobody is waiting for frame `pos`
+  if (pos >= waiters + (unsigned int)sa.backlog) return ~0ull;                        // enough frames are pending already
   if (ald(&sa.seqs[pos & (FH_QCAP - 1)]) != (unsigned long long)pos) return ~0ull;    // slot not released yet (ring full) or the number is gone
   unsigned int expect = pos;
   if (__hip_atomic_compare_exchange_strong(&sa.ctl->q_tail, &expect, pos + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) return pos;

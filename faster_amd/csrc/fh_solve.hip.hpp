@@ -1250,7 +1250,7 @@ struct Solver {
 
   // Every FH_LOOK_EVERY-th node of a tree the worker looks around: has the host (StopExecution, another thread) or the deadline
   // asked to stop (a12, solverGurobi.cpp:15-39: the reference polls its flag in a Gurobi callback)?  Is somebody out of work?
-  // returns bit 0: stop, bit 1: a worker without work is waiting for a frame
+  // returns bit 0: stop, bit 1: a frame may be published, bit 2: a workgroup without work is waiting right now, bits 8..13: how many
   __device__ int look_around(const ShareArgs& sa, int local_nodes) {
     FH_SP_T0();
     int flags = 0;
@@ -1268,26 +1268,28 @@ struct Solver {
         if (stop) ast(&sa.ctl->interrupted, stop);
       }
       if (stop) flags = 1;
-      else if (sa.enabled && waiters > tail) flags = 2;  // a taker is committed to a frame number nobody has published yet
+      else if (sa.enabled && tail < waiters + (unsigned int)sa.backlog)
+        flags = 2 | ((int)(waiters - tail) > 0 ? 4 : 0) | (min((int)(waiters - tail), 63) << 8);  // a taker is waiting (4: idle right now; count), or the backlog has room
     }
     FH_SP_ADD(prof, 0, 1);
     return uniform_i32(flags);
   }
 
-  // Give the shallowest stack frame that still has untried children to the queue: the children restart from the parent's
-  // factorisation (the snapshot of that level) exactly as they would have here.
-  __device__ void donate(const ShareArgs& sa, double* __restrict__ ws, int depth, double best_cost) {
-    FH_SP_T0();
-    const bool has = lane < depth && stk_next[lane < NSEG ? lane : 0] < stk_cnt[lane < NSEG ? lane : 0];
-    const int d = first_lane(has);
-    if (d < 0) return;
-    // a frame number first (one attempt): from here on a taker is committed to this number, so something MUST be published
+  int trial;        // 0-based index of the factor trial this worker is exploring
+  int trial_end;    // this worker goes on with the factors trial + 1 .. trial_end - 1 of the problem when the current trial is done
+                    // (the owner of a fresh problem: the whole window; the taker of a trial frame: its range; shrinks when trials are
+                    // given away; a taker of a tree frame has trial_end = trial + 1: nothing to go on with)
+
+  // First half of every donation.  A frame number first (ONE attempt): from then on a taker is committed to that number, so
+  // something MUST be published.  Then the problem's share record: created on its first donation (the incumbent and the
+  // bookkeeping move there), one more outstanding part otherwise.  ~0ull: nothing to publish (no taker, or no record left — an
+  // empty frame has been published for the taker).
+  __device__ unsigned long long begin_donation(const ShareArgs& sa, double best_cost) {
     unsigned long long pos = ~0ull;
     if (lane == 0) pos = q_reserve(sa);
     pos = uniform_u64(pos);
-    if (pos == ~0ull) return;
-    const bool fresh = rec < 0;
-    if (fresh) {  // the first frame this problem gives away: the incumbent and the bookkeeping move to a share record
+    if (pos == ~0ull) return pos;
+    if (rec < 0) {
       int r = -1;
       if (lane == 0) {
         const unsigned int got = aadd(&sa.ctl->rec_next, 1u);
@@ -1301,7 +1303,7 @@ struct Solver {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           q_publish(sa, pos);
         }
-        return;
+        return ~0ull;
       }
       ShareRec* R_ = sa.recs + r;
       unsigned long long alo, ahi;
@@ -1309,16 +1311,34 @@ struct Solver {
       if (lane < n) wt_store(&R_->x[lane], bestx_r);
       if (lane == 0) {
         ast(&R_->lock, 0u);
-        ast(&R_->pending, 2);  // this worker's part + the frame below
+        ast(&R_->pending, 2);  // this worker's part + the frame about to be published
+        ast(&R_->inc_rank, best_cost < INFINITY ? rank_pack(trial, best_cost) : FH_RANK_NONE);
         ast(&R_->inc_cost, f64_bits(best_cost));
         ast(&R_->inc_key, best_key);
-        ast(&R_->nodes, 0); ast(&R_->iters, 0); ast(&R_->limit, 0u); ast(&R_->flops, 0ull);
+        ast(reinterpret_cast<unsigned long long*>(&R_->inc_f), tb_lane0_64(TB_F));
+        ast(reinterpret_cast<unsigned long long*>(&R_->inc_h), f64_bits(h));
+        ast(&R_->nodes, 0); ast(&R_->iters, 0); ast(&R_->last_status, 0u); ast(&R_->flops, 0ull); ast(&R_->limited, 0ull);
         ast(&R_->assign_lo, alo); ast(&R_->assign_hi, ahi);
       }
       rec = r;
     } else if (lane == 0) {
       aadd(&(sa.recs + rec)->pending, 1);
     }
+    return pos;
+  }
+  // (lane 0 only) a 64-bit word of tb[]
+  __device__ __forceinline__ unsigned long long tb_lane0_64(int at) const { return ((unsigned long long)(unsigned)tb[at + 1] << 32) | (unsigned)tb[at]; }
+  static __device__ __forceinline__ unsigned long long pack2(int lo_, int hi_) { return (unsigned long long)(unsigned)lo_ | ((unsigned long long)(unsigned)hi_ << 32); }
+
+  // Give the shallowest stack frame that still has untried children to the queue: the children restart from the parent's
+  // factorisation (the snapshot of that level) exactly as they would have here.
+  __device__ void donate(const ShareArgs& sa, double* __restrict__ ws, int depth, double best_cost) {
+    FH_SP_T0();
+    const bool has = lane < depth && stk_next[lane < NSEG ? lane : 0] < stk_cnt[lane < NSEG ? lane : 0];
+    const int d = first_lane(has);
+    if (d < 0) return;
+    const unsigned long long pos = begin_donation(sa, best_cost);
+    if (pos == ~0ull) return;
     // partial assignment at the parent of frame d: the decisions of the frames d.. are undone; child order of the frame
     int a = -1;
     if (lane < N) {
@@ -1334,19 +1354,19 @@ struct Solver {
     const int qs = stk_q[d];
     TaskHdr* th = slot_hdr(sa, pos);
     if (lane == 0) {
-      const auto pk = [](int lo_, int hi_) { return (unsigned long long)(unsigned)lo_ | ((unsigned long long)(unsigned)hi_ << 32); };
-      wt_store(&th->w[TH_REC_B], pk(rec, tb[TB_B]));
-      wt_store(&th->w[TH_PHASE_DEPTH], pk(tb[TB_PHASE], depth0 + d));
+      wt_store(&th->w[TH_REC_B], pack2(rec, tb[TB_B]));
+      wt_store(&th->w[TH_PHASE_DEPTH], pack2(tb[TB_PHASE], depth0 + d));
       wt_store(&th->w[TH_KEY], prefix);
       wt_store(&th->w[TH_H], f64_bits(h));
-      wt_store(&th->w[TH_F], pk(tb[TB_F], tb[TB_F + 1]));
-      wt_store(&th->w[TH_BASE], pk(tb[TB_BASE], tb[TB_BASE + 1]));
-      wt_store(&th->w[TH_TRIALS_SEG], pk(tb[TB_TRIALS], stk_seg[d]));
-      wt_store(&th->w[TH_CNT_NEXT], pk(stk_cnt[d], stk_next[d]));
-      wt_store(&th->w[TH_Q_QE], pk(qs, qe));
+      wt_store(&th->w[TH_F], tb_lane0_64(TB_F));
+      wt_store(&th->w[TH_BASE], tb_lane0_64(TB_BASE));
+      wt_store(&th->w[TH_TRIALS_SEG], pack2(trial + 1, stk_seg[d]));
+      wt_store(&th->w[TH_CNT_NEXT], pack2(stk_cnt[d], stk_next[d]));
+      wt_store(&th->w[TH_Q_QE], pack2(qs, qe));
       wt_store(&th->w[TH_ORDER], olo);
       wt_store(&th->w[TH_ASSIGN_LO], alo);
       wt_store(&th->w[TH_ASSIGN_HI], ahi);
+      wt_store(&th->w[TH_KIND], 0ull);
     }
     // the parent's dual active-set state as snapshot_save left it (written by this wavefront: drain its stores first)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1365,22 +1385,78 @@ struct Solver {
     FH_SP_ADD(prof, 2, 1);
   }
 
+  // Give the remaining factor trials of the problem away (genNewTraj's loop `for (f = f_init; f <= f_final && !solved; f += f_inc)`,
+  // solverGurobi.cpp:445-446, is the outermost level of the problem's tree): the taker starts the next trial from its root while
+  // this one is still being explored, and passes the trials after that on in the same way.  Speculative — a later factor only
+  // matters if every earlier one turns out infeasible — so only problems that have proved hard do it, only while somebody is
+  // idle, and never once the current trial has a feasible leaf.  The reference rebuilds its model from scratch for every trial
+  // (:447-466): trials are independent.
+  template <class PR>
+  __device__ void donate_trials(const ShareArgs& sa, const PR& pr, double best_cost, int takers) {
+    if (best_cost < INFINITY || trial >= 4000) return;
+    // the trials this worker still owns after the current one: [trial + 1, end), end limited by the factor window
+    double fk = bits_f64(tb_get64(TB_F));
+    int end = trial + 1;
+    for (double f2 = fk + pr.f_inc; f2 <= pr.f_final && end < trial_end; f2 = f2 + pr.f_inc) end++;  // accumulated exactly as the loop does
+    int remaining = end - (trial + 1);
+    if (remaining <= 0) return;
+    // split them over the idle takers: consecutive ranges, published back to front so that this worker keeps what cannot be placed
+    if (takers < 1) takers = 1;
+    const int per = (remaining + takers - 1) / takers;
+    while (remaining > 0) {
+      const int k0 = max(trial + 1, end - per);  // this frame: trials [k0, end)
+      double f0 = fk;
+      for (int k = trial; k < k0; k++) f0 = f0 + pr.f_inc;
+      const unsigned long long pos = begin_donation(sa, best_cost);
+      if (pos == ~0ull) break;
+      TaskHdr* th = slot_hdr(sa, pos);
+      if (lane == 0) {
+        wt_store(&th->w[TH_REC_B], pack2(rec, tb[TB_B]));
+        wt_store(&th->w[TH_PHASE_DEPTH], pack2(tb[TB_PHASE], 0));
+        wt_store(&th->w[TH_F], f64_bits(f0));
+        wt_store(&th->w[TH_BASE], tb_lane0_64(TB_BASE));
+        wt_store(&th->w[TH_TRIALS_SEG], pack2(k0 + 1, end));
+        wt_store(&th->w[TH_KIND], 1ull);
+      }
+      drain_stores();
+      if (lane == 0) {
+        q_publish(sa, pos);
+        aadd(&sa.ctl->donated, 1u);
+        aadd(&sa.ctl->max_fill, 1u);  // (statistics: trial frames)
+      }
+      remaining -= end - k0;
+      end = k0;
+      trial_end = k0;
+    }
+  }
+
   // Out of fresh problems: draw a wait ticket and poll the slot the frame with that number will arrive in.  false: every unit
   // is done, enough others are waiting already, or the launch failed — leave.  On success the frame's snapshot is in workspace
   // level 0, the frame itself is stack level 0 in LDS (assignment at the parent, child order, untried children) and its header
   // words are in tb[]; nothing of it occupies registers while the problem is staged.
-  __device__ bool take_task(const ShareArgs& sa, double* __restrict__ ws) {
+  // returns 0: leave / nothing; 1: a stack frame of a tree; 2: the remaining trials of a problem (tb[]: TB_TRIALS - 1 = first
+  // trial, TB_F its factor).  idle: this workgroup has no fresh problem to draw (it waits for a frame); otherwise it only takes a
+  // frame that is pending right now (one compare-and-swap, only when there is one) and returns 0 at once if there is none.
+  __device__ int take_task(const ShareArgs& sa, double* __restrict__ ws, bool idle) {
    for (;;) {  // (an empty frame — its donor found no share record — sends the taker back for a new ticket)
     unsigned long long pos = ~0ull;
     int state = 0;  // 1: got a frame, 2: leave
     if (lane == 0) {
       const unsigned long long wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
       const unsigned int waiters = (unsigned int)wt, tail = (unsigned int)(wt >> 32);
-      if (waiters >= tail + (unsigned int)sa.max_hungry) state = 2;  // enough idle hands already (no ticket drawn: free to go)
-      else pos = (unsigned long long)aadd(&sa.ctl->wait_ticket, 1u);    // committed to frame number `pos` from here on
+      if (idle) {
+        if ((int)(waiters - tail) >= sa.max_hungry) state = 2;           // enough idle hands already (no ticket drawn: free to go)
+        else pos = (unsigned long long)aadd(&sa.ctl->wait_ticket, 1u);  // committed to frame number `pos` from here on
+      } else {
+        unsigned int expect = waiters;
+        if ((int)(tail - waiters) > 0 &&
+            __hip_atomic_compare_exchange_strong(&sa.ctl->wait_ticket, &expect, waiters + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT))
+          pos = (unsigned long long)waiters;  // frame `waiters` is published or about to be (its donor is copying it)
+        else state = 2;
+      }
     }
     state = uniform_i32(state);
-    if (state == 2) return false;
+    if (state == 2) return 0;
     const unsigned long long t0 = wall_ticks();
     FH_SP_T0();
     for (unsigned round = 0;; round++) {
@@ -1397,10 +1473,10 @@ struct Solver {
       }
       state = uniform_i32(state);
       if (state) break;
-      __builtin_amdgcn_s_sleep(127);  // ~4 us between polls of this workgroup's own word (8 us once nothing has come for a while)
-      if (round > 32) __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(32);  // ~1 us between polls of this workgroup's own word, ~5 us once nothing has come for a while
+      if (round > 64) __builtin_amdgcn_s_sleep(127);
     }
-    if (state == 2) return false;
+    if (state == 2) return 0;
     FH_SP_ADD(prof, 4, 1);
     pos = uniform_u64(pos);
 #ifdef FH_SHARE_PROFILE
@@ -1412,7 +1488,25 @@ struct Solver {
     const unsigned long long w_rec_b = cc_load(&hp->w[TH_REC_B]), w_phase_depth = cc_load(&hp->w[TH_PHASE_DEPTH]);
     if ((int)(unsigned)uniform_u64(w_rec_b) < 0) {
       if (lane == 0) q_release(sa, pos);
+      if (!idle) return 0;
       continue;
+    }
+    if (uniform_u64(cc_load(&hp->w[TH_KIND])) != 0ull) {  // the remaining trials of a problem: header only
+      const unsigned long long w_ts = cc_load(&hp->w[TH_TRIALS_SEG]);
+      if (lane == 0) {
+        tb[TB_REC] = (int)(unsigned)w_rec_b; tb[TB_B] = (int)(w_rec_b >> 32);
+        tb[TB_PHASE] = (int)(unsigned)w_phase_depth;
+        tb[TB_TRIALS] = (int)(unsigned)w_ts;
+        tb[TB_DEPTH0] = (int)(w_ts >> 32);  // (trial frames: the end of the range)
+        tb_put64(TB_F, cc_load(&hp->w[TH_F])); tb_put64(TB_BASE, cc_load(&hp->w[TH_BASE]));
+      }
+      drain_stores();
+      FH_SYNC();
+      if (lane == 0) {
+        q_release(sa, pos);
+        aadd(&sa.ctl->stolen, 1u);
+      }
+      return 2;
     }
     const unsigned long long w_trials_seg = cc_load(&hp->w[TH_TRIALS_SEG]), w_cnt_next = cc_load(&hp->w[TH_CNT_NEXT]);
     const unsigned long long w_q_qe = cc_load(&hp->w[TH_Q_QE]), w_order = cc_load(&hp->w[TH_ORDER]);
@@ -1444,7 +1538,7 @@ struct Solver {
       aadd(&sa.ctl->prof[7], 1ull);
 #endif
     }
-    return true;
+    return 1;
    }
   }
 
@@ -1456,13 +1550,14 @@ struct Solver {
     q = 0;  // (LDS factors are all zero after init_problem: nothing to clear when the snapshot is restored)
     depth0 = uniform_i32(tb[TB_DEPTH0]);
     cur_key = tb_get64(TB_KEY);
-    // the incumbent's cost prunes; its key is only compared under the record's lock (publish_incumbent), so that a torn
-    // (cost, key) pair can never prune a tie that the sequential search would have explored
-    best_cost = uniform_f64(bits_f64(ald(&(sa.recs + rec)->inc_cost)));
+    // the incumbent's (rounded-up) cost prunes; its key is only compared under the record's lock (publish_incumbent)
+    const unsigned long long r = uniform_u64(ald(&(sa.recs + rec)->inc_rank));
+    best_cost = rank_trial(r) == trial ? rank_cost_up(r) : INFINITY;  // (an incumbent of an earlier trial ends the search at its first node)
     best_key = ~0ull;
   }
 
-  // a better leaf was found by a worker of a shared tree: it enters the record if it beats the record lexicographically
+  // a better leaf was found by a worker of a shared problem: it enters the record if it beats the record lexicographically
+  // (trial, cost, DFS key)
   __device__ void publish_incumbent(const ShareArgs& sa, double cost) {
     ShareRec* R_ = sa.recs + rec;
     unsigned long long alo, ahi;
@@ -1470,9 +1565,10 @@ struct Solver {
     int take = 0;
     if (lane == 0) {
       if (rec_lock(sa, R_)) {
+        const int gt = rank_trial(ald(&R_->inc_rank));
         const double gc = bits_f64(ald(&R_->inc_cost));
         const unsigned long long gk = ald(&R_->inc_key);
-        take = (cost < gc || (cost == gc && best_key < gk)) ? 1 : 2;
+        take = (trial < gt || (trial == gt && (cost < gc || (cost == gc && best_key < gk)))) ? 1 : 2;
       }
     }
     take = uniform_i32(take);
@@ -1481,16 +1577,20 @@ struct Solver {
       if (lane == 0) {
         ast(&R_->assign_lo, alo); ast(&R_->assign_hi, ahi);
         ast(&R_->inc_key, best_key); ast(&R_->inc_cost, f64_bits(cost));
+        ast(reinterpret_cast<unsigned long long*>(&R_->inc_f), tb_lane0_64(TB_F));
+        ast(reinterpret_cast<unsigned long long*>(&R_->inc_h), f64_bits(h));
       }
+      drain_stores();
+      if (lane == 0) ast(&R_->inc_rank, rank_pack(trial, cost));  // last: what the lock-free readers prune with
       drain_stores();
     }
     if (take && lane == 0) rec_unlock(R_);
   }
 
-  // This worker's part of the current trial's tree is complete.  false: other parts are still being explored — whoever
-  // finishes last continues the problem.  true: this was the last part; nodes / iters / flops / limit / best_cost and the
-  // incumbent registers now hold the totals and the optimum of the trial.
-  __device__ bool finish_part(const ShareArgs& sa, int& nodes, int& iters, unsigned& limit, double& best_cost) {
+  // This worker has nothing more to do for the problem.  false: other parts of its tree are still being explored — whoever
+  // finishes last writes the result.  true: this was the last part; nodes / iters / flops hold the totals of the problem.
+  // limit: FH_ST_* limit status this worker ran into in its last search (0: none); last_trial: that search was the last factor.
+  __device__ bool finish_part(const ShareArgs& sa, int& nodes, int& iters, unsigned limit, bool last_trial) {
     FH_SP_T0();
     ShareRec* R_ = sa.recs + rec;
     int last = 0;
@@ -1499,7 +1599,7 @@ struct Solver {
       aadd(&R_->nodes, nodes);
       aadd(&R_->iters, iters);
       aadd(&R_->flops, flops);
-      if (limit) __hip_atomic_fetch_max(&R_->limit, limit, __ATOMIC_RELAXED, FH_AGENT);
+      if (limit == FH_ST_INTERRUPTED || (limit && last_trial)) __hip_atomic_fetch_max(&R_->last_status, limit, __ATOMIC_RELAXED, FH_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       last = __hip_atomic_fetch_sub(&R_->pending, 1, __ATOMIC_RELAXED, FH_AGENT) == 1 ? 1 : 0;
     }
@@ -1510,22 +1610,11 @@ struct Solver {
     nodes = uniform_i32(ald(&R_->nodes));
     iters = uniform_i32(ald(&R_->iters));
     flops = uniform_u64(ald(&R_->flops));
-    limit = (unsigned)uniform_i32((int)ald(&R_->limit));
-    best_cost = uniform_f64(bits_f64(ald(&R_->inc_cost)));
-    best_key = uniform_u64(ald(&R_->inc_key));
-    if (best_cost < INFINITY) {
-      const unsigned long long alo = uniform_u64(ald(&R_->assign_lo)), ahi = uniform_u64(ald(&R_->assign_hi));
-      if (lane < n) bestx_r = cc_load(&R_->x[lane]);
-      if (lane < NSEG) bestassign[lane] = unpack_byte(alo, ahi, lane);
-    }
-    if (lane == 0) {  // the totals travel with this worker from here on; the record starts the next trial empty
-      ast(&R_->nodes, 0); ast(&R_->iters, 0); ast(&R_->flops, 0ull); ast(&R_->limit, 0u);
-      ast(&R_->inc_cost, f64_bits(INFINITY)); ast(&R_->inc_key, ~0ull);
-      ast(&R_->pending, 1);
-    }
-    drain_stores();
-    FH_SYNC();
     return true;
+  }
+  // a node / iteration limit in the current trial of a shared problem: the trial's tree is incomplete, its leaves cannot win
+  __device__ void note_limited(const ShareArgs& sa) {
+    if (lane == 0) __hip_atomic_fetch_or(&(sa.recs + rec)->limited, 1ull << (trial < 63 ? trial : 63), __ATOMIC_RELAXED, FH_AGENT);
   }
 
   // ---- MIQP for one dt: depth-first branch and bound.  entry 0: from the root; entry 1: from the frame installed as
@@ -1611,21 +1700,34 @@ struct Solver {
       if (local_nodes >= par.max_nodes) { status_limit = FH_ST_NODE_LIMIT; break; }
       if (par.max_work > 0 && iters >= par.max_work) { status_limit = FH_ST_ITER_LIMIT; break; }
       local_nodes++;
-      // a tree that is already shared looks around twice as often, and a taker looks before its first node (it hands the other
-      // children of its frame on at once if more takers are waiting)
-      if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (entry == 1 && local_nodes == 1)) {
+      // a problem that is already shared looks around twice as often; a taker looks before its first node (it hands the other
+      // children of its frame, or the following trials, on at once if more takers are waiting)
+      if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (rec >= 0 && local_nodes == 1 && (entry == 1 || trial + 1 < trial_end))) {
         int fl = look_around(sa, local_nodes);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }
         // somebody is out of work: a problem that has proved hard (it already has a share record, or sa.min_nodes nodes so far)
-        // gives its shallowest open frames away (at most two per look).  (sa.enabled is 0 with a work cap or a MIP gap.)
-        if ((fl & 2) && depth > 0 && (rec >= 0 || nodes + local_nodes >= sa.min_nodes)) {
-          donate(sa, ws, depth, best_cost);
-          if (rec >= 0 && (look_around(sa, 1) & 2)) donate(sa, ws, depth, best_cost);
+        // gives its shallowest open frame away, and — once it is shared — the factor trials after this one, or a second frame.
+        // (sa.enabled is 0 with a work cap or a MIP gap.)
+        // (idle takers: nothing to lose by sharing early; no idle taker but room in the backlog: only the giants publish ahead)
+        if ((fl & 2) && ((fl & 4) ? (rec >= 0 || nodes + local_nodes >= 2) : (nodes + local_nodes >= sa.giant_nodes))) {
+          if (depth > 0) donate(sa, ws, depth, best_cost);
+          // ... and the factor trials after this one (a narrow tree may never have an open frame to give, but its trials are
+          // independent), or, when it has none left to give, a second frame
+          const int fl2 = look_around(sa, 1);
+          if (fl2 & 2) {
+            if (trial + 1 < trial_end) donate_trials(sa, pr, best_cost, (fl2 >> 8) & 63);
+            else if (rec >= 0 && depth > 0) donate(sa, ws, depth, best_cost);
+          }
         }
       }
-      if (rec >= 0) {  // shared tree: other workers' leaves prune here too
-        const double gc = uniform_f64(bits_f64(ald(&(sa.recs + rec)->inc_cost)));
-        if (gc < best_cost) { best_cost = gc; best_key = ~0ull; }
+      if (rec >= 0) {  // shared problem: other workers' leaves prune here too
+        const unsigned long long r = uniform_u64(ald(&(sa.recs + rec)->inc_rank));
+        const int rt = rank_trial(r);
+        if (rt < trial) break;  // an EARLIER factor already has a feasible trajectory: nothing in this trial can win
+        if (rt == trial) {
+          const double gc = rank_cost_up(r);
+          if (gc < best_cost) { best_cost = gc; best_key = ~0ull; }
+        }
       }
       double cost = 0;
       const int st = qp_run(best_cost * (1.0 - par.mip_gap), cur_key > best_key, par.max_iters, iters, cost);  // mip_gap 0 (default): exact
@@ -1719,6 +1821,12 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     return true;
   }
 
+#ifdef FH_SHARE_PROFILE
+  if (entry == 0 && lane == 0) {
+    const unsigned long long t00 = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
+    res.coeff[FH_MAX_SEG - 1][8] = (double)(wall_ticks() - t00) / 100.0;
+  }
+#endif
   sv.N = pr.n_seg;
   sv.n = 3 * pr.n_seg;
   sv.P = pr.n_poly;
@@ -1770,54 +1878,98 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
 #ifdef FH_PROFILE
   sv.prof[0] = __builtin_readcyclecounter() - tstart__;
 #endif
-  int trials = entry ? uniform_i32(sv.tb[sv.TB_TRIALS]) : 0, nodes = 0, iters = 0, status = FH_ST_INFEASIBLE;
+  // entry 0: a fresh problem, from its first factor.  entry 1: a stack frame of the tree of trial tb[TB_TRIALS] - 1 taken from the
+  // queue.  entry 2: the trials of the problem from number tb[TB_TRIALS] - 1 (factor tb[TB_F]) on, taken from the queue.
+  int trials = entry ? uniform_i32(sv.tb[sv.TB_TRIALS]) - 1 : 0, nodes = 0, iters = 0, status = FH_ST_INFEASIBLE;  // trials run before the current one
   bool solved = false;
   double f = entry ? sv.bits_f64(sv.tb_get64(sv.TB_F)) : pr.f_init, dt = 0, factor = 0, cost = 0;
   sv.rec = entry ? uniform_i32(sv.tb[sv.TB_REC]) : -1;
+  sv.trial_end = entry == 0 ? 0x7fffffff : (entry == 2 ? uniform_i32(sv.tb[sv.TB_DEPTH0]) : 0);  // (entry 1: nothing beyond its trial)
   sv.flops = 0ull;
   if (lane == 0) sv.tb_put64(sv.TB_BASE, sv.f64_bits(base));
+  unsigned limit = 0u;
+  bool last_trial = false;
   for (;;) {  // genNewTraj :445-446: for (f = f_init; f <= f_final && !solved; f = f + f_inc)
-    if (entry == 0) {
-      if (!(f <= pr.f_final)) break;
-      trials++;
+    if (entry != 1) {
+      if (!(f <= pr.f_final) || trials >= sv.trial_end) break;
+      if (sv.rec >= 0 && rank_trial(sv.uniform_u64(ald(&(sa.recs + sv.rec)->inc_rank))) <= trials) break;  // an earlier factor is feasible already
       dt = f * base;
     } else {
       dt = sv.bits_f64(sv.tb_get64(sv.TB_H));
     }
+    sv.trial = trials;
+    trials++;
+    last_trial = !(f + pr.f_inc <= pr.f_final);
     sv.h = dt;
-    if (lane == 0) {  // what a frame given away by this trial has to say about the problem
-      sv.tb_put64(sv.TB_F, sv.f64_bits(f));
-      sv.tb[sv.TB_TRIALS] = trials;
-    }
+    if (lane == 0) sv.tb_put64(sv.TB_F, sv.f64_bits(f));  // (what a frame given away by this trial has to say about it)
     { FH_T0(); sv.setup_trial(pr);
 #ifdef FH_PROFILE
       sv.prof[1] += __builtin_readcyclecounter() - t0__; sv.cnt[1] += 1;
 #endif
     }
     double best = INFINITY;
-    if (entry) sv.install_frame(pr, sa, best);
+    if (entry == 1) sv.install_frame(pr, sa, best);
 #ifdef FH_SHARE_PROFILE
     const bool sp_taken__ = entry != 0;
     const unsigned long long sp_ts__ = wall_ticks();
     const int sp_n0__ = nodes;
     if (sp_taken__ && lane == 0) { aadd(&sa.ctl->prof2[0], sp_ts__ - sp_tp__); aadd(&sa.ctl->prof2[1], 1ull); }
 #endif
-    const int st = sv.search(pr, par, sa, ws, entry, best, nodes, iters);
+    const int st = sv.search(pr, par, sa, ws, entry == 1 ? 1 : 0, best, nodes, iters);
 #ifdef FH_SHARE_PROFILE
     if (sp_taken__ && lane == 0) { aadd(&sa.ctl->prof2[2], wall_ticks() - sp_ts__); aadd(&sa.ctl->prof2[3], (unsigned long long)(nodes - sp_n0__)); }
 #endif
     entry = 0;
-    unsigned limit = (st == FH_ST_NODE_LIMIT || st == FH_ST_ITER_LIMIT || st == FH_ST_INTERRUPTED) ? (unsigned)st : 0u;
-    if (sv.rec >= 0 && !sv.finish_part(sa, nodes, iters, limit, best)) return false;
-    status = limit ? (int)limit : (best < INFINITY ? FH_ST_OPTIMAL : FH_ST_INFEASIBLE);
-    if (status == FH_ST_OPTIMAL) {
-      solved = true;
-      factor = f;
-      cost = best;
-      break;
+    limit = (st == FH_ST_NODE_LIMIT || st == FH_ST_ITER_LIMIT || st == FH_ST_INTERRUPTED) ? (unsigned)st : 0u;
+    if (sv.rec < 0) {  // nothing of this problem was given away: the sequential rule, in registers
+      status = limit ? (int)limit : (best < INFINITY ? FH_ST_OPTIMAL : FH_ST_INFEASIBLE);
+      if (status == FH_ST_OPTIMAL) {
+        solved = true;
+        factor = f;
+        cost = best;
+        break;
+      }
+      if (status == FH_ST_INTERRUPTED || (par.max_work > 0 && status == FH_ST_ITER_LIMIT)) break;
+      f = f + pr.f_inc;
+      continue;
     }
-    if (status == FH_ST_INTERRUPTED || (par.max_work > 0 && status == FH_ST_ITER_LIMIT)) break;
+    // shared problem: its leaves are in the record.  This worker goes on with the next factor if the following trials are still
+    // its own and no factor up to this one has a feasible leaf (other parts of this trial may still be running elsewhere: the
+    // next trial then starts speculatively, like the ones that were given away).
+    if (limit && limit != FH_ST_INTERRUPTED) sv.note_limited(sa);
+    if (trials >= sv.trial_end || limit == FH_ST_INTERRUPTED || best < INFINITY) break;
     f = f + pr.f_inc;
+  }
+  if (sv.rec >= 0) {
+    if (!sv.finish_part(sa, nodes, iters, limit, last_trial)) return false;  // the problem's tree is still being explored elsewhere
+    // the last part: the answer is the record's incumbent (first feasible factor, cheapest leaf, first in depth-first order)
+    const ShareRec* R_ = sa.recs + sv.rec;
+    const unsigned long long r = sv.uniform_u64(ald(&R_->inc_rank));
+    const unsigned long long limited = sv.uniform_u64(ald(&R_->limited));
+    const unsigned int last_status = (unsigned int)uniform_i32((int)ald(&R_->last_status));
+    const int wt = rank_trial(r);
+    solved = r != FH_RANK_NONE && last_status != FH_ST_INTERRUPTED && !((limited >> (wt < 63 ? wt : 63)) & 1ull);
+    if (solved) {
+      status = FH_ST_OPTIMAL;
+      trials = wt + 1;
+      cost = uniform_f64(sv.bits_f64(ald(&R_->inc_cost)));
+      factor = uniform_f64(sv.bits_f64(ald(reinterpret_cast<const unsigned long long*>(&R_->inc_f))));
+      dt = uniform_f64(sv.bits_f64(ald(reinterpret_cast<const unsigned long long*>(&R_->inc_h))));
+      const unsigned long long alo = sv.uniform_u64(ald(&R_->assign_lo)), ahi = sv.uniform_u64(ald(&R_->assign_hi));
+      if (lane < sv.n) sv.bestx_r = cc_load(&R_->x[lane]);
+      if (lane < NSEG) sv.bestassign[lane] = sv.unpack_byte(alo, ahi, lane);
+      sv.h = dt;
+      sv.setup_trial(pr);  // the zero-jerk states of the winning step (this worker may have been exploring another trial)
+    } else {  // no factor of the window is feasible (or the search was cut short): trials_ and dt_ of the last trial of the window
+      // (a limit in the winning trial disqualifies its leaves — the sequential search would have gone on to the next factor, which
+      // cannot be reconstructed here: reported as not solved.  Otherwise the status of the last trial, as the sequential loop leaves it.)
+      status = (r != FH_RANK_NONE && last_status != FH_ST_INTERRUPTED) ? FH_ST_NODE_LIMIT : (last_status ? (int)last_status : FH_ST_INFEASIBLE);
+      trials = 0;
+      for (double fk = pr.f_init; fk <= pr.f_final; fk = fk + pr.f_inc) {
+        trials++;
+        dt = fk * base;
+      }
+    }
   }
 
   if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
@@ -1834,6 +1986,9 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
       const int o = 3 * t + i;
       v = kind == 0 ? sv.x[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
     }
+#ifdef FH_SHARE_PROFILE
+    if (idx == (FH_MAX_SEG - 1) * 12 + 8) continue;  // (diagnostic: the owner's start time, written when the problem was begun)
+#endif
     res.coeff[t][rem] = v;
   }
 #ifdef FH_PROFILE
@@ -1846,6 +2001,14 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     unsigned int cv = 0;
     for (int i = 0; i < 12; i++) cv = (i == lane) ? sv.cnt[i] : cv;
     res.coeff[FH_MAX_SEG - 2][lane] = (double)cv;
+  }
+#endif
+#ifdef FH_SHARE_PROFILE
+  if (lane == 0 && sv.N < FH_MAX_SEG) {  // diagnostic: when (us since this workgroup started) the problem began here / ended, shared?
+    const unsigned long long t00 = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
+    res.coeff[FH_MAX_SEG - 1][11] = (double)(wall_ticks() - t00) / 100.0;
+    res.coeff[FH_MAX_SEG - 1][10] = (double)(sp_tp__ - t00) / 100.0;
+    res.coeff[FH_MAX_SEG - 1][9] = sv.rec >= 0 ? 1.0 : 0.0;
   }
 #endif
   if (lane < FH_MAX_SEG) res.assign[lane] = (solved && lane < sv.N && sv.P > 0) ? (int8_t)sv.bestassign[lane] : (int8_t)-1;
@@ -1905,7 +2068,14 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
   for (;;) {
     int entry = 0, unit = 0, phase = 0;
     bool interrupted = false;
-    if (tickets_left) {
+    // a frame of a hard problem comes before a fresh problem; without fresh problems the workgroup waits for frames
+    if (sa.enabled && (sa.backlog > 0 || !tickets_left)) entry = sv.take_task(sa, ws, !tickets_left);
+    if (entry) {
+      unit = uniform_i32(sv.tb[sv.TB_B]);
+      phase = uniform_i32(sv.tb[sv.TB_PHASE]);
+    } else if (!tickets_left) {
+      break;  // every unit is done (or enough others are waiting, or sharing is off)
+    } else {
       unsigned int b = 0, intr = 0;
       if (threadIdx.x == 0) {
         b = (unsigned int)min(aadd(&sa.ctl->ticket, 1ull), (unsigned long long)ka.n);
@@ -1927,17 +2097,11 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
 #ifdef FH_SHARE_PROFILE
         sp_dry__ = wall_ticks();
 #endif
+        continue;
       } else {
         unit = (int)b;
         if (threadIdx.x == 0) { sv.tb[sv.TB_B] = unit; sv.tb[sv.TB_PHASE] = 0; }
       }
-    }
-    if (!tickets_left) {
-      if (!sa.enabled) break;
-      if (!sv.take_task(sa, ws)) break;
-      entry = 1;
-      unit = uniform_i32(sv.tb[sv.TB_B]);
-      phase = uniform_i32(sv.tb[sv.TB_PHASE]);
     }
     // (wave-uniform by construction; said explicitly because the divergence analysis loses it across this loop nest and would keep
     // these — and every address derived from them — in vector registers)
