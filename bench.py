@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--pipeline", choices=["fused", "split"], default="fused",
                     help="fused: one launch per step, each unit of work is a pair taken through whole solve, hand-off and safe solve; "
                          "split: whole launch -> hand-off launch -> safe launch (same results)")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     ap.add_argument("--no-share", action="store_true", help="one wavefront per problem (fh_params.share = 0)")
     args = ap.parse_args()

@@ -2128,10 +2128,14 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
       if (!finished) break;  // the unit continues in another workgroup
       if constexpr (PAIRS) {
         if (phase == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-          pair_glue_one(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.safe[unit],
-                        ka.sfaces, (int)threadIdx.x);
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+          // the whole result was written by this wavefront (plain stores): drained, then read back by the hand-off
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          pair_glue_one<true>(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.safe[unit],
+                              ka.sfaces, (int)threadIdx.x);
+          // the safe problem went out write-through: drained, then this CU's stale L1 lines dropped (a neighbouring record may
+          // share a line); a workgroup that takes a frame of it later acquires in take_task
+          drain_stores();
+          acquire_agent();
           phase = 1;
           entry = 0;
           if (threadIdx.x == 0) sv.tb[sv.TB_PHASE] = 1;

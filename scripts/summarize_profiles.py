@@ -12,14 +12,15 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-# 1. kernel stats (rocprofv3 --kernel-trace --stats)
-for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
-    rows = list(csv.DictReader(open(f)))
-    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as o:
-        w = csv.DictWriter(o, fieldnames=rows[0].keys())
-        w.writeheader()
-        w.writerows(rows)
-    print("kernel stats:", [(r["Name"][:40], r["Calls"], r["AverageNs"]) for r in rows[:4]])
+# 1. kernel stats (rocprofv3 --kernel-trace --stats): the driver's configuration, and one batch at a time ("solo")
+for sub, suffix in (("stats", "_kernel_stats.csv"), ("stats_solo", "_kernel_stats_solo.csv")):
+    for f in glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(dst, tag + suffix), "w") as o:
+            w = csv.DictWriter(o, fieldnames=rows[0].keys())
+            w.writeheader()
+            w.writerows(rows)
+        print(sub, "kernel stats:", [(r["Name"][:44], r["Calls"], r["AverageNs"]) for r in rows[:4]])
 
 # 2. PMC counters, summed over the dimension instances, averaged per dispatch of each kernel
 summary = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -45,6 +46,7 @@ if sk and "FETCH_SIZE" in out[sk] and "WRITE_SIZE" in out[sk]:
     # the bytes of a wide coalesced read => doubled.  WRITE_SIZE is uncalibrated (taken as is).
     fetch = out[sk]["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2
     write = out[sk]["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+    out["_kernel"] = sk
     out["_hbm_traffic_per_launch_bytes"] = {"kernel": sk, "fetch_corrected": fetch, "write": write, "total": fetch + write,
                                             "note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported; KiB units"}
 json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
