@@ -164,17 +164,33 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
   const int src0 = P ? pw.face_off[start] : 0;
   const int total = P ? pw.face_off[start + cnt] - src0 : 0;
   const int first_end = P ? pw.face_off[start + 1] - src0 : 0;  // rows of the polytope that holds R
-  for (int f = lane; f < total; f += 64) {
-    fh_face fc = wfaces[fb + src0 + f];
-    const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-    double b = fc.b - shrink * nr;
-    if (keep_r && f < first_end) {
-      const double ar = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2];
-      b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
+  if (WT) {
+    // write-through stores are one fabric write per separate piece: lane = one DOUBLE of the output (4 per face row), so that an
+    // instruction writes 512 contiguous bytes (a lane per face row, 8 bytes at a stride of 32, cost 8x the HBM write traffic)
+    double* out = reinterpret_cast<double*>(sfaces + fb);
+    for (int j = lane; j < 4 * total; j += 64) {
+      const int f = j >> 2, c = j & 3;
+      const fh_face fc = wfaces[fb + src0 + f];
+      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+      double b = fc.b - shrink * nr;
+      if (keep_r && f < first_end) {
+        const double ar = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2];
+        b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
+      }
+      glue_store<true>(out + j, c == 0 ? fc.a[0] : (c == 1 ? fc.a[1] : (c == 2 ? fc.a[2] : b)));
     }
-    fc.b = b;
-    fh_face* dst = &sfaces[fb + f];
-    glue_store<WT>(&dst->a[0], fc.a[0]); glue_store<WT>(&dst->a[1], fc.a[1]); glue_store<WT>(&dst->a[2], fc.a[2]); glue_store<WT>(&dst->b, fc.b);
+  } else {
+    for (int f = lane; f < total; f += 64) {
+      fh_face fc = wfaces[fb + src0 + f];
+      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+      double b = fc.b - shrink * nr;
+      if (keep_r && f < first_end) {
+        const double ar = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2];
+        b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
+      }
+      fc.b = b;
+      sfaces[fb + f] = fc;
+    }
   }
   if (lane <= FH_MAX_POLY) {
     const int p = lane < cnt ? lane : cnt;

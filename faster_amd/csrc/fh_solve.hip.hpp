@@ -2112,11 +2112,18 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
     for (;;) {  // the problems of the unit (a pair has two)
       bool finished;
       if constexpr (PAIRS) {
-        const fh_problem* pr = phase ? &ka.safe[unit] : &problems[unit];
-        const fh_face* fcs = phase ? ka.sfaces : faces;
-        fh_result* out = phase ? &ka.sres[unit] : &results[unit];
-        finished = run_problem<NSEG, fh_problem>(sv, *pr, fcs, ka.max_faces, ka.par, sa, ws, entry, interrupted, *out);
-      } else {
+        // The problem record of a pair launch may have been written inside this launch (the safe problem, by this or another
+        // workgroup, write-through): the scalar data cache is invalidated, after which the record is read like the read-only
+        // records of a plain launch — uniform scalar loads through the constant address space (a generic pointer would keep the
+        // address and every field in vector registers: 130 spilled VGPRs).  A record does not change while it is being solved.
+        __builtin_amdgcn_s_dcache_inv();
+        typedef const __attribute__((address_space(4))) fh_problem const_problem;
+        const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(phase ? &ka.safe[unit] : &problems[unit]));
+        const fh_face* fcs = reinterpret_cast<const fh_face*>(sv.uniform_u64((unsigned long long)(phase ? ka.sfaces : faces)));
+        fh_result* out = reinterpret_cast<fh_result*>(sv.uniform_u64((unsigned long long)(phase ? &ka.sres[unit] : &results[unit])));
+        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ws, entry, interrupted, *out);
+      }
+      else {
         // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
         // the uniform loads on the scalar unit (s_load) although the kernel contains fences and atomics, after which the
         // compiler no longer treats `const __restrict__` global memory as unclobbered (132 vector loads instead of 28 scalar ones).
@@ -2131,11 +2138,11 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
           // the whole result was written by this wavefront (plain stores): drained, then read back by the hand-off
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           pair_glue_one<true>(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.safe[unit],
-                              ka.sfaces, (int)threadIdx.x);
-          // the safe problem went out write-through: drained, then this CU's stale L1 lines dropped (a neighbouring record may
-          // share a line); a workgroup that takes a frame of it later acquires in take_task
+                              ka.sfaces, opaque((int)threadIdx.x));
+          // the safe problem went out write-through and is drained: this wavefront reads its own stores back (a CU's L1 follows
+          // that CU's stores; no agent-scope acquire here — it made every pair drop the CU's L1 and, measured, 0.5 GB of dirty
+          // snapshot lines per launch leave L2); a workgroup that takes a frame of it later acquires in take_task
           drain_stores();
-          acquire_agent();
           phase = 1;
           entry = 0;
           if (threadIdx.x == 0) sv.tb[sv.TB_PHASE] = 1;
