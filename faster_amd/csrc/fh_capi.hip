@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,7 +35,9 @@ struct fh_ctx {
   size_t lds_attr[6] = {0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
   unsigned int* d_abort = nullptr;          // its device address
+  unsigned int* h_report = nullptr;         // pinned: the control block's report words of the last launch (copied with the results)
   double pair_margin = -1.0;                // fh_set_pair_margin
+  bool ctl_ready = false;                   // the device-side control block is in its initial state (left so by the previous launch)
   bool launched = false;                    // a solve launch has been issued since the control block was last checked
   int last_grid = 0;
 };
@@ -77,8 +80,9 @@ static int ensure(fh_ctx* ctx, int slot, size_t bytes) {
   return FH_OK;
 }
 
-// Re-initialises the work-sharing state before EVERY solve launch (ticket, counters, ring head/tail and sequence numbers):
-// nothing persists between launches, so a failed launch cannot poison the next one.
+// Initialises the work-sharing state (ticket, counters, hand-off counters, ring sequence numbers) before the FIRST solve launch of
+// a context and after a launch that could not be issued; every launch leaves the block initialised for the next one (its last
+// workgroup resets it: solve_kernel), so nothing a launch did can poison the next.
 __global__ void share_init_kernel(fh::ShareCtl* ctl, unsigned long long* seqs) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (unsigned)FH_QCAP) seqs[i] = (unsigned long long)i;
@@ -103,6 +107,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   int rc;
   if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * SV::SNAP_PADDED)) != FH_OK) return rc;
   const size_t slot_stride = sizeof(fh::TaskHdr) + sizeof(double) * (size_t)SV::SNAP_PADDED;
+  if (!ctx->d_buf[6]) ctx->ctl_ready = false;
   if ((rc = ensure(ctx, 6, 4096 + sizeof(unsigned long long) * FH_QCAP)) != FH_OK) return rc;
   if ((rc = ensure(ctx, 8, slot_stride * FH_QCAP)) != FH_OK) return rc;
   if ((rc = ensure(ctx, 9, sizeof(fh::ShareRec) * FH_NRECS)) != FH_OK) return rc;
@@ -145,8 +150,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
         ctx->ev.push_back(e);
       }
   }
-  hipLaunchKernelGGL(share_init_kernel, dim3((FH_QCAP + 255) / 256), dim3(256), 0, ctx->stream, sa.ctl, sa.seqs);
-  FH_HIP(hipGetLastError());
+  if (!ctx->ctl_ready) {
+    hipLaunchKernelGGL(share_init_kernel, dim3((FH_QCAP + 255) / 256), dim3(256), 0, ctx->stream, sa.ctl, sa.seqs);
+    FH_HIP(hipGetLastError());
+  }
+  ctx->ctl_ready = false;  // (true again once the launch below has been issued: it resets the block when it ends)
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, d_results, ka);
@@ -154,6 +162,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   FH_HIP(hipEventRecord(e1, ctx->stream));
   ctx->ev_used += 2;
   ctx->launched = true;
+  ctx->ctl_ready = true;
   ctx->last_grid = grid;
   return FH_OK;
 }
@@ -164,8 +173,8 @@ static int check_share_error(fh_ctx* ctx) {
   ctx->launched = false;
   fh::ShareCtl h;
   FH_HIP(hipMemcpy(&h, ctx->d_buf[6], sizeof(h), hipMemcpyDeviceToHost));
-  if (h.error) {
-    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(h.error) + "); results of the launch are incomplete";
+  if (h.report[5]) {
+    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(h.report[5]) + "); results of the launch are incomplete";
     return FH_ERR_DEVICE;
   }
   return FH_OK;
@@ -222,6 +231,7 @@ int fh_create(fh_ctx** out, int device) {
   FH_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_abort), 64, hipHostMallocMapped | hipHostMallocCoherent));
   *ctx->h_abort = 0u;
   FH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_abort), ctx->h_abort, 0));
+  FH_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_report), 64, hipHostMallocDefault));
   return FH_OK;
 }
 
@@ -232,6 +242,7 @@ void fh_destroy(fh_ctx* ctx) {
     for (int i = 0; i < 10; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
+    if (ctx->h_report) (void)hipHostFree(ctx->h_report);
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   }
@@ -302,12 +313,12 @@ int fh_share_stats_read(fh_ctx* ctx, fh_share_stats* out) {
   FH_HIP(hipStreamSynchronize(ctx->stream));
   fh::ShareCtl h;
   FH_HIP(hipMemcpy(&h, ctx->d_buf[6], sizeof(h), hipMemcpyDeviceToHost));
-  out->donated = h.donated; out->stolen = h.stolen; out->queue_full = h.q_full; out->records_full = h.rec_full;
-  out->records_used = std::min<unsigned>(h.rec_next, FH_NRECS); out->error = h.error; out->interrupted = h.interrupted;
+  out->donated = h.report[0]; out->stolen = h.report[1]; out->queue_full = h.report[2]; out->records_full = h.report[3];
+  out->records_used = std::min<unsigned>(h.report[4], FH_NRECS); out->error = h.report[5]; out->interrupted = h.report[6];
   out->workgroups = (uint32_t)ctx->last_grid;
   ctx->launched = false;
-  if (h.error) {
-    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(h.error) + ")";
+  if (h.report[5]) {
+    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(h.report[5]) + ")";
     return FH_ERR_DEVICE;
   }
   return FH_OK;
@@ -401,8 +412,16 @@ int fh_solve_batch(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces
                              (fh_result*)ctx->d_buf[2]);
   if (rc != FH_OK) return rc;
   FH_HIP(hipMemcpyAsync(results, ctx->d_buf[2], sizeof(fh_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  // the launch's report words ride along with the results (one synchronisation for a single genNewTraj())
+  FH_HIP(hipMemcpyAsync(ctx->h_report, reinterpret_cast<unsigned char*>(ctx->d_buf[6]) + offsetof(fh::ShareCtl, report), 64,
+                        hipMemcpyDeviceToHost, ctx->stream));
   FH_HIP(hipStreamSynchronize(ctx->stream));
-  return check_share_error(ctx);
+  ctx->launched = false;
+  if (ctx->h_report[5]) {
+    ctx->err = "solve kernel: work-sharing protocol failure (code " + std::to_string(ctx->h_report[5]) + "); results of the launch are incomplete";
+    return FH_ERR_DEVICE;
+  }
+  return FH_OK;
 }
 
 int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n,

@@ -52,7 +52,8 @@ struct ShareCtl {
   unsigned long long ticket;  // next fresh unit
   unsigned int rec_next;      // share records handed out
   unsigned int donated, stolen, q_full, rec_full, lock_spins, max_fill;  // statistics
-  unsigned int pad1[7];
+  unsigned int exited;        // workgroups that have left the kernel: the last one re-initialises this block for the next launch
+  unsigned int pad1[6];
   // ---- line 2: the hand-off counters (zeroed before every launch; written only when a worker runs out of problems or a frame
   // is published, read by the busy workers every few nodes) ----
   unsigned int wait_ticket;  // wait tickets drawn: takers committed to frame numbers 0 .. wait_ticket-1   } one aligned 8-byte
@@ -64,8 +65,10 @@ struct ShareCtl {
   // ---- line 4: [0,1] staging + trial set-up of a taken frame until its first node, [2,3] searching taken frames (ticks, nodes),
   // [4,5] finish_part (ticks, count), [6] ticks of workers between "tickets exhausted" and leaving, [7] workers that left ----
   unsigned long long prof2[8];
+  // ---- line 5: what the host reads after a launch (copied here by the last workgroup before it resets lines 0-2) ----
+  unsigned int report[16];  // donated, stolen, q_full, rec_full, records used, error, interrupted, trial frames
 };
-static_assert(sizeof(ShareCtl) == 320, "five 64-byte lines");
+static_assert(sizeof(ShareCtl) == 384, "six 64-byte lines");
 
 // The incumbent of a shared problem is ordered by (factor trial, cost, DFS key): genNewTraj() returns the FIRST factor of the
 // window with a feasible trajectory (solverGurobi.cpp:445-446), so a leaf of an earlier trial beats every leaf of a later one, and

@@ -34,7 +34,7 @@ namespace fh {
 
 // every FH_LOOK_EVERY-th node of a tree the worker reads the control block (stop request, hungry workers): power of two
 #ifndef FH_LOOK_EVERY
-#define FH_LOOK_EVERY 4
+#define FH_LOOK_EVERY 8
 #endif
 
 // A workgroup is ONE wavefront (launch bounds 64): its LDS operations are issued and performed in program order, so what a
@@ -2156,6 +2156,25 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
 #ifdef FH_SHARE_PROFILE
   if (threadIdx.x == 0 && sp_dry__) { aadd(&sa.ctl->prof2[6], wall_ticks() - sp_dry__); aadd(&sa.ctl->prof2[7], 1ull); }
 #endif
+  // The last workgroup to leave hands the control block to the next launch of this context in its initial state (counters zero,
+  // ring sequence numbers i), after copying what the host wants to read.  No separate initialisation kernel per launch: on a
+  // chip whose vector registers are all held by persistent workgroups of other launches, such a tiny kernel waited milliseconds
+  // for a slot (rocprofv3: 12 ms average with 8 launches in flight), and a single genNewTraj() paid a second launch.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int last = 0;
+  if (threadIdx.x == 0) last = aadd(&sa.ctl->exited, 1u) == gridDim.x - 1u ? 1 : 0;
+  if (uniform_i32(last)) {
+    ShareCtl* c = sa.ctl;
+    if (threadIdx.x == 0) {
+      unsigned int rp[8] = {ald(&c->donated), ald(&c->stolen), ald(&c->q_full), ald(&c->rec_full), ald(&c->rec_next), ald(&c->error),
+                            ald(&c->interrupted), ald(&c->max_fill)};
+      for (int i = 0; i < 8; i++) ast(&c->report[i], rp[i]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int* w = reinterpret_cast<unsigned int*>(c);
+    if (threadIdx.x < 48) ast(&w[threadIdx.x], 0u);  // lines 0-2: done/error/interrupted, ticket/statistics/exited, wait_ticket/q_tail
+    for (int i = threadIdx.x; i < FH_QCAP; i += 64) ast(&sa.seqs[i], (unsigned long long)i);
+  }
 }
 
 // FP64 vector peak of the device as this code can reach it: independent v_fma_f64 chains, 8 per lane, no memory traffic

@@ -18,7 +18,7 @@ for name, (pr, faces) in cases.items():
         ts = []
         for _ in range(50):
             t = time.perf_counter(); r2 = ctx.solve_batch_speculative(pr, faces, width); ts.append(time.perf_counter() - t)
-        assert all(np.array_equal(r2[k], r[k]) for k in abi.result_dtype.names)
+        assert all(np.array_equal(r2[k], r[k]) for k in abi.result_dtype.names if k not in ("nodes", "qp_iters", "kflops"))
         print("%-34s   width %2d: median %.3f ms  min %.3f ms  (trials %d)" % ("", width, 1e3 * np.median(ts), 1e3 * min(ts), r2["trials"][0]))
 for n in (1, 16, 256):
     ts = []
