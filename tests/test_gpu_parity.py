@@ -191,17 +191,18 @@ def test_maximum_sizes(ctx, oracle):
     ok = compare(got, ref)
     assert ok.sum() >= 24
     check_assignment_valid(pr, faces, got)
-    # same exact method and branching rule => the same branch-and-bound tree, node for node, on these whole problems when one
-    # wavefront explores a tree alone (a regression check on the node-state snapshots of the NVP = 48 instantiation; trials
-    # rejected before any QP and single-polytope problems are counted differently by the oracle, so this is not asserted in
-    # general; with sharing, pruning depends on when another wavefront's incumbent arrives, so only the results are equal)
+    # same exact method and branching rule => the same branch-and-bound tree on these whole problems when one wavefront explores
+    # a tree alone, except that the kernel skips siblings it can prove infeasible from a child's Farkas certificate
+    # (conflict-directed backjumping) while the oracle enumerates them: never more nodes, and most trees node for node (a
+    # regression check on the node-state snapshots of the NVP = 48 instantiation; with sharing, pruning depends on when another
+    # wavefront's incumbent arrives, so only the results are compared there)
     solo = capi.Context(0)
     par = abi.default_params()
     par["share"] = 0
     solo.set_params(par)
     alone = solo.solve_batch(pr, faces)
     solo.close()
-    assert alone["nodes"].max() > 50 and np.array_equal(alone["nodes"], ref["nodes"])
+    assert alone["nodes"].max() > 50 and np.all(alone["nodes"] <= ref["nodes"]) and (alone["nodes"] == ref["nodes"]).mean() > 0.5
     for f in ("solved", "trials", "status", "factor", "dt", "cost", "coeff", "assign"):
         assert np.array_equal(alone[f], got[f]), f
 
