@@ -1,0 +1,517 @@
+// fh_path.hip.hpp — voxel-grid path search on the device (gfx950): the first half of the corridor front-end.
+//
+// Reference: JPS_Manager::updateJPSMap -> MapUtil::readMap (/root/reference/faster/src/jps_manager.cpp:129-139,
+// faster/include/read_map.hpp:30-185) builds an occupancy grid from a point cloud; JPS_Manager::solveJPS3D (jps_manager.cpp:141-200)
+// frees the cells around start and goal, searches the 26-connected grid (jps3d graph_search.cpp: Euclidean step costs and heuristic)
+// and cleans the cell path up (jps_planner.cpp:36-105, :286-291: removeLinePts, removeCornerPts forwards and backwards).
+// The CPU restatement this kernel is checked against cell for cell is faster_amd/host/corridor_frontend.{hpp,cpp} (plan_path).
+//
+// One query per 64-lane wavefront, persistent wavefronts pulling queries from a counter.  The search is A*; what a GPU needs is a
+// priority queue without a serial heap:
+//   * the open list is a MONOTONE BUCKET QUEUE: the key of an entry is its f = g + h quantised to 2^-20 cells; a consistent
+//     heuristic makes the keys of expanded cells non-decreasing and a child's key at most 2*sqrt(3) above its parent's, so a
+//     circular window of 256 buckets of 1/32 cell is all that is ever live;
+//   * a bucket is a list of 64-entry chunks in HBM (SoA, one coalesced load per chunk); a pop scans the lowest non-empty bucket
+//     with one entry per lane and reduces (key, squared distance to the goal, cell index) lexicographically on the DPP network —
+//     a strict total order, so the expansion order does not depend on the container (the host restatement uses std::priority_queue
+//     with the same order and produces the same paths);
+//   * the popped entry is replaced by the last entry of the bucket's head chunk; the 26 neighbours are relaxed one per lane and
+//     appended to their buckets in parallel (lanes grouped by bucket with ballots);
+//   * per-cell state (g, parent, open/closed) lives in a per-wavefront array in HBM that is never cleared: entries carry the serial
+//     number of the query that wrote them.
+// All bucket bookkeeping (heads, fill counts, chunk links, free list) is wave-uniform state in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)   // cell indices must equal the host's: no fused multiply-adds in the coordinate arithmetic
+
+namespace fhp {
+
+constexpr int NBK = 256;        // circular bucket window
+constexpr int BK_SHIFT = 15;    // bucket = key >> 15: 2^-5 cell per bucket
+constexpr int NCHUNK = 2048;    // chunks of 64 open-list entries per wavefront (131072 entries)
+constexpr int CHUNK_WORDS = 192;
+constexpr int MAXRAW = 1024;    // longest raw cell path
+constexpr double KEY_SCALE = 1048576.0;
+
+struct MapView {
+  int nx, ny, nz, total, m_free;
+  double res, ox, oy, oz;
+  const unsigned* bits;  // occupancy, one bit per cell
+};
+
+struct CellState {  // 16 B
+  double g;
+  int parent;
+  unsigned stamp;  // 2 * serial + closed
+};
+
+struct PlanArgs {
+  const double* starts;   // [n][3]
+  const double* goals;    // [n][3]
+  int n;
+  int max_points;
+  double* paths;          // [n][max_points][3]
+  int* n_points;          // [n]: vertices, 0 no path, -1 more than max_points, -2 a search limit was hit
+  long long* expansions;  // [n] or null
+  CellState* cells;       // [waves][total]
+  unsigned* chunks;       // [waves][NCHUNK][192]
+  unsigned* serials;      // [waves]
+  int* ticket;
+  // corridor post-processing (Faster::createMoreVertexes, faster.cpp:80-97; deleteVertexes, utils.cpp:1117-1124); 0 = off
+  double max_vertex_dist;
+  int max_poly;
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int rank_in(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step(int v) {
+  const int o = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = dpp_min_step<0x111, 0xf>(v);
+  v = dpp_min_step<0x112, 0xf>(v);
+  v = dpp_min_step<0x114, 0xf>(v);
+  v = dpp_min_step<0x118, 0xf>(v);
+  v = dpp_min_step<0x142, 0xa>(v);
+  v = dpp_min_step<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+struct Planner {
+  const MapView& mv;
+  int lane;
+  int s[3], t[3];  // start / goal cells (uniform)
+  // LDS
+  short* bhead;  // [NBK]   head chunk of each bucket, -1 empty
+  short* bcnt;   // [NBK]   entries in the head chunk
+  short* cnext;  // [NCHUNK] next chunk of a bucket / of the free list
+  int* raw;      // [MAXRAW]
+  int* va;       // [MAXRAW]
+  int* vb;       // [MAXRAW]
+  int free_head;
+
+  __device__ Planner(const MapView& m, char* lds) : mv(m) {
+    lane = lane_id();
+    bhead = (short*)lds;
+    bcnt = bhead + NBK;
+    cnext = bcnt + NBK;
+    raw = (int*)(cnext + NCHUNK);
+    va = raw + MAXRAW;
+    vb = va + MAXRAW;
+  }
+
+  __device__ __forceinline__ bool outside(int x, int y, int z) const {
+    return x < 0 || y < 0 || z < 0 || x >= mv.nx || y >= mv.ny || z >= mv.nz;
+  }
+  __device__ __forceinline__ int index(int x, int y, int z) const { return x + mv.nx * y + mv.nx * mv.ny * z; }
+  __device__ __forceinline__ bool freed(int x, int y, int z) const {  // setFreeVoxelAndSurroundings around start and goal
+    const int m = mv.m_free;
+    const bool a = x >= s[0] - m && x <= s[0] + m && y >= s[1] - m && y <= s[1] + m && z >= s[2] - m && z <= s[2] + m;
+    const bool b = x >= t[0] - m && x <= t[0] + m && y >= t[1] - m && y <= t[1] + m && z >= t[2] - m && z <= t[2] + m;
+    return a || b;
+  }
+  __device__ __forceinline__ bool occupied_in(int x, int y, int z) const {  // inside the grid is the caller's business
+    if (freed(x, y, z)) return false;
+    const int id = index(x, y, z);
+    return (mv.bits[id >> 5] >> (id & 31)) & 1u;
+  }
+  __device__ __forceinline__ bool is_free(int x, int y, int z) const { return !outside(x, y, z) && !occupied_in(x, y, z); }
+  __device__ __forceinline__ void to_cell(double px, double py, double pz, int c[3]) const {  // MapUtil::floatToInt
+    c[0] = (int)round((px - mv.ox) / mv.res - 0.5);
+    c[1] = (int)round((py - mv.oy) / mv.res - 0.5);
+    c[2] = (int)round((pz - mv.oz) / mv.res - 0.5);
+  }
+  __device__ __forceinline__ void decode(int id, int& x, int& y, int& z) const {
+    const int nxy = mv.nx * mv.ny;
+    z = id / nxy;
+    const int rem = id - z * nxy;
+    y = rem / mv.nx;
+    x = rem - y * mv.nx;
+  }
+  __device__ __forceinline__ void center(int id, double c[3]) const {  // MapUtil::intToFloat
+    int x, y, z;
+    decode(id, x, y, z);
+    c[0] = (x + 0.5) * mv.res + mv.ox;
+    c[1] = (y + 0.5) * mv.res + mv.oy;
+    c[2] = (z + 0.5) * mv.res + mv.oz;
+  }
+
+  __device__ __forceinline__ int alloc_chunk() {
+    const int c = free_head;
+    if (c >= 0) free_head = rfl((int)cnext[c]);
+    return c;
+  }
+
+  // ray test of removeCornerPts (MapUtil::isBlocked-style sampling every 0.8 cell): uniform result
+  __device__ bool blocked(const double a[3], const double b[3]) const {
+    const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+    const double mx = fmax(fabs(dx), fmax(fabs(dy), fabs(dz))) / mv.res;
+    const int steps = (int)(mx / 0.8);
+    if (steps <= 0) return false;
+    const double sc = 1.0 / steps;
+    for (int n0 = 1; n0 < steps; n0 += 64) {
+      const int n = n0 + lane;
+      bool out = false, occ = false;
+      if (n < steps) {
+        const double f = sc * n;
+        int c[3];
+        to_cell(a[0] + dx * f, a[1] + dy * f, a[2] + dz * f, c);
+        out = outside(c[0], c[1], c[2]);
+        if (!out) occ = occupied_in(c[0], c[1], c[2]);
+      }
+      const unsigned long long mo = __ballot(out);
+      unsigned long long mc = __ballot(occ);
+      if (mo) {
+        mc &= (mo & (~mo + 1ull)) - 1ull;  // the walk stops at the first sample outside the grid
+        return mc != 0ull;
+      }
+      if (mc) return true;
+    }
+    return false;
+  }
+  __device__ __forceinline__ static double dist(const double a[3], const double b[3]) {
+    const double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+    return sqrt(x * x + y * y + z * z);
+  }
+
+  // jps_planner.cpp:36-81 on a list of cells (every vertex of the clean-up is a cell centre); in -> out, returns the count
+  __device__ int remove_corner_points(const int* in, int n, int* out) const {
+    if (n < 2) {
+      if (n == 1) out[0] = in[0];
+      return n;
+    }
+    double prev[3], a[3], b[3];
+    center(rfl(in[0]), prev);
+    center(rfl(in[1]), b);
+    out[0] = in[0];
+    int no = 1;
+    double c1 = blocked(prev, b) ? INFINITY : dist(prev, b);
+    for (int i = 1; i + 1 < n; i++) {
+      const int ia = rfl(in[i]);
+      center(ia, a);
+      center(rfl(in[i + 1]), b);
+      const double dab = dist(a, b);
+      const double c2 = blocked(a, b) ? INFINITY : dab;
+      const double c3 = blocked(prev, b) ? INFINITY : dist(prev, b);
+      if (c3 < c1 + c2) c1 = c3;
+      else {
+        out[no++] = ia;
+        c1 = dab;
+        prev[0] = a[0]; prev[1] = a[1]; prev[2] = a[2];
+      }
+    }
+    out[no++] = in[n - 1];
+    return no;
+  }
+
+  // One query.  Returns the number of cells of the cleaned path in va[] (start -> goal), 0 = no path, -2 = limit.
+  __device__ int search(const PlanArgs& pa, CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
+    const unsigned st_open = serial * 2u, st_closed = serial * 2u + 1u;
+    for (int i = lane; i < NBK; i += 64) { bhead[i] = -1; bcnt[i] = 0; }
+    for (int i = lane; i < NCHUNK; i += 64) cnext[i] = (short)(i + 1 < NCHUNK ? i + 1 : -1);
+    free_head = 0;
+    const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
+    int limit = 0;
+    // the start cell
+    {
+      const int h2 = (s[0] - t[0]) * (s[0] - t[0]) + (s[1] - t[1]) * (s[1] - t[1]) + (s[2] - t[2]) * (s[2] - t[2]);
+      const double f = 0.0 + sqrt((double)h2);
+      if (f >= 2040.0) return -2;
+      const int key = (int)(f * KEY_SCALE);
+      const int c = alloc_chunk();
+      unsigned* e = chunks + (size_t)c * CHUNK_WORDS;
+      if (lane == 0) {
+        e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)sid;
+        CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = st_open;
+        cells[sid] = cs;
+      }
+      const int b = (key >> BK_SHIFT) & (NBK - 1);
+      bhead[b] = (short)c; bcnt[b] = 1; cnext[c] = -1;
+    }
+    int cur_abs = ((int)(sqrt((double)((s[0] - t[0]) * (s[0] - t[0]) + (s[1] - t[1]) * (s[1] - t[1]) + (s[2] - t[2]) * (s[2] - t[2]))) * KEY_SCALE)) >> BK_SHIFT;
+    int n_open = 1;
+    bool found = false;
+    // neighbour of this lane
+    const int k = lane + (lane >= 13 ? 1 : 0);
+    const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
+    const double step = sqrt((double)(dx * dx + dy * dy + dz * dz));
+
+    while (n_open > 0) {
+      // ---- lowest non-empty bucket
+      for (;;) {
+        const int hb = bhead[(cur_abs + lane) & (NBK - 1)];
+        const unsigned long long m = __ballot(hb >= 0);
+        if (m) { cur_abs += (int)__builtin_ctzll(m); break; }
+        cur_abs += 64;
+      }
+      const int b = cur_abs & (NBK - 1);
+      const int hc = rfl((int)bhead[b]);
+      int cnt = rfl((int)bcnt[b]);
+      // ---- minimum of (key, h2, id) over the bucket
+      int bf = 0x7fffffff, bh = 0x7fffffff, bi = 0x7fffffff, bslot = -1;
+      int hf = 0, hh = 0, hid = 0;
+      {
+        int cc = hc, ccnt = cnt;
+        bool first = true;
+        while (cc >= 0) {
+          const unsigned* e = chunks + (size_t)cc * CHUNK_WORDS;
+          int f = 0x7fffffff, h = 0x7fffffff, id = 0x7fffffff;
+          if (lane < ccnt) { f = (int)e[lane]; h = (int)e[64 + lane]; id = (int)e[128 + lane]; }
+          if (first) { hf = f; hh = h; hid = id; first = false; }
+          const bool less = f < bf || (f == bf && (h < bh || (h == bh && id < bi)));
+          if (less) { bf = f; bh = h; bi = id; bslot = cc * 64 + lane; }
+          cc = rfl((int)cnext[cc]);
+          ccnt = 64;
+        }
+      }
+      const int mf = wave_min_i32(bf);
+      bool cand = bf == mf;
+      const int mh = wave_min_i32(cand ? bh : 0x7fffffff);
+      cand = cand && bh == mh;
+      const int id = wave_min_i32(cand ? bi : 0x7fffffff);
+      cand = cand && bi == id;
+      const int wl = (int)__builtin_ctzll(__ballot(cand));
+      const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+      // ---- remove it: the last entry of the head chunk takes its place
+      const int last = cnt - 1;
+      if (wslot != hc * 64 + last) {
+        const int lf = __builtin_amdgcn_readlane(hf, last), lh = __builtin_amdgcn_readlane(hh, last), li = __builtin_amdgcn_readlane(hid, last);
+        if (lane == 0) {
+          unsigned* e = chunks + (size_t)(wslot >> 6) * CHUNK_WORDS + (wslot & 63);
+          e[0] = (unsigned)lf; e[64] = (unsigned)lh; e[128] = (unsigned)li;
+        }
+      }
+      cnt--;
+      if (cnt == 0) {
+        const int nh = rfl((int)cnext[hc]);
+        bhead[b] = (short)nh;
+        bcnt[b] = (short)(nh >= 0 ? 64 : 0);
+        cnext[hc] = (short)free_head;
+        free_head = hc;
+      } else bcnt[b] = (short)cnt;
+      n_open--;
+      // ---- the cell
+      const CellState cs = cells[id];
+      if (cs.stamp == st_closed) continue;  // a stale duplicate: the cell was expanded from a better entry
+      if (lane == 0) cells[id].stamp = st_closed;
+      if (id == tid) { found = true; break; }
+      expansions++;
+      const double g = cs.g;
+      int cx, cy, cz;
+      decode(id, cx, cy, cz);
+      // ---- relax the 26 neighbours, one per lane
+      const int x = cx + dx, y = cy + dy, z = cz + dz;
+      bool ok = lane < 26 && is_free(x, y, z);
+      int nid = 0, key = 0, h2 = 0, babs = 0x7fffffff;
+      if (ok) {
+        nid = index(x, y, z);
+        const CellState ns = cells[nid];
+        const bool visited = (ns.stamp >> 1) == serial;
+        const double ng = g + step;
+        if (visited && ((ns.stamp & 1u) || !(ng < ns.g))) ok = false;
+        else {
+          CellState w; w.g = ng; w.parent = id; w.stamp = st_open;
+          cells[nid] = w;
+          h2 = (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
+          const double f = ng + sqrt((double)h2);
+          if (f >= 2040.0) { limit = 1; ok = false; }
+          else { key = (int)(f * KEY_SCALE); babs = key >> BK_SHIFT; }
+        }
+      }
+      unsigned long long pend = __ballot(ok);
+      if (pend) {
+        const int lo = wave_min_i32(babs);
+        if (lo < cur_abs) cur_abs = lo;
+      }
+      // ---- append, lanes grouped by bucket
+      while (pend) {
+        const int l0 = (int)__builtin_ctzll(pend);
+        const int bb = __builtin_amdgcn_readlane(babs, l0);
+        const bool mine = ok && babs == bb;
+        const unsigned long long grp = __ballot(mine);
+        pend &= ~grp;
+        const int kk = (int)__popcll(grp), rank = rank_in(grp);
+        const int bidx = bb & (NBK - 1);
+        int c0 = rfl((int)bhead[bidx]), cn = rfl((int)bcnt[bidx]);
+        if (c0 < 0 || cn == 64) {
+          const int nc = alloc_chunk();
+          if (nc < 0) { limit = 1; pend = 0; break; }
+          cnext[nc] = (short)c0;
+          c0 = nc; cn = 0;
+          bhead[bidx] = (short)c0;
+        }
+        const int space = 64 - cn;
+        if (mine && rank < space) {
+          unsigned* e = chunks + (size_t)c0 * CHUNK_WORDS + cn + rank;
+          e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+        }
+        if (kk > space) {
+          const int nc = alloc_chunk();
+          if (nc < 0) { limit = 1; pend = 0; break; }
+          cnext[nc] = (short)c0;
+          bhead[bidx] = (short)nc;
+          if (mine && rank >= space) {
+            unsigned* e = chunks + (size_t)nc * CHUNK_WORDS + (rank - space);
+            e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+          }
+          bcnt[bidx] = (short)(kk - space);
+        } else bcnt[bidx] = (short)(cn + kk);
+        n_open += kk;
+      }
+      if (__ballot(limit != 0)) return -2;
+    }
+    if (!found) return 0;
+
+    // ---- raw cell path, goal -> start
+    int len = 0;
+    for (int id = tid;;) {
+      if (len >= MAXRAW) return -2;
+      raw[len++] = id;
+      if (id == sid) break;
+      id = rfl(cells[id].parent);
+      if (id < 0) break;
+    }
+    // ---- removeLinePts (jps_planner.cpp:83-105) on the start -> goal order: raw[len-1-i]
+    int na = 0;
+    if (len < 3) {
+      for (int i = lane; i < len; i += 64) va[i] = raw[len - 1 - i];
+      na = len;
+    } else {
+      for (int i0 = 0; i0 < len; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        int idv = 0;
+        if (i < len) {
+          idv = raw[len - 1 - i];
+          if (i == 0 || i == len - 1) keep = true;
+          else {
+            double p0[3], p1[3], p2[3];
+            center(raw[len - i], p0);      // path[i-1]
+            center(idv, p1);
+            center(raw[len - 2 - i], p2);  // path[i+1]
+            const double qx = (p2[0] - p1[0]) - (p1[0] - p0[0]), qy = (p2[1] - p1[1]) - (p1[1] - p0[1]), qz = (p2[2] - p1[2]) - (p1[2] - p0[2]);
+            keep = fabs(qx) + fabs(qy) + fabs(qz) > 1e-2;
+          }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) va[na + rank_in(m)] = idv;
+        na += (int)__popcll(m);
+      }
+    }
+    // ---- removeCornerPts forwards, then on the reversed path, then back (jps_planner.cpp:286-291)
+    int nb = remove_corner_points(va, na, vb);
+    for (int i = lane; i < nb; i += 64) va[i] = vb[nb - 1 - i];
+    const int nc = remove_corner_points(va, nb, vb);
+    for (int i = lane; i < nc; i += 64) va[i] = vb[nc - 1 - i];
+    return nc;
+  }
+};
+
+constexpr int PLAN_LDS_BYTES = NBK * 2 * 2 + NCHUNK * 2 + 3 * MAXRAW * 4;
+
+// One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
+// (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
+__global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
+  __shared__ __attribute__((aligned(16))) char lds[PLAN_LDS_BYTES];
+  Planner pl(mv, lds);
+  const int lane = pl.lane;
+  const int wave = (int)blockIdx.x;
+  CellState* cells = pa.cells + (size_t)wave * mv.total;
+  unsigned* chunks = pa.chunks + (size_t)wave * NCHUNK * CHUNK_WORDS;
+  unsigned serial = pa.serials[wave];
+  for (;;) {
+    int q = 0;
+    if (lane == 0) q = atomicAdd(pa.ticket, 1);
+    q = rfl(q);
+    if (q >= pa.n) break;
+    double st[3], gl[3];
+    for (int k = 0; k < 3; k++) { st[k] = pa.starts[3 * q + k]; gl[k] = pa.goals[3 * q + k]; }
+    st[2] = fmax(st[2], 0.0);  // jps_manager.cpp:143-144
+    gl[2] = fmax(gl[2], 0.0);
+    pl.to_cell(st[0], st[1], st[2], pl.s);
+    pl.to_cell(gl[0], gl[1], gl[2], pl.t);
+    for (int k = 0; k < 3; k++) { pl.s[k] = rfl(pl.s[k]); pl.t[k] = rfl(pl.t[k]); }
+    long long expansions = 0;
+    int nv = 0;
+    if (!pl.outside(pl.s[0], pl.s[1], pl.s[2]) && !pl.outside(pl.t[0], pl.t[1], pl.t[2])) {
+      serial++;
+      if (serial >= 0x7fffffffu) serial = 1;  // (2^31 queries per wavefront; the workspace would have to be cleared here)
+      nv = pl.search(pa, cells, chunks, serial, expansions);
+    }
+    double* out = pa.paths + (size_t)q * pa.max_points * 3;
+    int np = nv;
+    if (nv > 0) {
+      // vertices in LDS order va[0..nv): ends forced
+      const int count = nv > 1 ? nv : 2;
+      // createMoreVertexes / zero-length legs / deleteVertexes are sequential and short: lane 0 walks the legs
+      if (lane == 0) {
+        int w = 0;
+        bool over = false;
+        double prev[3] = {st[0], st[1], st[2]};
+        auto put = [&](const double p[3]) {
+          if (w < pa.max_points) { out[3 * w] = p[0]; out[3 * w + 1] = p[1]; out[3 * w + 2] = p[2]; }
+          else over = true;
+          w++;
+        };
+        put(prev);
+        for (int i = 1; i < count; i++) {
+          double nxt[3];
+          if (i == count - 1) { nxt[0] = gl[0]; nxt[1] = gl[1]; nxt[2] = gl[2]; }
+          else pl.center(pl.va[i], nxt);
+          if (pa.max_vertex_dist > 0.0) {
+            const double d = Planner::dist(nxt, prev);
+            if (d > pa.max_vertex_dist) {
+              const int add = (int)floor(d / pa.max_vertex_dist);
+              const double vx = (nxt[0] - prev[0]) / d, vy = (nxt[1] - prev[1]) / d, vz = (nxt[2] - prev[2]) / d;
+              for (int a = 0; a < add; a++) {
+                double p[3] = {prev[0] + vx * pa.max_vertex_dist, prev[1] + vy * pa.max_vertex_dist, prev[2] + vz * pa.max_vertex_dist};
+                put(p);
+                prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2];
+              }
+            }
+            if (Planner::dist(nxt, prev) < 1e-9) continue;  // the repeated end point of an exact multiple
+          }
+          put(nxt);
+          prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];
+        }
+        if (pa.max_poly > 0 && w > pa.max_poly + 1) { w = pa.max_poly + 1; over = false; }
+        np = over ? -1 : w;
+      }
+      np = rfl(np);
+    }
+    if (lane == 0) {
+      pa.n_points[q] = np;
+      if (pa.expansions) pa.expansions[q] = expansions;
+    }
+  }
+  if (lane == 0) pa.serials[wave] = serial;
+}
+
+// MapUtil::readMap (read_map.hpp:100-185): every point marks its cell and the cube of +-m cells around it; the flat index test is
+// the reference's (no per-axis clipping).
+__global__ void mark_kernel(const double* cloud, int n, int nx, int ny, int nz, double res, double ox, double oy, double oz, int m,
+                            unsigned* bits) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  int c[3];
+  c[0] = (int)round((cloud[3 * i] - ox) / res - 0.5);
+  c[1] = (int)round((cloud[3 * i + 1] - oy) / res - 0.5);
+  c[2] = (int)round((cloud[3 * i + 2] - oz) / res - 0.5);
+  for (int k = 0; k < 3; k++) c[k] = c[k] > 0 ? c[k] : 0;
+  const long long total = (long long)nx * ny * nz;
+  for (int ix = c[0] - m; ix <= c[0] + m; ix++)
+    for (int iy = c[1] - m; iy <= c[1] + m; iy++)
+      for (int iz = c[2] - m; iz <= c[2] + m; iz++) {
+        const long long id = ix + (long long)nx * iy + (long long)nx * ny * iz;
+        if (id >= 0 && id < total) atomicOr(&bits[id >> 5], 1u << (id & 31));
+      }
+}
+
+}  // namespace fhp
