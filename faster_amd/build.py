@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = os.path.join(HERE, "libfasterhip.so")
-SOURCES = [os.path.join(HERE, "csrc", "fh_capi.hip"), os.path.join(HERE, "csrc", "fh_pool.hip")]
+SOURCES = [os.path.join(HERE, "csrc", "fh_capi.hip"), os.path.join(HERE, "csrc", "fh_pool.hip"),
+           os.path.join(HERE, "csrc", "fh_map.hip")]
 import glob  # noqa: E402
 
 DEPS = SOURCES + sorted(glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [os.path.join(ROOT, "include", "fasterhip.h")]

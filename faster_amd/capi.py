@@ -20,6 +20,8 @@ SYMBOLS = [
     "fh_decompose_batch", "fh_decompose_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
+    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_sync", "fh_map_read", "fh_map_read_device",
+    "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
 
@@ -98,6 +100,28 @@ def lib():
         L.fh_pool_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp]
         L.fh_pool_solve_pairs.restype = i32
         L.fh_pool_solve_pairs.argtypes = [vp, vp, vp, i64, i32, vp, f64, f64, i32, vp, vp, i32, vp, vp]
+        L.fh_map_create.restype = i32
+        L.fh_map_create.argtypes = [ctypes.POINTER(vp), i32]
+        L.fh_map_destroy.restype = None
+        L.fh_map_destroy.argtypes = [vp]
+        L.fh_map_last_error.restype = ctypes.c_char_p
+        L.fh_map_last_error.argtypes = [vp]
+        L.fh_map_set_stream.restype = i32
+        L.fh_map_set_stream.argtypes = [vp, vp]
+        L.fh_map_sync.restype = i32
+        L.fh_map_sync.argtypes = [vp]
+        L.fh_map_read.restype = i32
+        L.fh_map_read.argtypes = [vp, vp, i32, vp, f64, vp, f64, f64, f64]
+        L.fh_map_read_device.restype = i32
+        L.fh_map_read_device.argtypes = [vp, vp, i32, vp, f64, vp, f64, f64, f64]
+        L.fh_map_dims.restype = i32
+        L.fh_map_dims.argtypes = [vp, vp, vp]
+        L.fh_map_occupancy.restype = i32
+        L.fh_map_occupancy.argtypes = [vp, vp]
+        L.fh_map_plan_batch.restype = i32
+        L.fh_map_plan_batch.argtypes = [vp, vp, vp, i32, i32, f64, i32, vp, vp, vp]
+        L.fh_map_plan_batch_device.restype = i32
+        L.fh_map_plan_batch_device.argtypes = [vp, vp, vp, i32, i32, f64, i32, vp, vp, vp]
         L.fh_timing_reset.restype = i32
         L.fh_timing_reset.argtypes = [vp]
         L.fh_timing_read.restype = i32
@@ -166,6 +190,79 @@ class Pool:
                                               whole.shape[0], abi.ptr(safe_templates), r_frac, shrink, max_safe_poly, abi.ptr(wres),
                                               abi.ptr(sres), root, d_whole_root, d_safe_root), "fh_pool_solve_pairs")
         return wres, sres
+
+
+class Map:
+    """Device voxel map + batched path search (fh_map_*): JPS_Manager::updateJPSMap / solveJPS3D for batches of queries."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        rc = lib().fh_map_create(ctypes.byref(self._h), device)
+        if rc != 0:
+            self._h = None
+            raise FasterHipError("fh_map_create: rc=%d (no HIP device? there is no CPU fallback)" % rc)
+
+    def close(self):
+        if self._h:
+            lib().fh_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FasterHipError("%s: rc=%d %s" % (what, rc, lib().fh_map_last_error(self._h).decode()))
+
+    def set_stream(self, stream):
+        self._check(lib().fh_map_set_stream(self._h, stream), "fh_map_set_stream")
+
+    def sync(self):
+        self._check(lib().fh_map_sync(self._h), "fh_map_sync")
+
+    def read(self, cloud, cells, res, center, z_ground, z_max, inflation):
+        cloud = np.ascontiguousarray(cloud, dtype=np.float64).reshape(-1, 3)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        center = np.ascontiguousarray(center, dtype=np.float64)
+        self._check(lib().fh_map_read(self._h, abi.ptr(cloud) if len(cloud) else None, len(cloud), abi.ptr(cells), float(res), abi.ptr(center),
+                                      float(z_ground), float(z_max), float(inflation)), "fh_map_read")
+
+    def read_device(self, d_cloud, n_cloud, cells, res, center, z_ground, z_max, inflation):
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        center = np.ascontiguousarray(center, dtype=np.float64)
+        self._check(lib().fh_map_read_device(self._h, d_cloud, n_cloud, abi.ptr(cells), float(res), abi.ptr(center), float(z_ground),
+                                             float(z_max), float(inflation)), "fh_map_read_device")
+
+    def dims(self):
+        d = np.zeros(3, dtype=np.int32)
+        o = np.zeros(3, dtype=np.float64)
+        self._check(lib().fh_map_dims(self._h, abi.ptr(d), abi.ptr(o)), "fh_map_dims")
+        return d, o
+
+    def occupancy(self):
+        d, _ = self.dims()
+        occ = np.zeros(int(d[0]) * int(d[1]) * int(d[2]), dtype=np.int8)
+        self._check(lib().fh_map_occupancy(self._h, abi.ptr(occ)), "fh_map_occupancy")
+        return occ.reshape(int(d[2]), int(d[1]), int(d[0]))
+
+    def plan_batch(self, starts, goals, max_points=64, max_vertex_dist=0.0, max_poly=0):
+        """-> (paths [n][max_points][3], n_points [n], expansions [n])"""
+        starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+        goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
+        n = len(starts)
+        paths = np.zeros((n, max_points, 3), dtype=np.float64)
+        npts = np.zeros(n, dtype=np.int32)
+        ex = np.zeros(n, dtype=np.int64)
+        self._check(lib().fh_map_plan_batch(self._h, abi.ptr(starts), abi.ptr(goals), n, max_points, float(max_vertex_dist), int(max_poly),
+                                            abi.ptr(paths), abi.ptr(npts), abi.ptr(ex)), "fh_map_plan_batch")
+        return paths, npts, ex
+
+    def plan_batch_device(self, d_starts, d_goals, n, max_points, d_paths, d_n_points, d_expansions=None, max_vertex_dist=0.0, max_poly=0):
+        self._check(lib().fh_map_plan_batch_device(self._h, d_starts, d_goals, n, max_points, float(max_vertex_dist), int(max_poly), d_paths,
+                                                   d_n_points, d_expansions), "fh_map_plan_batch_device")
 
 
 class Context:

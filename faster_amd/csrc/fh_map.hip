@@ -1,0 +1,278 @@
+// fh_map.hip — host side of the voxel-map entry points of the C ABI (include/fasterhip.h, fh_map_*): occupancy grid from a point
+// cloud and batched path search on the device (kernels: fh_path.hip.hpp).  Replaces JPS_Manager::updateJPSMap / solveJPS3D
+// (/root/reference/faster/src/jps_manager.cpp:129-200) for batches of start/goal queries over one map.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/fasterhip.h"
+#include "fh_path.hip.hpp"
+
+struct fh_map {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int n_cu = 0;
+  // the grid
+  bool have_map = false;
+  int nx = 0, ny = 0, nz = 0;
+  double res = 0.1, origin[3] = {0, 0, 0}, inflation = 0.0;
+  unsigned* d_bits = nullptr;
+  size_t bits_cap = 0;
+  // search workspace
+  int waves = 0;
+  size_t ws_total = 0;  // cells per wavefront the workspace was sized for
+  fhp::CellState* d_cells = nullptr;
+  unsigned* d_chunks = nullptr;
+  unsigned* d_serials = nullptr;
+  int* d_ticket = nullptr;
+  // staging of the host-pointer entry points
+  void* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t stage_cap[5] = {0, 0, 0, 0, 0};
+};
+
+#define FM_HIP(call)                                                   \
+  do {                                                                 \
+    hipError_t e__ = (call);                                           \
+    if (e__ != hipSuccess) {                                           \
+      m->err = std::string(#call) + ": " + hipGetErrorString(e__);     \
+      return FH_ERR_DEVICE;                                            \
+    }                                                                  \
+  } while (0)
+
+namespace {
+struct MapDeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit MapDeviceScope(const fh_map* m) {
+    if (m && hipGetDevice(&prev) == hipSuccess && prev != m->device) switched = hipSetDevice(m->device) == hipSuccess;
+  }
+  ~MapDeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+int stage(fh_map* m, int slot, size_t bytes) {
+  if (bytes <= m->stage_cap[slot]) return FH_OK;
+  if (m->d_stage[slot]) {
+    FM_HIP(hipStreamSynchronize(m->stream));
+    FM_HIP(hipFree(m->d_stage[slot]));
+  }
+  m->d_stage[slot] = nullptr;
+  m->stage_cap[slot] = 0;
+  const size_t want = std::max(bytes, (size_t)4096);
+  FM_HIP(hipMalloc(&m->d_stage[slot], want));
+  m->stage_cap[slot] = want;
+  return FH_OK;
+}
+
+// per-wavefront search state: sized by the grid; at most 16 wavefronts per CU (4 per SIMD) and 48 GB
+int ensure_workspace(fh_map* m) {
+  const size_t total = (size_t)m->nx * m->ny * m->nz;
+  const size_t per_wave = total * sizeof(fhp::CellState) + (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS * 4;
+  int waves = m->n_cu * 16;
+  if (const char* e = getenv("FH_DEBUG_PLAN_WAVES_PER_CU")) waves = m->n_cu * std::max(1, atoi(e));
+  const size_t budget = (size_t)48 << 30;
+  if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);
+  if (m->d_cells && m->ws_total == total && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
+  FM_HIP(hipStreamSynchronize(m->stream));
+  if (m->d_cells) FM_HIP(hipFree(m->d_cells));
+  if (m->d_chunks) FM_HIP(hipFree(m->d_chunks));
+  if (m->d_serials) FM_HIP(hipFree(m->d_serials));
+  m->d_cells = nullptr; m->d_chunks = nullptr; m->d_serials = nullptr;
+  m->waves = 0;
+  FM_HIP(hipMalloc(&m->d_cells, (size_t)waves * total * sizeof(fhp::CellState)));
+  FM_HIP(hipMalloc(&m->d_chunks, (size_t)waves * fhp::NCHUNK * fhp::CHUNK_WORDS * 4));
+  FM_HIP(hipMalloc(&m->d_serials, (size_t)waves * 4));
+  // stamps start at "never visited"; the serial numbers continue across calls, so this is the only clear
+  FM_HIP(hipMemsetAsync(m->d_cells, 0, (size_t)waves * total * sizeof(fhp::CellState), m->stream));
+  FM_HIP(hipMemsetAsync(m->d_serials, 0, (size_t)waves * 4, m->stream));
+  if (!m->d_ticket) FM_HIP(hipMalloc(&m->d_ticket, 64));
+  m->waves = waves;
+  m->ws_total = total;
+  return FH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fh_map_create(fh_map** out, int device) {
+  if (!out) return FH_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return FH_ERR_DEVICE;
+  fh_map* m = new (std::nothrow) fh_map();
+  if (!m) return FH_ERR_NOMEM;
+  m->device = device;
+  MapDeviceScope scope(m);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess || hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete m;
+    return FH_ERR_DEVICE;
+  }
+  m->n_cu = prop.multiProcessorCount;
+  m->stream = m->own_stream;
+  *out = m;
+  return FH_OK;
+}
+
+void fh_map_destroy(fh_map* m) {
+  if (!m) return;
+  MapDeviceScope scope(m);
+  (void)hipStreamSynchronize(m->stream);
+  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket})
+    if (p) (void)hipFree(p);
+  for (void* p : m->d_stage)
+    if (p) (void)hipFree(p);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  delete m;
+}
+
+const char* fh_map_last_error(const fh_map* m) { return m ? m->err.c_str() : "null map"; }
+
+int fh_map_set_stream(fh_map* m, void* stream) {
+  if (!m) return FH_ERR_ARG;
+  MapDeviceScope scope(m);
+  FM_HIP(hipStreamSynchronize(m->stream));
+  m->stream = stream ? (hipStream_t)stream : m->own_stream;
+  return FH_OK;
+}
+
+int fh_map_sync(fh_map* m) {
+  if (!m) return FH_ERR_ARG;
+  MapDeviceScope scope(m);
+  FM_HIP(hipStreamSynchronize(m->stream));
+  return FH_OK;
+}
+
+// MapUtil::readMap (read_map.hpp:30-185): grid of cells[] cells (x, y widened by 5*inflation/res) centred on `center`, clipped to
+// [z_ground, z_max]; the dimension arithmetic below is the reference's (integer truncations included).
+int fh_map_read_device(fh_map* m, const double* d_cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3],
+                       double z_ground, double z_max, double inflation) {
+  if (!m || !cells || !center || n_cloud < 0 || (n_cloud > 0 && !d_cloud_xyz) || !(res > 0.0) || !(inflation >= 0.0)) return FH_ERR_ARG;
+  if (cells[0] <= 0 || cells[1] <= 0 || cells[2] <= 0) return FH_ERR_ARG;
+  MapDeviceScope scope(m);
+  int dx = cells[0] + (int)(5 * inflation / res), dy = cells[1] + (int)(5 * inflation / res), dz = cells[2];
+  int down = (int)(dz / 2.0), up = (int)(dz / 2.0);
+  if (center[2] - res * dz / 2.0 < z_ground) down = std::max((int)((center[2] - z_ground) / res), 0);
+  if (center[2] + res * dz / 2.0 > z_max) {
+    up = (int)((z_max - center[2]) / res);
+    up = up > 0 ? up : 1;
+  }
+  dz = down + up;
+  if (dz <= 0 || (long long)dx * dy * dz > (1ll << 27)) return FH_ERR_ARG;
+  m->nx = dx; m->ny = dy; m->nz = dz;
+  m->res = res;
+  m->inflation = inflation;
+  m->origin[0] = center[0] - res * dx / 2.0;
+  m->origin[1] = center[1] - res * dy / 2.0;
+  m->origin[2] = center[2] - res * down;
+  const size_t total = (size_t)dx * dy * dz, words = (total + 31) / 32;
+  if (words * 4 > m->bits_cap) {
+    FM_HIP(hipStreamSynchronize(m->stream));
+    if (m->d_bits) FM_HIP(hipFree(m->d_bits));
+    m->d_bits = nullptr; m->bits_cap = 0;
+    FM_HIP(hipMalloc(&m->d_bits, words * 4));
+    m->bits_cap = words * 4;
+  }
+  FM_HIP(hipMemsetAsync(m->d_bits, 0, words * 4, m->stream));
+  if (n_cloud > 0) {
+    const int mcube = (int)std::floor(inflation / res);
+    hipLaunchKernelGGL(fhp::mark_kernel, dim3((unsigned)((n_cloud + 255) / 256)), dim3(256), 0, m->stream, d_cloud_xyz, n_cloud, dx, dy, dz, res,
+                       m->origin[0], m->origin[1], m->origin[2], mcube, m->d_bits);
+    FM_HIP(hipGetLastError());
+  }
+  m->have_map = true;
+  return FH_OK;
+}
+
+int fh_map_read(fh_map* m, const double* cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3], double z_ground,
+                double z_max, double inflation) {
+  if (!m || n_cloud < 0 || (n_cloud > 0 && !cloud_xyz)) return FH_ERR_ARG;
+  MapDeviceScope scope(m);
+  int rc;
+  if (n_cloud > 0) {
+    if ((rc = stage(m, 0, sizeof(double) * 3 * (size_t)n_cloud)) != FH_OK) return rc;
+    FM_HIP(hipMemcpyAsync(m->d_stage[0], cloud_xyz, sizeof(double) * 3 * (size_t)n_cloud, hipMemcpyHostToDevice, m->stream));
+  }
+  if ((rc = fh_map_read_device(m, (const double*)m->d_stage[0], n_cloud, cells, res, center, z_ground, z_max, inflation)) != FH_OK) return rc;
+  FM_HIP(hipStreamSynchronize(m->stream));
+  return FH_OK;
+}
+
+int fh_map_dims(const fh_map* m, int32_t dims[3], double origin[3]) {
+  if (!m || !m->have_map) return FH_ERR_ARG;
+  if (dims) { dims[0] = m->nx; dims[1] = m->ny; dims[2] = m->nz; }
+  if (origin) { origin[0] = m->origin[0]; origin[1] = m->origin[1]; origin[2] = m->origin[2]; }
+  return FH_OK;
+}
+
+// occupancy as the reference stores it: one int8 per cell, 0 free / 100 occupied (x fastest)
+int fh_map_occupancy(fh_map* m, int8_t* occ) {
+  if (!m || !m->have_map || !occ) return FH_ERR_ARG;
+  MapDeviceScope scope(m);
+  const size_t total = (size_t)m->nx * m->ny * m->nz, words = (total + 31) / 32;
+  std::vector<unsigned> bits(words);
+  FM_HIP(hipMemcpyAsync(bits.data(), m->d_bits, words * 4, hipMemcpyDeviceToHost, m->stream));
+  FM_HIP(hipStreamSynchronize(m->stream));
+  for (size_t i = 0; i < total; i++) occ[i] = (bits[i >> 5] >> (i & 31)) & 1u ? 100 : 0;
+  return FH_OK;
+}
+
+int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_goals, int n, int max_points, double max_vertex_dist,
+                             int max_poly, double* d_paths, int32_t* d_n_points, int64_t* d_expansions) {
+  if (!m || !m->have_map || n < 0 || max_points < 2 || (n > 0 && (!d_starts || !d_goals || !d_paths || !d_n_points))) return FH_ERR_ARG;
+  if (n == 0) return FH_OK;
+  MapDeviceScope scope(m);
+  int rc;
+  if ((rc = ensure_workspace(m)) != FH_OK) return rc;
+  fhp::MapView mv;
+  mv.nx = m->nx; mv.ny = m->ny; mv.nz = m->nz;
+  mv.total = m->nx * m->ny * m->nz;
+  mv.m_free = (int)std::floor(m->inflation / m->res);
+  mv.res = m->res; mv.ox = m->origin[0]; mv.oy = m->origin[1]; mv.oz = m->origin[2];
+  mv.bits = m->d_bits;
+  fhp::PlanArgs pa;
+  pa.starts = d_starts; pa.goals = d_goals; pa.n = n; pa.max_points = max_points;
+  pa.paths = d_paths; pa.n_points = d_n_points; pa.expansions = (long long*)d_expansions;
+  pa.cells = m->d_cells; pa.chunks = m->d_chunks; pa.serials = m->d_serials; pa.ticket = m->d_ticket;
+  pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
+  FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
+  const int grid = std::min(m->waves, n);
+  hipLaunchKernelGGL(fhp::plan_kernel, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
+  FM_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_map_plan_batch(fh_map* m, const double* starts, const double* goals, int n, int max_points, double max_vertex_dist, int max_poly,
+                      double* paths, int32_t* n_points, int64_t* expansions) {
+  if (!m || !m->have_map || n < 0 || max_points < 2 || (n > 0 && (!starts || !goals || !paths || !n_points))) return FH_ERR_ARG;
+  if (n == 0) return FH_OK;
+  MapDeviceScope scope(m);
+  int rc;
+  const size_t bq = sizeof(double) * 3 * (size_t)n, bp = sizeof(double) * 3 * (size_t)n * max_points;
+  if ((rc = stage(m, 1, 2 * bq)) != FH_OK) return rc;
+  if ((rc = stage(m, 2, bp)) != FH_OK) return rc;
+  if ((rc = stage(m, 3, 4 * (size_t)n)) != FH_OK) return rc;
+  if ((rc = stage(m, 4, 8 * (size_t)n)) != FH_OK) return rc;
+  double* d_q = (double*)m->d_stage[1];
+  FM_HIP(hipMemcpyAsync(d_q, starts, bq, hipMemcpyHostToDevice, m->stream));
+  FM_HIP(hipMemcpyAsync(d_q + 3 * (size_t)n, goals, bq, hipMemcpyHostToDevice, m->stream));
+  if ((rc = fh_map_plan_batch_device(m, d_q, d_q + 3 * (size_t)n, n, max_points, max_vertex_dist, max_poly, (double*)m->d_stage[2],
+                                     (int32_t*)m->d_stage[3], (int64_t*)m->d_stage[4])) != FH_OK)
+    return rc;
+  FM_HIP(hipMemcpyAsync(paths, m->d_stage[2], bp, hipMemcpyDeviceToHost, m->stream));
+  FM_HIP(hipMemcpyAsync(n_points, m->d_stage[3], 4 * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+  if (expansions) FM_HIP(hipMemcpyAsync(expansions, m->d_stage[4], 8 * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+  FM_HIP(hipStreamSynchronize(m->stream));
+  return FH_OK;
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@
 //     heuristic makes the keys of expanded cells non-decreasing and a child's key at most 2*sqrt(3) above its parent's, so a
 //     circular window of 256 buckets of 1/32 cell is all that is ever live;
 //   * a bucket is a list of 64-entry chunks in HBM (SoA, one coalesced load per chunk); a pop scans the lowest non-empty bucket
-//     with one entry per lane and reduces (key, squared distance to the goal, cell index) lexicographically on the DPP network —
+//     with one entry per lane and reduces (key, cell index) lexicographically on the DPP network —
 //     a strict total order, so the expansion order does not depend on the container (the host restatement uses std::priority_queue
 //     with the same order and produces the same paths);
 //   * the popped entry is replaced by the last entry of the bucket's head chunk; the 26 neighbours are relaxed one per lane and
@@ -31,8 +31,8 @@ namespace fhp {
 constexpr int NBK = 256;        // circular bucket window
 constexpr int BK_SHIFT = 15;    // bucket = key >> 15: 2^-5 cell per bucket
 constexpr int NCHUNK = 2048;    // chunks of 64 open-list entries per wavefront (131072 entries)
-constexpr int CHUNK_WORDS = 192;
-constexpr int MAXRAW = 1024;    // longest raw cell path
+constexpr int CHUNK_WORDS = 128;  // 64 keys, 64 cells
+constexpr int MAXRAW = 4096;    // longest raw cell path (the clean-up lists live in the chunk pool, which is dead by then)
 constexpr double KEY_SCALE = 1048576.0;
 
 struct MapView {
@@ -56,7 +56,7 @@ struct PlanArgs {
   int* n_points;          // [n]: vertices, 0 no path, -1 more than max_points, -2 a search limit was hit
   long long* expansions;  // [n] or null
   CellState* cells;       // [waves][total]
-  unsigned* chunks;       // [waves][NCHUNK][192]
+  unsigned* chunks;       // [waves][NCHUNK][128]
   unsigned* serials;      // [waves]
   int* ticket;
   // corridor post-processing (Faster::createMoreVertexes, faster.cpp:80-97; deleteVertexes, utils.cpp:1117-1124); 0 = off
@@ -91,21 +91,24 @@ struct Planner {
   // LDS
   short* bhead;  // [NBK]   head chunk of each bucket, -1 empty
   short* bcnt;   // [NBK]   entries in the head chunk
-  short* cnext;  // [NCHUNK] next chunk of a bucket / of the free list
+  short* cnext;  // [NCHUNK] next chunk of a bucket
+  short* fstack; // [NCHUNK] free chunks (stack)
+  int ftop;
+  // HBM (the wavefront's chunk pool, once the search is over)
   int* raw;      // [MAXRAW]
   int* va;       // [MAXRAW]
   int* vb;       // [MAXRAW]
-  int free_head;
 
   __device__ Planner(const MapView& m, char* lds) : mv(m) {
     lane = lane_id();
     bhead = (short*)lds;
     bcnt = bhead + NBK;
     cnext = bcnt + NBK;
-    raw = (int*)(cnext + NCHUNK);
-    va = raw + MAXRAW;
-    vb = va + MAXRAW;
+    fstack = cnext + NCHUNK;
+    raw = va = vb = nullptr;
   }
+  // stores of some lanes are read back by others: the clean-up lists are tiny, so simply wait for the stores
+  __device__ __forceinline__ static void settle() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
   __device__ __forceinline__ bool outside(int x, int y, int z) const {
     return x < 0 || y < 0 || z < 0 || x >= mv.nx || y >= mv.ny || z >= mv.nz;
@@ -143,12 +146,6 @@ struct Planner {
     c[2] = (z + 0.5) * mv.res + mv.oz;
   }
 
-  __device__ __forceinline__ int alloc_chunk() {
-    const int c = free_head;
-    if (c >= 0) free_head = rfl((int)cnext[c]);
-    return c;
-  }
-
   // ray test of removeCornerPts (MapUtil::isBlocked-style sampling every 0.8 cell): uniform result
   __device__ bool blocked(const double a[3], const double b[3]) const {
     const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
@@ -184,13 +181,13 @@ struct Planner {
   // jps_planner.cpp:36-81 on a list of cells (every vertex of the clean-up is a cell centre); in -> out, returns the count
   __device__ int remove_corner_points(const int* in, int n, int* out) const {
     if (n < 2) {
-      if (n == 1) out[0] = in[0];
+      if (n == 1 && lane == 0) out[0] = in[0];
       return n;
     }
     double prev[3], a[3], b[3];
     center(rfl(in[0]), prev);
     center(rfl(in[1]), b);
-    out[0] = in[0];
+    if (lane == 0) out[0] = in[0];
     int no = 1;
     double c1 = blocked(prev, b) ? INFINITY : dist(prev, b);
     for (int i = 1; i + 1 < n; i++) {
@@ -202,12 +199,14 @@ struct Planner {
       const double c3 = blocked(prev, b) ? INFINITY : dist(prev, b);
       if (c3 < c1 + c2) c1 = c3;
       else {
-        out[no++] = ia;
+        if (lane == 0) out[no] = ia;
+        no++;
         c1 = dab;
         prev[0] = a[0]; prev[1] = a[1]; prev[2] = a[2];
       }
     }
-    out[no++] = in[n - 1];
+    if (lane == 0) out[no] = in[n - 1];
+    no++;
     return no;
   }
 
@@ -215,122 +214,132 @@ struct Planner {
   __device__ int search(const PlanArgs& pa, CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
     const unsigned st_open = serial * 2u, st_closed = serial * 2u + 1u;
     for (int i = lane; i < NBK; i += 64) { bhead[i] = -1; bcnt[i] = 0; }
-    for (int i = lane; i < NCHUNK; i += 64) cnext[i] = (short)(i + 1 < NCHUNK ? i + 1 : -1);
-    free_head = 0;
+    for (int i = lane; i < NCHUNK; i += 64) fstack[i] = (short)(NCHUNK - 1 - i);  // chunk 0 on top
+    ftop = NCHUNK;
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     int limit = 0;
+    int cur_abs;
     // the start cell
     {
       const int h2 = (s[0] - t[0]) * (s[0] - t[0]) + (s[1] - t[1]) * (s[1] - t[1]) + (s[2] - t[2]) * (s[2] - t[2]);
       const double f = 0.0 + sqrt((double)h2);
       if (f >= 2040.0) return -2;
       const int key = (int)(f * KEY_SCALE);
-      const int c = alloc_chunk();
+      const int c = rfl((int)fstack[--ftop]);
       unsigned* e = chunks + (size_t)c * CHUNK_WORDS;
       if (lane == 0) {
-        e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)sid;
+        e[0] = (unsigned)key; e[64] = (unsigned)sid;
         CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = st_open;
         cells[sid] = cs;
       }
-      const int b = (key >> BK_SHIFT) & (NBK - 1);
+      cur_abs = key >> BK_SHIFT;
+      const int b = cur_abs & (NBK - 1);
       bhead[b] = (short)c; bcnt[b] = 1; cnext[c] = -1;
     }
-    int cur_abs = ((int)(sqrt((double)((s[0] - t[0]) * (s[0] - t[0]) + (s[1] - t[1]) * (s[1] - t[1]) + (s[2] - t[2]) * (s[2] - t[2]))) * KEY_SCALE)) >> BK_SHIFT;
     int n_open = 1;
     bool found = false;
     // neighbour of this lane
     const int k = lane + (lane >= 13 ? 1 : 0);
     const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
     const double step = sqrt((double)(dx * dx + dy * dy + dz * dz));
+    const int nxy = mv.nx * mv.ny;
 
     while (n_open > 0) {
-      // ---- lowest non-empty bucket
+      // ---- lowest non-empty bucket (head and fill count of 64 buckets per look)
+      int hc, cnt;
       for (;;) {
-        const int hb = bhead[(cur_abs + lane) & (NBK - 1)];
+        const int bl = (cur_abs + lane) & (NBK - 1);
+        const int hb = bhead[bl], cb = bcnt[bl];
         const unsigned long long m = __ballot(hb >= 0);
-        if (m) { cur_abs += (int)__builtin_ctzll(m); break; }
+        if (m) {
+          const int l = (int)__builtin_ctzll(m);
+          cur_abs += l;
+          hc = __builtin_amdgcn_readlane(hb, l);
+          cnt = __builtin_amdgcn_readlane(cb, l);
+          break;
+        }
         cur_abs += 64;
       }
       const int b = cur_abs & (NBK - 1);
-      const int hc = rfl((int)bhead[b]);
-      int cnt = rfl((int)bcnt[b]);
-      // ---- minimum of (key, h2, id) over the bucket
-      int bf = 0x7fffffff, bh = 0x7fffffff, bi = 0x7fffffff, bslot = -1;
-      int hf = 0, hh = 0, hid = 0;
+      // ---- minimum of (key, cell) over the bucket
+      int bf = 0x7fffffff, bi = 0x7fffffff, bslot = -1;
+      int hf = 0, hid = 0;
       {
         int cc = hc, ccnt = cnt;
         bool first = true;
         while (cc >= 0) {
           const unsigned* e = chunks + (size_t)cc * CHUNK_WORDS;
-          int f = 0x7fffffff, h = 0x7fffffff, id = 0x7fffffff;
-          if (lane < ccnt) { f = (int)e[lane]; h = (int)e[64 + lane]; id = (int)e[128 + lane]; }
-          if (first) { hf = f; hh = h; hid = id; first = false; }
-          const bool less = f < bf || (f == bf && (h < bh || (h == bh && id < bi)));
-          if (less) { bf = f; bh = h; bi = id; bslot = cc * 64 + lane; }
+          int f = 0x7fffffff, id = 0x7fffffff;
+          if (lane < ccnt) { f = (int)e[lane]; id = (int)e[64 + lane]; }
+          if (first) { hf = f; hid = id; first = false; }
+          if (f < bf || (f == bf && id < bi)) { bf = f; bi = id; bslot = cc * 64 + lane; }
           cc = rfl((int)cnext[cc]);
           ccnt = 64;
         }
       }
       const int mf = wave_min_i32(bf);
       bool cand = bf == mf;
-      const int mh = wave_min_i32(cand ? bh : 0x7fffffff);
-      cand = cand && bh == mh;
       const int id = wave_min_i32(cand ? bi : 0x7fffffff);
       cand = cand && bi == id;
       const int wl = (int)__builtin_ctzll(__ballot(cand));
       const int wslot = __builtin_amdgcn_readlane(bslot, wl);
-      // ---- remove it: the last entry of the head chunk takes its place
+      // ---- the cell and its 26 neighbours: every load depends on `id` only, so they all go out together
+      int cx, cy, cz;
+      {
+        cz = id / nxy;
+        const int rem = id - cz * nxy;
+        cy = rem / mv.nx;
+        cx = rem - cy * mv.nx;
+      }
+      const int x = cx + dx, y = cy + dy, z = cz + dz;
+      const bool inside = lane < 26 && !outside(x, y, z);
+      const int nid = inside ? index(x, y, z) : id;
+      const CellState cs = cells[id];
+      const CellState ns = cells[nid];
+      const unsigned occw = mv.bits[nid >> 5];
+      // ---- remove the popped entry: the last entry of the head chunk takes its place
       const int last = cnt - 1;
       if (wslot != hc * 64 + last) {
-        const int lf = __builtin_amdgcn_readlane(hf, last), lh = __builtin_amdgcn_readlane(hh, last), li = __builtin_amdgcn_readlane(hid, last);
+        const int lf = __builtin_amdgcn_readlane(hf, last), li = __builtin_amdgcn_readlane(hid, last);
         if (lane == 0) {
           unsigned* e = chunks + (size_t)(wslot >> 6) * CHUNK_WORDS + (wslot & 63);
-          e[0] = (unsigned)lf; e[64] = (unsigned)lh; e[128] = (unsigned)li;
+          e[0] = (unsigned)lf; e[64] = (unsigned)li;
         }
       }
-      cnt--;
-      if (cnt == 0) {
+      if (last == 0) {
         const int nh = rfl((int)cnext[hc]);
         bhead[b] = (short)nh;
         bcnt[b] = (short)(nh >= 0 ? 64 : 0);
-        cnext[hc] = (short)free_head;
-        free_head = hc;
-      } else bcnt[b] = (short)cnt;
+        fstack[ftop++] = (short)hc;
+      } else bcnt[b] = (short)last;
       n_open--;
-      // ---- the cell
-      const CellState cs = cells[id];
       if (cs.stamp == st_closed) continue;  // a stale duplicate: the cell was expanded from a better entry
       if (lane == 0) cells[id].stamp = st_closed;
       if (id == tid) { found = true; break; }
       expansions++;
-      const double g = cs.g;
-      int cx, cy, cz;
-      decode(id, cx, cy, cz);
-      // ---- relax the 26 neighbours, one per lane
-      const int x = cx + dx, y = cy + dy, z = cz + dz;
-      bool ok = lane < 26 && is_free(x, y, z);
-      int nid = 0, key = 0, h2 = 0, babs = 0x7fffffff;
+      // ---- relax, one neighbour per lane
+      bool ok = inside && (freed(x, y, z) || !((occw >> (nid & 31)) & 1u));
+      int key = 0, babs = 0x7fffffff;
       if (ok) {
-        nid = index(x, y, z);
-        const CellState ns = cells[nid];
         const bool visited = (ns.stamp >> 1) == serial;
-        const double ng = g + step;
+        const double ng = cs.g + step;
         if (visited && ((ns.stamp & 1u) || !(ng < ns.g))) ok = false;
         else {
           CellState w; w.g = ng; w.parent = id; w.stamp = st_open;
           cells[nid] = w;
-          h2 = (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
+          const int h2 = (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
           const double f = ng + sqrt((double)h2);
           if (f >= 2040.0) { limit = 1; ok = false; }
           else { key = (int)(f * KEY_SCALE); babs = key >> BK_SHIFT; }
         }
       }
       unsigned long long pend = __ballot(ok);
-      if (pend) {
-        const int lo = wave_min_i32(babs);
-        if (lo < cur_abs) cur_abs = lo;
-      }
-      // ---- append, lanes grouped by bucket
+      if (__ballot(ok && babs < cur_abs)) cur_abs = wave_min_i32(babs);  // (rounding can put a child one bucket below its parent)
+      // ---- append, lanes grouped by bucket; bucket state and the next free chunks are fetched for all groups at once
+      const int my_b = babs & (NBK - 1);
+      const int my_head = ok ? (int)bhead[my_b] : -1, my_cnt = ok ? (int)bcnt[my_b] : 0;
+      const int my_free = (lane < 32 && lane < ftop) ? (int)fstack[ftop - 1 - lane] : -1;
+      int used = 0;
       while (pend) {
         const int l0 = (int)__builtin_ctzll(pend);
         const int bb = __builtin_amdgcn_readlane(babs, l0);
@@ -339,10 +348,11 @@ struct Planner {
         pend &= ~grp;
         const int kk = (int)__popcll(grp), rank = rank_in(grp);
         const int bidx = bb & (NBK - 1);
-        int c0 = rfl((int)bhead[bidx]), cn = rfl((int)bcnt[bidx]);
+        int c0 = __builtin_amdgcn_readlane(my_head, l0), cn = __builtin_amdgcn_readlane(my_cnt, l0);
         if (c0 < 0 || cn == 64) {
-          const int nc = alloc_chunk();
-          if (nc < 0) { limit = 1; pend = 0; break; }
+          const int nc = used < 32 ? __builtin_amdgcn_readlane(my_free, used) : -1;
+          used++;
+          if (nc < 0) { limit = 1; break; }
           cnext[nc] = (short)c0;
           c0 = nc; cn = 0;
           bhead[bidx] = (short)c0;
@@ -350,34 +360,41 @@ struct Planner {
         const int space = 64 - cn;
         if (mine && rank < space) {
           unsigned* e = chunks + (size_t)c0 * CHUNK_WORDS + cn + rank;
-          e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+          e[0] = (unsigned)key; e[64] = (unsigned)nid;
         }
         if (kk > space) {
-          const int nc = alloc_chunk();
-          if (nc < 0) { limit = 1; pend = 0; break; }
+          const int nc = used < 32 ? __builtin_amdgcn_readlane(my_free, used) : -1;
+          used++;
+          if (nc < 0) { limit = 1; break; }
           cnext[nc] = (short)c0;
           bhead[bidx] = (short)nc;
           if (mine && rank >= space) {
             unsigned* e = chunks + (size_t)nc * CHUNK_WORDS + (rank - space);
-            e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+            e[0] = (unsigned)key; e[64] = (unsigned)nid;
           }
           bcnt[bidx] = (short)(kk - space);
         } else bcnt[bidx] = (short)(cn + kk);
         n_open += kk;
       }
+      ftop -= used;
       if (__ballot(limit != 0)) return -2;
     }
     if (!found) return 0;
 
     // ---- raw cell path, goal -> start
+    raw = (int*)chunks;
+    va = raw + MAXRAW;
+    vb = va + MAXRAW;
     int len = 0;
     for (int id = tid;;) {
       if (len >= MAXRAW) return -2;
-      raw[len++] = id;
+      if (lane == 0) raw[len] = id;
+      len++;
       if (id == sid) break;
       id = rfl(cells[id].parent);
       if (id < 0) break;
     }
+    settle();
     // ---- removeLinePts (jps_planner.cpp:83-105) on the start -> goal order: raw[len-1-i]
     int na = 0;
     if (len < 3) {
@@ -405,16 +422,21 @@ struct Planner {
         na += (int)__popcll(m);
       }
     }
+    settle();
     // ---- removeCornerPts forwards, then on the reversed path, then back (jps_planner.cpp:286-291)
     int nb = remove_corner_points(va, na, vb);
+    settle();
     for (int i = lane; i < nb; i += 64) va[i] = vb[nb - 1 - i];
+    settle();
     const int nc = remove_corner_points(va, nb, vb);
+    settle();
     for (int i = lane; i < nc; i += 64) va[i] = vb[nc - 1 - i];
+    settle();
     return nc;
   }
 };
 
-constexpr int PLAN_LDS_BYTES = NBK * 2 * 2 + NCHUNK * 2 + 3 * MAXRAW * 4;
+constexpr int PLAN_LDS_BYTES = NBK * 2 * 2 + NCHUNK * 2 * 2;
 
 // One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
 // (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
@@ -453,11 +475,9 @@ __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
       // createMoreVertexes / zero-length legs / deleteVertexes are sequential and short: lane 0 walks the legs
       if (lane == 0) {
         int w = 0;
-        bool over = false;
         double prev[3] = {st[0], st[1], st[2]};
         auto put = [&](const double p[3]) {
           if (w < pa.max_points) { out[3 * w] = p[0]; out[3 * w + 1] = p[1]; out[3 * w + 2] = p[2]; }
-          else over = true;
           w++;
         };
         put(prev);
@@ -481,8 +501,8 @@ __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
           put(nxt);
           prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];
         }
-        if (pa.max_poly > 0 && w > pa.max_poly + 1) { w = pa.max_poly + 1; over = false; }
-        np = over ? -1 : w;
+        if (pa.max_poly > 0 && w > pa.max_poly + 1) w = pa.max_poly + 1;
+        np = w > pa.max_points ? -1 : w;
       }
       np = rfl(np);
     }

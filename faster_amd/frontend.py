@@ -23,6 +23,8 @@ def lib():
         L.ff_decompose.argtypes = [vp, i32, vp, i32, vp, f64, f64, vp, i32, vp, vp]
         L.ff_plan.restype = i32
         L.ff_plan.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, vp, i32]
+        L.ff_plan_batch.restype = i32
+        L.ff_plan_batch.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp]
         L.ff_corridor_batch.restype = i32
         L.ff_corridor_batch.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, f64, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp]
         _LIB = L
@@ -58,26 +60,35 @@ def plan(cloud, cells, res, center, z_ground, z_max, inflation, start, goal, max
     return out[:k].copy() if k > 0 else None
 
 
-def forest_cloud(seed, size=(20.0, 20.0, 3.0), density=0.1, radius=0.3, spacing=0.15):
-    """Random forest of vertical cylinders (BASELINE config 5: 20 x 20 x 3 m, r = 0.3 m, 0.1 trees/m^2) sampled as the
-    occupied-point cloud a mapper would deliver (surface points every `spacing` m)."""
-    rng = np.random.default_rng(seed)
-    n_trees = int(round(density * size[0] * size[1]))
-    centres = rng.uniform([0.5, 0.5], [size[0] - 0.5, size[1] - 0.5], size=(n_trees, 2))
-    ang = np.arange(0, 2 * np.pi, spacing / radius)
-    zs = np.arange(0.0, size[2] + 1e-9, spacing)
-    ring = np.stack([radius * np.cos(ang), radius * np.sin(ang)], axis=1)
-    pts = (centres[:, None, None, :] + ring[None, None, :, :]) + np.zeros((1, len(zs), 1, 1))
-    cloud = np.concatenate([pts.reshape(-1, 2), np.tile(np.repeat(zs, len(ang)), n_trees)[:, None]], axis=1)
-    return cloud, centres
+def plan_batch(cloud, cells, res, center, z_ground, z_max, inflation, starts, goals, max_points=64, max_vertex_dist=0.0, max_poly=0,
+               want_grid=False):
+    """n queries over one map on the CPU (OpenMP): the counterpart of capi.Map.plan_batch, same outputs
+    (paths [n][max_points][3], n_points [n], expansions [n]) (+ occupancy [nz][ny][nx], dims, origin with want_grid)."""
+    cloud = _c(cloud).reshape(-1, 3)
+    starts, goals = _c(starts).reshape(-1, 3), _c(goals).reshape(-1, 3)
+    n = len(starts)
+    paths = np.zeros((n, max_points, 3))
+    npts = np.zeros(n, dtype=np.int32)
+    ex = np.zeros(n, dtype=np.int64)
+    dims = np.zeros(3, dtype=np.int32)
+    origin = np.zeros(3)
+    occ = None
+    if want_grid:  # geometry first (the grid size is an output)
+        lib().ff_plan_batch(abi.ptr(cloud) if len(cloud) else None, 0, int(cells[0]), int(cells[1]), int(cells[2]), res, abi.ptr(_c(center)),
+                            z_ground, z_max, inflation, None, None, 0, max_points, 0.0, 0, None, abi.ptr(npts), None, None, abi.ptr(dims),
+                            abi.ptr(origin))
+        occ = np.zeros(int(dims[0]) * int(dims[1]) * int(dims[2]), dtype=np.int8)
+    lib().ff_plan_batch(abi.ptr(cloud) if len(cloud) else None, len(cloud), int(cells[0]), int(cells[1]), int(cells[2]), res,
+                        abi.ptr(_c(center)), z_ground, z_max, inflation, abi.ptr(starts), abi.ptr(goals), n, max_points, max_vertex_dist,
+                        max_poly, abi.ptr(paths), abi.ptr(npts), abi.ptr(ex), abi.ptr(occ) if occ is not None else None, abi.ptr(dims),
+                        abi.ptr(origin))
+    if want_grid:
+        return paths, npts, ex, occ.reshape(int(dims[2]), int(dims[1]), int(dims[0])), dims, origin
+    return paths, npts, ex
 
 
-def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, drone_radius=0.05,
-                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, **kw):
-    """BASELINE config 5: n start/goal pairs in one random forest; corridors from the voxel path search + ellipsoid
-    decomposition (this front-end).  Returns (problems, faces, info)."""
-    from . import corridor
-
+def forest_queries(n, seed, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, min_goal_dist=6.0, return_rng=False):
+    """The map and the start/goal pairs of BASELINE config 5 (what forest_batch searches): cloud, cells, center, starts, goals."""
     rng = np.random.default_rng(seed + 1)
     cloud, centres = forest_cloud(seed, size)
 
@@ -98,6 +109,32 @@ def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20
         goals[near] = free_points(int(near.sum()))
     cells = (int(size[0] / res) + 10, int(size[1] / res) + 10, int(size[2] / res))
     center = np.array([size[0] / 2, size[1] / 2, size[2] / 2])
+    if return_rng:
+        return cloud, cells, center, starts, goals, rng
+    return cloud, cells, center, starts, goals
+
+
+def forest_cloud(seed, size=(20.0, 20.0, 3.0), density=0.1, radius=0.3, spacing=0.15):
+    """Random forest of vertical cylinders (BASELINE config 5: 20 x 20 x 3 m, r = 0.3 m, 0.1 trees/m^2) sampled as the
+    occupied-point cloud a mapper would deliver (surface points every `spacing` m)."""
+    rng = np.random.default_rng(seed)
+    n_trees = int(round(density * size[0] * size[1]))
+    centres = rng.uniform([0.5, 0.5], [size[0] - 0.5, size[1] - 0.5], size=(n_trees, 2))
+    ang = np.arange(0, 2 * np.pi, spacing / radius)
+    zs = np.arange(0.0, size[2] + 1e-9, spacing)
+    ring = np.stack([radius * np.cos(ang), radius * np.sin(ang)], axis=1)
+    pts = (centres[:, None, None, :] + ring[None, None, :, :]) + np.zeros((1, len(zs), 1, 1))
+    cloud = np.concatenate([pts.reshape(-1, 2), np.tile(np.repeat(zs, len(ang)), n_trees)[:, None]], axis=1)
+    return cloud, centres
+
+
+def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, drone_radius=0.05,
+                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, **kw):
+    """BASELINE config 5: n start/goal pairs in one random forest; corridors from the voxel path search + ellipsoid
+    decomposition (this front-end).  Returns (problems, faces, info)."""
+    from . import corridor
+
+    cloud, cells, center, starts, goals, rng = forest_queries(n, seed, size, res, inflation, min_goal_dist, return_rng=True)
     faces = np.zeros((n, faces_per_problem, 4))
     face_off = np.zeros((n, 9), dtype=np.int32)
     n_poly = np.zeros(n, dtype=np.int32)

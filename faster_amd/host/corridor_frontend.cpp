@@ -45,20 +45,26 @@ std::vector<V3> remove_corner_points(const VoxelGrid& g, const std::vector<V3>& 
   return out;
 }
 
+// Open-list order.  jps3d compares f with a 1e-6 tolerance and prefers the larger g on ties (graph_search.h:19-29) — not a strict
+// weak order, so the expansion order depends on the heap implementation.  Here the order is a strict TOTAL one: f quantised to
+// 2^-20 cells, then the cell index (the larger-g preference changes the number of expansions by 0.3 % in the forest maps — with
+// step costs 1, sqrt 2, sqrt 3 exact ties in f between different cells are rare — and is dropped).  Any priority queue then expands
+// the same cells in the same order — the device search (csrc/fh_path.hip.hpp, a bucket queue) is checked against this function
+// vertex for vertex.
 struct Node {
-  double f, g;
-  int id;
+  int key, id;
 };
-struct NodeOrder {  // graph_search.h:19-29: smaller f first; on (near) ties the larger g first
+struct NodeOrder {
   bool operator()(const Node& a, const Node& b) const {
-    if (a.f >= b.f - 1e-6 && a.f <= b.f + 1e-6) return a.g < b.g;
-    return a.f > b.f;
+    if (a.key != b.key) return a.key > b.key;
+    return a.id > b.id;
   }
 };
+constexpr double kKeyScale = 1048576.0;
 
 }  // namespace
 
-bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double inflation, std::vector<V3>& path) {
+bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double inflation, std::vector<V3>& path, long long* expansions) {
   path.clear();
   const V3 start(start_in.x, start_in.y, std::max(start_in.z, 0.0)), goal(goal_in.x, goal_in.y, std::max(goal_in.z, 0.0));
   int s[3], t[3];
@@ -74,18 +80,25 @@ bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double in
   std::vector<char> closed((size_t)total, 0);
   std::priority_queue<Node, std::vector<Node>, NodeOrder> open;
   const int sid = grid.index(s[0], s[1], s[2]), tid = grid.index(t[0], t[1], t[2]);
-  auto heur = [&](int x, int y, int z) {
-    return std::sqrt((double)(x - t[0]) * (x - t[0]) + (double)(y - t[1]) * (y - t[1]) + (double)(z - t[2]) * (z - t[2]));
+  auto dist2 = [&](int x, int y, int z) {
+    return (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
   };
   gval[sid] = 0;
-  open.push({heur(s[0], s[1], s[2]), 0.0, sid});
+  {
+    const int h2 = dist2(s[0], s[1], s[2]);
+    const double f = 0.0 + std::sqrt((double)h2);
+    if (f >= 2040.0) return false;  // the key range of the device search (fh_map_plan_batch reports -2)
+    open.push({(int)(f * kKeyScale), sid});
+  }
   bool found = false;
   while (!open.empty()) {
     const Node cur = open.top();
     open.pop();
-    if (closed[cur.id]) continue;
+    if (closed[cur.id]) continue;  // a stale duplicate: the cell was expanded from a better entry
     closed[cur.id] = 1;
     if (cur.id == tid) { found = true; break; }
+    if (expansions) ++*expansions;
+    const double g = gval[cur.id];
     const int cz = cur.id / (grid.nx * grid.ny), rem = cur.id - cz * grid.nx * grid.ny, cy = rem / grid.nx, cx = rem - cy * grid.nx;
     for (int dx = -1; dx <= 1; dx++)
       for (int dy = -1; dy <= 1; dy++)
@@ -95,11 +108,14 @@ bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double in
           if (!grid.is_free(x, y, z)) continue;
           const int id = grid.index(x, y, z);
           if (closed[id]) continue;
-          const double ng = cur.g + std::sqrt((double)(dx * dx + dy * dy + dz * dz));
+          const double ng = g + std::sqrt((double)(dx * dx + dy * dy + dz * dz));
           if (ng < gval[id]) {
             gval[id] = ng;
             parent[id] = cur.id;
-            open.push({ng + heur(x, y, z), ng, id});
+            const int h2 = dist2(x, y, z);
+            const double f = ng + std::sqrt((double)h2);
+            if (f >= 2040.0) return false;
+            open.push({(int)(f * kKeyScale), id});
           }
         }
   }
@@ -186,6 +202,69 @@ int ff_plan(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y, int 
   return (int)path.size();
 }
 
+
+// Faster::createMoreVertexes (faster/src/faster.cpp:80-97: legs longer than `max_vertex_dist` are cut, each new vertex one
+// spacing beyond the previous one) and deleteVertexes (faster/src/utils.cpp:1117-1124: at most max_poly legs kept).
+// createMoreVertexes repeats the end point when a leg is an exact multiple of the spacing; the reference would then decompose a
+// zero-length segment — dropped here.
+static void refine_vertices(std::vector<fhfront::V3>& path, double max_vertex_dist, int max_poly) {
+  using fhfront::V3;
+  if (max_vertex_dist > 0.0) {
+    for (size_t j = 0; j + 1 < path.size(); j++) {
+      const double dist = (path[j + 1] - path[j]).norm();
+      const int add = (int)std::floor(dist / max_vertex_dist);
+      if (dist > max_vertex_dist) {
+        const V3 v = (path[j + 1] - path[j]).normalized();
+        for (int k = 0; k < add; k++) {
+          path.insert(path.begin() + j + 1, path[j] + v * max_vertex_dist);
+          j++;
+        }
+      }
+    }
+    for (size_t j = 0; j + 1 < path.size();) {
+      if ((path[j + 1] - path[j]).norm() < 1e-9) path.erase(path.begin() + j + 1);
+      else j++;
+    }
+  }
+  if (max_poly > 0 && (int)path.size() > max_poly + 1) path.resize(max_poly + 1);
+}
+
+// n start/goal queries over one map (OpenMP over queries): the CPU counterpart of fh_map_plan_batch (include/fasterhip.h), same
+// arguments and outputs; occ (may be NULL) receives the grid, dims/origin its geometry.
+int ff_plan_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y, int cells_z, double res, const double* center,
+                  double z_ground, double z_max, double inflation, const double* starts, const double* goals, int n, int max_points,
+                  double max_vertex_dist, int max_poly, double* paths, int* n_points, long long* expansions, signed char* occ, int* dims,
+                  double* origin) {
+  using namespace fhfront;
+  std::vector<V3> cloud;
+  for (int i = 0; i < n_cloud; i++) cloud.push_back(V3(cloud_xyz[3 * i], cloud_xyz[3 * i + 1], cloud_xyz[3 * i + 2]));
+  VoxelGrid base;
+  base.build(cloud, cells_x, cells_y, cells_z, res, V3(center[0], center[1], center[2]), z_ground, z_max, inflation);
+  if (dims) { dims[0] = base.nx; dims[1] = base.ny; dims[2] = base.nz; }
+  if (origin) { origin[0] = base.origin[0]; origin[1] = base.origin[1]; origin[2] = base.origin[2]; }
+  if (occ) std::memcpy(occ, base.occ.data(), base.occ.size());
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int i = 0; i < n; i++) {
+    VoxelGrid g = base;  // the search frees the cells around start and goal
+    std::vector<V3> path;
+    long long ex = 0;
+    const bool ok = plan_path(g, V3(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), V3(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]),
+                              inflation, path, &ex);
+    if (expansions) expansions[i] = ex;
+    n_points[i] = 0;
+    if (!ok) continue;
+    // the clean-up walks past max_points like the device: deleteVertexes may bring an over-long list back under the limit
+    refine_vertices(path, max_vertex_dist, max_poly);
+    if ((int)path.size() > max_points) { n_points[i] = -1; continue; }
+    n_points[i] = (int)path.size();
+    for (size_t j = 0; j < path.size(); j++) {
+      double* o = paths + 3 * ((size_t)i * max_points + j);
+      o[0] = path[j].x; o[1] = path[j].y; o[2] = path[j].z;
+    }
+  }
+  return 0;
+}
+
 // Batch corridor generation for Monte-Carlo workloads (BASELINE config 5): one shared cloud, n start/goal pairs.
 // Per pair: voxel path search -> Faster::createMoreVertexes (faster/src/faster.cpp:80-97, segments longer than
 // `max_vertex_dist` are cut) -> deleteVertexes (faster/src/utils.cpp:1117-1124, at most max_poly segments kept) ->
@@ -210,24 +289,7 @@ int ff_corridor_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cel
     const V3 s(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), t(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]);
     goal_out[3 * i] = t.x; goal_out[3 * i + 1] = t.y; goal_out[3 * i + 2] = t.z;
     if (!plan_path(g, s, t, inflation, path)) continue;
-    for (size_t j = 0; j + 1 < path.size(); j++) {  // createMoreVertexes
-      const double dist = (path[j + 1] - path[j]).norm();
-      const int add = (int)std::floor(dist / max_vertex_dist);
-      if (dist > max_vertex_dist) {
-        const V3 v = (path[j + 1] - path[j]).normalized();
-        for (int k = 0; k < add; k++) {
-          path.insert(path.begin() + j + 1, path[j] + v * max_vertex_dist);
-          j++;
-        }
-      }
-    }
-    // (createMoreVertexes repeats the end point when a leg is an exact multiple of the spacing; the reference would then
-    //  decompose a zero-length segment — dropped here)
-    for (size_t j = 0; j + 1 < path.size();) {
-      if ((path[j + 1] - path[j]).norm() < 1e-9) path.erase(path.begin() + j + 1);
-      else j++;
-    }
-    if ((int)path.size() > max_poly + 1) path.resize(max_poly + 1);  // deleteVertexes
+    refine_vertices(path, max_vertex_dist, max_poly);
     const std::vector<LinearConstraint> cs = decompose_path(path, cloud, drone_radius, z_ground);
     int total = 0;
     bool fits = true;

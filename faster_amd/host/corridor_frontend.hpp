@@ -351,6 +351,7 @@ struct VoxelGrid {
 
 // 26-connected A* with Euclidean step costs and heuristic (graph_search.cpp:73-75), then jps3d's path clean-up
 // (jps_planner.cpp:286-291).  Returns false if start/goal are not free or no path exists.
-bool plan_path(VoxelGrid& grid, const V3& start, const V3& goal, double inflation, std::vector<V3>& path);
+bool plan_path(VoxelGrid& grid, const V3& start, const V3& goal, double inflation, std::vector<V3>& path,
+               long long* expansions = nullptr);
 
 }  // namespace fhfront

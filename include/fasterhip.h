@@ -268,6 +268,39 @@ int fh_pool_solve_pairs(fh_pool* pool, const fh_problem* whole, const fh_face* f
                         const fh_problem* safe_templates, double r_frac, double shrink, int max_safe_poly, fh_result* whole_results,
                         fh_result* safe_results, int root, fh_result* d_whole_results_root, fh_result* d_safe_results_root);
 
+/* ---- voxel map + batched path search on the device (first half) ------------------------------------------
+ * fh_map replaces the pair JPS_Manager::updateJPSMap / JPS_Manager::solveJPS3D (faster/src/jps_manager.cpp:129-139, :141-200):
+ *   fh_map_read[_device]   = MapUtil::readMap (faster/include/read_map.hpp:30-185): occupancy grid of cells[] cells of `res` metres
+ *                            centred on `center` (x, y widened by 5*inflation/res cells, z clipped to [z_ground, z_max]); every cloud
+ *                            point marks its cell and the cube of +-floor(inflation/res) cells around it;
+ *   fh_map_plan_batch[_device] = solveJPS3D for n independent start/goal queries over that map: z clamped to >= 0, the cells around
+ *                            start and goal freed (setFreeVoxelAndSurroundings; per query, the map itself is not modified), optimal
+ *                            26-connected grid path with Euclidean costs, jps3d's clean-up (removeLinePts, removeCornerPts forwards and
+ *                            backwards), ends forced onto the requested points.  One query per wavefront.
+ *   With max_vertex_dist > 0 the vertices additionally go through Faster::createMoreVertexes (faster/src/faster.cpp:80-97) and, with
+ *   max_poly > 0, deleteVertexes (faster/src/utils.cpp:1117-1124): what Faster::replan hands to the convex decomposition.
+ * paths: [n][max_points][3]; n_points[i]: number of vertices, 0 = no path (start/goal outside the map or not connected),
+ * -1 = more than max_points vertices, -2 = a search limit was hit (f >= 2040 cells, 131072 open entries, 1024 raw path cells).
+ * expansions (may be NULL): cells expanded per query.  The CPU restatement the kernels are checked against vertex for vertex is
+ * faster_amd/host/corridor_frontend.cpp (plan_path).  One stream per map; entry points of one map are not re-entrant.
+ * No CPU fallback: FH_ERR_DEVICE without a device. */
+typedef struct fh_map fh_map;
+int fh_map_create(fh_map** out, int device);
+void fh_map_destroy(fh_map* map);
+const char* fh_map_last_error(const fh_map* map);
+int fh_map_set_stream(fh_map* map, void* hip_stream);
+int fh_map_sync(fh_map* map);
+int fh_map_read(fh_map* map, const double* cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3],
+                double z_ground, double z_max, double inflation);
+int fh_map_read_device(fh_map* map, const double* d_cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3],
+                       double z_ground, double z_max, double inflation);
+int fh_map_dims(const fh_map* map, int32_t dims[3], double origin[3]);
+int fh_map_occupancy(fh_map* map, int8_t* occ); /* [nz][ny][nx], 0 free / 100 occupied, as MapUtil stores it */
+int fh_map_plan_batch(fh_map* map, const double* starts, const double* goals, int n, int max_points, double max_vertex_dist,
+                      int max_poly, double* paths, int32_t* n_points, int64_t* expansions);
+int fh_map_plan_batch_device(fh_map* map, const double* d_starts, const double* d_goals, int n, int max_points, double max_vertex_dist,
+                             int max_poly, double* d_paths, int32_t* d_n_points, int64_t* d_expansions);
+
 /* Timing of the solve kernel, measured with HIP events recorded around every solve-kernel launch on
  * the context stream (the same stream the kernel runs on).  fh_timing_reset() forgets recorded launches;
  * fh_timing_read() synchronises with the last recorded launch and writes the duration (ms) of up to

@@ -90,6 +90,11 @@ def test_no_cpu_fallback_without_gpu(built):
     assert capi.lib().fh_solve_batch(h, abi.ptr(pr), None, 0, 1, abi.ptr(res)) == -2
     assert capi.lib().fh_sync(h) == -2
     capi.lib().fh_destroy(h)
+    # the voxel map / path search and the device pool have no CPU path either
+    with pytest.raises(capi.FasterHipError):
+        capi.Map(0)
+    mh = ctypes.c_void_p()
+    assert capi.lib().fh_map_create(ctypes.byref(mh), 0) == -2 and not mh.value
 
 
 def test_product_does_not_import_the_oracle():

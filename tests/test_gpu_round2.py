@@ -315,3 +315,91 @@ def test_solver_hip_stop_execution_from_another_thread(tmp_path):
     print(r.stdout[-600:])
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "STOP_OK" in r.stdout
+
+
+# ---- voxel map + batched path search on the device (fh_map_*), SURVEY.md 8(f) N1 first half -------------------------------------
+
+def _compare_plans(host, dev, refined=False):
+    hp, hn, hex_ = host
+    dp, dn, dex = dev
+    assert np.array_equal(hn, dn), "vertex counts differ at %s" % np.nonzero(hn != dn)[0][:8]
+    assert np.array_equal(hex_, dex), "the device expanded other cells than the host (same total order => same expansions)"
+    for i in np.nonzero(hn > 0)[0]:
+        if refined:   # createMoreVertexes divides by a computed norm: last-bit differences of sqrt are allowed
+            np.testing.assert_allclose(dp[i, :hn[i]], hp[i, :hn[i]], rtol=0, atol=1e-12)
+        else:         # cell centres and the requested end points: exact
+            assert np.array_equal(dp[i, :hn[i]], hp[i, :hn[i]]), i
+
+
+@pytest.mark.gpu
+def test_device_map_and_path_search_equal_host_frontend():
+    """fh_map_read == MapUtil::readMap restatement (occupancy cell for cell), fh_map_plan_batch == plan_path (vertices bit for bit,
+    the same number of expanded cells) on the forest of BASELINE config 5; then the vertices Faster::replan would decompose."""
+    from faster_amd import frontend
+
+    n = 4096
+    res, infl, zmax = 0.2, 0.3, 3.0
+    cloud, cells, center, starts, goals = frontend.forest_queries(n, 21)
+    hp, hn, hex_, hocc, hdims, horig = frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, want_grid=True)
+    m = capi.Map(0)
+    m.read(cloud, cells, res, center, 0.0, zmax, infl)
+    dims, orig = m.dims()
+    assert np.array_equal(dims, hdims) and np.array_equal(orig, horig)
+    assert np.array_equal(m.occupancy(), hocc)
+    assert (hn > 0).mean() > 0.95 and hex_.mean() > 1000
+    _compare_plans((hp, hn, hex_), m.plan_batch(starts, goals))
+    _compare_plans(frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, max_points=16, max_vertex_dist=1.5, max_poly=8),
+                   m.plan_batch(starts, goals, max_points=16, max_vertex_dist=1.5, max_poly=8), refined=True)
+    # a second call on the same map object reuses the per-wavefront state (serial numbers instead of clearing)
+    _compare_plans((hp, hn, hex_), m.plan_batch(starts, goals))
+    # max_points too small is reported per query, not silently truncated
+    _, dn_small, _ = m.plan_batch(starts[:256], goals[:256], max_points=3)
+    assert np.array_equal(dn_small, np.where(hn[:256] > 3, -1, hn[:256]))
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["wall", "empty", "coarse", "tall"])
+def test_device_path_search_edge_cases(case):
+    from faster_amd import frontend
+
+    rng = np.random.default_rng(3)
+    res, infl, zg, zmax = 0.25, 0.25, 0.0, 2.0
+    cells, center = (40, 40, 8), np.array([5.0, 5.0, 1.0])
+    if case == "wall":      # a full plane x = 5: nothing on the right is reachable from the left
+        yy, zz = np.meshgrid(np.arange(-3, 13, 0.1), np.arange(-1, 3, 0.1))
+        cloud = np.column_stack([np.full(yy.size, 5.0), yy.ravel(), zz.ravel()])
+    elif case == "empty":
+        cloud = np.zeros((0, 3))
+    elif case == "coarse":  # inflation smaller than a cell (no cube), coarse cells
+        cloud, _ = frontend.forest_cloud(4, size=(10.0, 10.0, 2.0), density=0.2)
+        res, infl = 0.5, 0.2
+        cells = (20, 20, 4)
+    else:                   # map centred high above the ground: z clipping of readMap on both sides
+        cloud, _ = frontend.forest_cloud(5, size=(10.0, 10.0, 2.0), density=0.2)
+        center = np.array([5.0, 5.0, 1.7])
+        cells = (40, 40, 12)
+    n = 256
+    starts = np.column_stack([rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
+    goals = np.column_stack([rng.uniform(6.0, 9.5, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
+    goals[:8] = starts[:8] + 0.01            # same cell: the path is [start, goal] (jps_manager.cpp:181-186)
+    goals[8] = starts[8]                     # identical points
+    starts[9] = [-50.0, 5.0, 1.0]            # outside the map: no path
+    goals[10] = [5.0, 500.0, 1.0]
+    starts[11, 2] = -0.7                     # z clamped to 0 (jps_manager.cpp:143-144)
+    goals[12, 2] = -0.2
+    starts[13] = goals[13] - [0.3, 0.0, 0.0]  # neighbouring cells
+    host = frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals, want_grid=True)
+    m = capi.Map(0)
+    m.read(cloud, cells, res, center, zg, zmax, infl)
+    assert np.array_equal(m.occupancy(), host[3])
+    dev = m.plan_batch(starts, goals)
+    _compare_plans(host[:3], dev)
+    assert dev[1][9] == 0 and dev[1][10] == 0
+    if case == "wall":
+        assert (dev[1][16:] == 0).all(), "paths through a closed wall"
+    if case == "empty":
+        assert (dev[1][16:] == 2).all(), "free space: the cleaned path is the straight leg"
+    _compare_plans(frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals, max_points=24, max_vertex_dist=0.7, max_poly=0),
+                   m.plan_batch(starts, goals, max_points=24, max_vertex_dist=0.7, max_poly=0), refined=True)
+    m.close()
