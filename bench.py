@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--workload", choices=["c4", "c5"], default="c4",
                     help="c4 (default, the metric's configuration): synthetic corridors; c5: Monte-Carlo forest, corridors from the "
                          "voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes (BASELINE config 5)")
+    ap.add_argument("--front", choices=["device", "host"], default="device",
+                    help="c5 only: where the corridors come from — the device front-end (fh_map_* path search + fh_corridor_batch_device, "
+                         "default) or the CPU front-end (same results: tests/test_gpu_round2.py)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--r-margin", type=float, default=0.05,
                     help="hand-off keeps R at least this far inside its safe corridor (FASTER decomposes the safe corridor around R); "
@@ -140,7 +143,15 @@ def main():
         fb.build_frontend()
         N = args.n_seg = 15
         args.max_poly = 8
-        whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8)
+        if args.front == "device":
+            fctx, fmap = capi.Context(local_rank), capi.Map(local_rank)
+            frontend.forest_batch(256, seed=seed + 2, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank)  # allocations
+            whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap,
+                                                        device=local_rank)
+            fctx.close()
+            fmap.close()
+        else:
+            whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8)
     else:
         whole, faces, _ = corridor.whole_batch(args.pairs, seed=seed, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
     total_pairs = len(whole)  # (c5: pairs without a path are dropped)
@@ -288,6 +299,9 @@ def main():
                 "mean_bnb_nodes_safe": float(sres["nodes"].mean()),
                 "mean_qp_iters_per_pair": float(wres["qp_iters"].mean() + sres["qp_iters"].mean()),
                 "mean_trials_per_pair": float(wres["trials"].mean() + sres["trials"].mean()),
+                **({"front_end": {"where": finfo["front"], "timing": finfo["front_timing"], "pairs_without_path": finfo["no_path"],
+                                  "note": "corridor generation is outside the timed region (the metric is the solver's)"}}
+                   if args.workload == "c5" else {}),
                 "share_stats_last_launch": share_stats,
             },
             "roofline": {

@@ -17,7 +17,7 @@ SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
     "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_solve_pairs_device",
-    "fh_decompose_batch", "fh_decompose_batch_device",
+    "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
     "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_sync", "fh_map_read", "fh_map_read_device",
@@ -82,6 +82,8 @@ def lib():
         L.fh_decompose_batch.argtypes = [vp, vp, i32, vp, i32, vp, f64, f64, i32, vp, vp]
         L.fh_decompose_batch_device.restype = i32
         L.fh_decompose_batch_device.argtypes = [vp, vp, i32, vp, i32, vp, f64, f64, i32, vp, vp]
+        L.fh_corridor_batch_device.restype = i32
+        L.fh_corridor_batch_device.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, vp, f64, f64, i32, vp, vp, vp, vp]
         L.fh_sync.restype = i32
         L.fh_sync.argtypes = [vp]
         L.fh_pool_create.restype = i32
@@ -389,6 +391,13 @@ class Context:
         return faces, counts
 
     # ---- device-pointer entry points (raw addresses; memory owned by the caller, e.g. torch tensors) ----
+    def corridor_batch_device(self, d_cloud, n_cloud, d_paths, d_n_points, n, max_points, max_poly, faces_per_problem, d_faces, d_face_off,
+                              d_n_poly, d_goal=None, drone_radius=0.05, z_ground=0.0, bbox=(2.0, 2.0, 1.0)):
+        bbox = np.ascontiguousarray(bbox, dtype=np.float64)
+        self._check(lib().fh_corridor_batch_device(self._h, d_cloud, n_cloud, d_paths, d_n_points, n, max_points, max_poly, abi.ptr(bbox),
+                                                   float(drone_radius), float(z_ground), faces_per_problem, d_faces, d_face_off, d_n_poly,
+                                                   d_goal), "fh_corridor_batch_device")
+
     def solve_batch_device(self, d_problems, d_faces, n, max_seg, max_faces, d_results):
         self._check(lib().fh_solve_batch_device(self._h, d_problems, d_faces, n, max_seg, max_faces, d_results),
                     "fh_solve_batch_device")

@@ -29,8 +29,9 @@ struct fh_ctx {
   // staging buffers of the host-pointer entry points (grown on demand, reused)
   // slot 5: snapshot workspace, 6: work-sharing control block + ring sequence numbers, 7: decomposition workspace,
   // 8: task slots of the ring, 9: share records
-  void* d_buf[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // 10: corridor segments, 11: per-segment polytope rows, 12: per-segment row counts (fh_corridor_batch_device)
+  void* d_buf[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
   size_t lds_attr[6] = {0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
@@ -239,7 +240,7 @@ void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 13; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
     if (ctx->h_report) (void)hipHostFree(ctx->h_report);
@@ -640,6 +641,87 @@ int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const 
   FH_HIP(hipMemcpyAsync(faces, ctx->d_buf[3], fb, hipMemcpyDeviceToHost, ctx->stream));
   FH_HIP(hipMemcpyAsync(counts, ctx->d_buf[4], nb, hipMemcpyDeviceToHost, ctx->stream));
   FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+
+// ---- corridors of a batch of paths: segments -> decomposition -> polytope rows in the layout fh_problem points at ---------------
+namespace {
+// segment j of pair i = (vertex j, vertex j+1) of its path, NaN where the path has no such leg; goal = the last vertex kept
+__global__ void corridor_segments_kernel(const double* __restrict__ paths, const int32_t* __restrict__ n_points, int n, int max_points,
+                                         int max_poly, double* __restrict__ segments, double* __restrict__ goal) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * max_poly) return;
+  const int i = (int)(t / max_poly), j = (int)(t % max_poly);
+  const int np = n_points[i];
+  double* sg = segments + 6 * t;
+  if (np >= 2 && j + 1 < np) {
+    const double* v = paths + 3 * ((size_t)i * max_points + j);
+    for (int k = 0; k < 6; k++) sg[k] = v[k];
+  } else {
+    for (int k = 0; k < 6; k++) sg[k] = __builtin_nan("");
+  }
+  if (j == 0 && goal) {
+    for (int k = 0; k < 3; k++) goal[3 * (size_t)i + k] = np >= 2 ? paths[3 * ((size_t)i * max_points + (np - 1)) + k] : __builtin_nan("");
+  }
+}
+
+// one wavefront per pair: the rows of its polytopes back to back at faces[i * faces_per_problem ...], offsets as fh_problem.face_off
+__global__ void __launch_bounds__(64) corridor_assemble_kernel(const int32_t* __restrict__ n_points, int n, int max_poly, int seg_cap,
+                                                               const fh_face* __restrict__ seg_faces, const int32_t* __restrict__ seg_counts,
+                                                               int faces_per_problem, fh_face* __restrict__ faces,
+                                                               int32_t* __restrict__ face_off, int32_t* __restrict__ n_poly) {
+  const int i = (int)blockIdx.x, lane = (int)threadIdx.x;
+  if (i >= n) return;
+  const int np = n_points[i];
+  const int legs = np >= 2 ? np - 1 : 0;
+  int total = 0;
+  bool fits = legs > 0 && legs <= max_poly && legs <= FH_MAX_POLY;
+  for (int p = 0; p < legs && fits; p++) {
+    const int c = seg_counts[(size_t)i * max_poly + p];
+    if (c <= 0 || total + c > faces_per_problem) { fits = false; break; }
+    const fh_face* src = seg_faces + ((size_t)i * max_poly + p) * seg_cap;
+    for (int r = lane; r < c; r += 64) faces[(size_t)i * faces_per_problem + total + r] = src[r];
+    total += c;
+    if (lane == 0) face_off[9 * (size_t)i + p + 1] = total;
+  }
+  if (lane == 0) {
+    face_off[9 * (size_t)i] = 0;
+    if (fits) {
+      for (int p = legs; p < FH_MAX_POLY; p++) face_off[9 * (size_t)i + p + 1] = total;
+      n_poly[i] = legs;
+    } else {
+      for (int p = 0; p <= FH_MAX_POLY; p++) face_off[9 * (size_t)i + p] = 0;
+      n_poly[i] = 0;
+    }
+  }
+}
+}  // namespace
+
+int fh_corridor_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_paths, const int32_t* d_n_points, int n,
+                             int max_points, int max_poly, const double local_bbox[3], double drone_radius, double z_ground,
+                             int faces_per_problem, fh_face* d_faces, int32_t* d_face_off, int32_t* d_n_poly, double* d_goal) {
+  if (!ctx || n < 0 || n_cloud < 0 || max_points < 2 || max_poly < 1 || max_poly > FH_MAX_POLY || faces_per_problem < 8 || !local_bbox)
+    return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_paths || !d_n_points || !d_faces || !d_face_off || !d_n_poly || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
+  const size_t nseg = (size_t)n * max_poly;
+  if (nseg > (size_t)0x7fffffff) return FH_ERR_ARG;
+  const int seg_cap = FH_MAX_FACES_POLY;
+  int rc;
+  if ((rc = ensure(ctx, 10, sizeof(double) * 6 * nseg)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 11, sizeof(fh_face) * nseg * seg_cap)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 12, sizeof(int32_t) * nseg)) != FH_OK) return rc;
+  hipLaunchKernelGGL(corridor_segments_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, ctx->stream, d_paths, d_n_points, n, max_points,
+                     max_poly, (double*)ctx->d_buf[10], d_goal);
+  FH_HIP(hipGetLastError());
+  if ((rc = fh_decompose_batch_device(ctx, d_cloud_xyz, n_cloud, (const double*)ctx->d_buf[10], (int)nseg, local_bbox, drone_radius, z_ground,
+                                      seg_cap, (fh_face*)ctx->d_buf[11], (int32_t*)ctx->d_buf[12])) != FH_OK)
+    return rc;
+  hipLaunchKernelGGL(corridor_assemble_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_n_points, n, max_poly, seg_cap,
+                     (const fh_face*)ctx->d_buf[11], (const int32_t*)ctx->d_buf[12], faces_per_problem, d_faces, d_face_off, d_n_poly);
+  FH_HIP(hipGetLastError());
   return FH_OK;
 }
 

@@ -16,6 +16,10 @@
 #include "../../include/fasterhip.h"
 #include "fh_solve.hip.hpp"  // wave reductions
 
+// every decision of the decomposition (which point is closest, on which side of a plane a point lies) must fall as on the host:
+// the same products and sums, no fused multiply-adds
+#pragma clang fp contract(off)
+
 namespace fh {
 
 #define FH_DECOMP_CAP 1024  // obstacle points of interest per segment (points inside the local box); more => count = -1
@@ -42,17 +46,21 @@ __device__ __forceinline__ D3 mulT(const Rot& R, D3 v) {
   return d3(R.m[0][0] * v.x + R.m[1][0] * v.y + R.m[2][0] * v.z, R.m[0][1] * v.x + R.m[1][1] * v.y + R.m[2][1] * v.z,
             R.m[0][2] * v.x + R.m[1][2] * v.y + R.m[2][2] * v.z);
 }
-__device__ __forceinline__ Rot rot_onto(D3 v) {  // Rz(yaw) Ry(pitch), zero roll (geometric_utils.h:27-35)
-  const double pitch = atan2(-v.z, sqrt(v.x * v.x + v.y * v.y)), yaw = atan2(v.y, v.x);
-  const double cp = cos(pitch), sp = sin(pitch), cy = cos(yaw), sy = sin(yaw);
+// Rz(yaw) Ry(pitch), zero roll (geometric_utils.h:27-35); cosines and sines straight from the components, exactly as the host
+// restatement (corridor_frontend.hpp: rotation_onto): only correctly rounded operations, so both sides agree bit for bit
+__device__ __forceinline__ Rot rot_onto(D3 v) {
+  const double hxy = sqrt(v.x * v.x + v.y * v.y), n3 = sqrt(hxy * hxy + v.z * v.z);
+  const double cp = n3 > 0 ? hxy / n3 : 1.0, sp = n3 > 0 ? -v.z / n3 : 0.0;
+  const double cy = hxy > 0 ? v.x / hxy : 1.0, sy = hxy > 0 ? v.y / hxy : 0.0;
   Rot r;
   r.m[0][0] = cy * cp; r.m[0][1] = -sy; r.m[0][2] = cy * sp;
   r.m[1][0] = sy * cp; r.m[1][1] = cy;  r.m[1][2] = sy * sp;
   r.m[2][0] = -sp;     r.m[2][1] = 0;   r.m[2][2] = cp;
   return r;
 }
-__device__ __forceinline__ Rot rot_roll(const Rot& Ri, double roll) {  // Ri * Rx(roll)
-  const double c = cos(roll), s = sin(roll);
+__device__ __forceinline__ Rot rot_roll(const Rot& Ri, double z, double y) {  // Ri * Rx(atan2(z, y))
+  const double h = sqrt(y * y + z * z);
+  const double c = h > 0 ? y / h : 1.0, s = h > 0 ? z / h : 0.0;
   Rot r;
   for (int i = 0; i < 3; i++) {
     r.m[i][0] = Ri.m[i][0];
@@ -85,8 +93,17 @@ __device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt,
     const int l2 = first_lane(anyi >= 0);
     return l2 >= 0 ? __builtin_amdgcn_readlane(anyi, l2) : -1;
   }
-  const int L = first_lane(best == mn);
-  return __builtin_amdgcn_readlane(bi, L);
+  // exact ties (mirror-symmetric points of a regular cloud): the lowest list index wins, as in the host's sequential scan
+  int v = best == mn ? bi : 0x7fffffff;
+#define FH_DPP_MIN_I32(ctrl, rmask)                                                   \
+  {                                                                                   \
+    const int o = __builtin_amdgcn_update_dpp(0x7fffffff, v, ctrl, rmask, 0xf, false); \
+    v = o < v ? o : v;                                                                \
+  }
+  FH_DPP_MIN_I32(0x111, 0xf) FH_DPP_MIN_I32(0x112, 0xf) FH_DPP_MIN_I32(0x114, 0xf) FH_DPP_MIN_I32(0x118, 0xf)
+  FH_DPP_MIN_I32(0x142, 0xa) FH_DPP_MIN_I32(0x143, 0xc)
+#undef FH_DPP_MIN_I32
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 #define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the list lives in the HBM workspace (dense clouds); more => count = -1
@@ -140,7 +157,7 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
     if (ic < 0) break;
     const D3 pw = d3(px[ic], py[ic], pz[ic]);
     D3 l = mulT(Ri, pw - c);
-    Rf = rot_roll(Ri, atan2(l.z, l.y));
+    Rf = rot_roll(Ri, l.z, l.y);
     l = mulT(Rf, pw - c);
     if (l.x < axes.x) axes.y = fabs(l.y) / sqrt(1 - (l.x / axes.x) * (l.x / axes.x));
     cur = d3(axes.x, axes.y, axes.y);
@@ -183,7 +200,7 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
     const D3 g = mul(Rf, d3(l.x / (axes.x * axes.x), l.y / (axes.y * axes.y), l.z / (axes.z * axes.z)));
     const double gn = norm(g);
     if (!(gn > 0) || !isfinite(gn)) break;  // degenerate ellipsoid: no separating planes (as the host version)
-    const D3 n = g * (1.0 / gn);
+    const D3 n = d3(g.x / gn, g.y / gn, g.z / gn);
     emit(cp, n);
     for (int i = lane; i < cnt; i += 64)
       if ((flag[i] & 4) && !(dot(n, d3(px[i], py[i], pz[i]) - cp) < 0)) flag[i] &= (unsigned char)~4;
@@ -216,12 +233,18 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
     const D3 p1 = d3(segments[6 * seg + 0], segments[6 * seg + 1], segments[6 * seg + 2]);
     const D3 p2 = d3(segments[6 * seg + 3], segments[6 * seg + 4], segments[6 * seg + 5]);
     fh_face* out = faces + (size_t)seg * (size_t)max_faces;
+    if (p1.x != p1.x) {  // NaN: an unused slot of a fixed-stride segment table (fh_corridor_batch_device)
+      if (lane == 0) counts[seg] = 0;
+      continue;
+    }
     // local bounding box (line_segment.h:57-98), plane order kept: +h, -h, +dir, -dir, +v, -v
     const D3 dvec = p2 - p1;
-    const D3 dir = dvec * (1.0 / norm(dvec));
+    const double dn = norm(dvec);
+    const D3 dir = d3(dvec.x / dn, dvec.y / dn, dvec.z / dn);
     D3 dh = d3(dir.y, -dir.x, 0.0);
     if (norm(dh) == 0) dh = d3(-1, 0, 0);
-    dh = dh * (1.0 / norm(dh));
+    const double hn = norm(dh);
+    dh = d3(dh.x / hn, dh.y / hn, dh.z / hn);
     const D3 dv = d3(dir.y * dh.z - dir.z * dh.y, dir.z * dh.x - dir.x * dh.z, dir.x * dh.y - dir.y * dh.x);
     D3 bp[6], bn[6];
     bp[0] = p1 + dh * by; bn[0] = dh;

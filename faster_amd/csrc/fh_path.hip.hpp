@@ -475,31 +475,38 @@ __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
       // createMoreVertexes / zero-length legs / deleteVertexes are sequential and short: lane 0 walks the legs
       if (lane == 0) {
         int w = 0;
-        double prev[3] = {st[0], st[1], st[2]};
+        double last[3] = {st[0], st[1], st[2]};  // the last vertex kept
         auto put = [&](const double p[3]) {
           if (w < pa.max_points) { out[3 * w] = p[0]; out[3 * w + 1] = p[1]; out[3 * w + 2] = p[2]; }
           w++;
+          last[0] = p[0]; last[1] = p[1]; last[2] = p[2];
         };
-        put(prev);
+        // a vertex closer than 1e-9 to the last kept one is dropped (createMoreVertexes repeats the end of a leg that is an exact
+        // multiple of the spacing; the host restatement erases the later of the two)
+        auto emit = [&](const double p[3]) {
+          if (pa.max_vertex_dist > 0.0 && Planner::dist(p, last) < 1e-9) return;
+          put(p);
+        };
+        put(last);
+        double a[3] = {st[0], st[1], st[2]};  // start of the current leg: always the ORIGINAL vertex, as in createMoreVertexes
         for (int i = 1; i < count; i++) {
-          double nxt[3];
-          if (i == count - 1) { nxt[0] = gl[0]; nxt[1] = gl[1]; nxt[2] = gl[2]; }
-          else pl.center(pl.va[i], nxt);
+          double b[3];
+          if (i == count - 1) { b[0] = gl[0]; b[1] = gl[1]; b[2] = gl[2]; }
+          else pl.center(pl.va[i], b);
           if (pa.max_vertex_dist > 0.0) {
-            const double d = Planner::dist(nxt, prev);
+            const double d = Planner::dist(b, a);
             if (d > pa.max_vertex_dist) {
               const int add = (int)floor(d / pa.max_vertex_dist);
-              const double vx = (nxt[0] - prev[0]) / d, vy = (nxt[1] - prev[1]) / d, vz = (nxt[2] - prev[2]) / d;
-              for (int a = 0; a < add; a++) {
-                double p[3] = {prev[0] + vx * pa.max_vertex_dist, prev[1] + vy * pa.max_vertex_dist, prev[2] + vz * pa.max_vertex_dist};
-                put(p);
-                prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2];
+              const double vx = (b[0] - a[0]) / d, vy = (b[1] - a[1]) / d, vz = (b[2] - a[2]) / d;
+              double q[3] = {a[0], a[1], a[2]};
+              for (int k = 0; k < add; k++) {
+                q[0] = q[0] + vx * pa.max_vertex_dist; q[1] = q[1] + vy * pa.max_vertex_dist; q[2] = q[2] + vz * pa.max_vertex_dist;
+                emit(q);
               }
             }
-            if (Planner::dist(nxt, prev) < 1e-9) continue;  // the repeated end point of an exact multiple
           }
-          put(nxt);
-          prev[0] = nxt[0]; prev[1] = nxt[1]; prev[2] = nxt[2];
+          emit(b);
+          a[0] = b[0]; a[1] = b[1]; a[2] = b[2];
         }
         if (pa.max_poly > 0 && w > pa.max_poly + 1) w = pa.max_poly + 1;
         np = w > pa.max_points ? -1 : w;

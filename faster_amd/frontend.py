@@ -128,20 +128,65 @@ def forest_cloud(seed, size=(20.0, 20.0, 3.0), density=0.1, radius=0.3, spacing=
     return cloud, centres
 
 
+def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation, starts, goals, max_poly, max_vertex_dist, faces_per_problem,
+                          drone_radius, z_ground=0.0, device=0):
+    """The corridor front-end on the device: fh_map_read + fh_map_plan_batch_device (path search, createMoreVertexes,
+    deleteVertexes) + fh_corridor_batch_device (decomposition, rows in fh_problem's layout).  `ctx`: capi.Context, `vmap`: capi.Map.
+    Returns host copies (faces [n][fpp][4], face_off [n][9], n_poly [n], goal [n][3]) and the device times in seconds."""
+    import time
+
+    import torch
+
+    dev = torch.device("cuda", device)
+    n, mp = len(starts), max_poly + 1
+    d_cloud = torch.from_numpy(_c(cloud).reshape(-1, 3)).to(dev)
+    d_s, d_g = torch.from_numpy(_c(starts)).to(dev), torch.from_numpy(_c(goals)).to(dev)
+    d_paths = torch.zeros((n, mp, 3), dtype=torch.float64, device=dev)
+    d_np = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ex = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_faces = torch.zeros((n, faces_per_problem, 4), dtype=torch.float64, device=dev)
+    d_off = torch.zeros((n, 9), dtype=torch.int32, device=dev)
+    d_npoly = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_goal = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vmap.read_device(d_cloud.data_ptr(), len(d_cloud), cells, res, center, z_ground, z_max, inflation)
+    vmap.sync()
+    t1 = time.perf_counter()
+    vmap.plan_batch_device(d_s.data_ptr(), d_g.data_ptr(), n, mp, d_paths.data_ptr(), d_np.data_ptr(), d_ex.data_ptr(), max_vertex_dist, max_poly)
+    vmap.sync()
+    t2 = time.perf_counter()
+    ctx.corridor_batch_device(d_cloud.data_ptr(), len(d_cloud), d_paths.data_ptr(), d_np.data_ptr(), n, mp, max_poly, faces_per_problem,
+                              d_faces.data_ptr(), d_off.data_ptr(), d_npoly.data_ptr(), d_goal.data_ptr(), drone_radius, z_ground)
+    ctx.sync()
+    t3 = time.perf_counter()
+    timing = {"map_s": t1 - t0, "path_search_s": t2 - t1, "decomposition_s": t3 - t2, "expansions": int(d_ex.sum().item())}
+    goal = d_goal.cpu().numpy()
+    goal[np.isnan(goal)] = 0.0
+    return d_faces.cpu().numpy(), d_off.cpu().numpy(), d_npoly.cpu().numpy(), goal, timing
+
+
 def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, drone_radius=0.05,
-                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, **kw):
+                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, front="host", ctx=None, vmap=None, device=0, **kw):
     """BASELINE config 5: n start/goal pairs in one random forest; corridors from the voxel path search + ellipsoid
-    decomposition (this front-end).  Returns (problems, faces, info)."""
+    decomposition: front="host" this CPU front-end (OpenMP), front="device" the same steps through the C ABI on the GPU
+    (capi.Map + capi.Context; no CPU fallback).  Returns (problems, faces, info)."""
     from . import corridor
 
     cloud, cells, center, starts, goals, rng = forest_queries(n, seed, size, res, inflation, min_goal_dist, return_rng=True)
-    faces = np.zeros((n, faces_per_problem, 4))
-    face_off = np.zeros((n, 9), dtype=np.int32)
-    n_poly = np.zeros(n, dtype=np.int32)
-    goal_out = np.zeros((n, 3))
-    overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
-                                       inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
-                                       faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
+    if front == "device":
+        faces, face_off, n_poly, goal_out, timing = corridor_batch_device(ctx, vmap, cloud, cells, res, center, size[2], inflation, starts, goals,
+                                                                          max_poly, max_vertex_dist, faces_per_problem, drone_radius, device=device)
+        overflow = 0
+    else:
+        faces = np.zeros((n, faces_per_problem, 4))
+        face_off = np.zeros((n, 9), dtype=np.int32)
+        n_poly = np.zeros(n, dtype=np.int32)
+        goal_out = np.zeros((n, 3))
+        overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
+                                           inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
+                                           faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
+        timing = None
     ok = n_poly > 0
     counts = face_off[np.arange(n), n_poly]
     flat = np.concatenate([faces[i, :counts[i]] for i in np.nonzero(ok)[0]]) if ok.any() else np.zeros((0, 4))
@@ -163,5 +208,6 @@ def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20
     pr["x0"][:, 3:6] = u * rng.uniform(0, 1.5, size=(len(idx), 1))
     pr["xf"][:, 0:3] = goal_out[idx]
     info = {"cloud": cloud, "starts": starts[idx], "goals": goals[idx], "no_path": int((~ok).sum()), "overflow": int(overflow),
-            "faces_per_polytope": float(counts[idx].sum() / max(n_poly[idx].sum(), 1))}
+            "faces_per_polytope": float(counts[idx].sum() / max(n_poly[idx].sum(), 1)), "front": front, "front_timing": timing,
+            "kept": idx}
     return pr, fc, info

@@ -88,18 +88,25 @@ struct LinearConstraint {  // rows a.x <= b
 
 constexpr double kEps = 1e-10;  // DecompUtil's epsilon_ (decomp_basis/data_type.h:129)
 
-// rotation taking the x axis onto v with zero roll: Rz(yaw) * Ry(pitch)   (geometric_utils.h:27-35)
+// rotation taking the x axis onto v with zero roll: Rz(yaw) * Ry(pitch)   (geometric_utils.h:27-35).  The reference goes through
+// atan2 / cos / sin; here the cosines and sines are taken straight from the components (cos(atan2(y, x)) = x / hypot): the same
+// rotation, and only +, *, /, sqrt are involved — all correctly rounded on the host and on the device, so the device kernel
+// (csrc/fh_decomp.hip.hpp) reproduces this decomposition bit for bit instead of to a libm's last digit (which decides on which side
+// FASTER's inflation pushes a point that lies in the plane of the segment).
 inline M3 rotation_onto(const V3& v) {
-  const double pitch = std::atan2(-v.z, std::sqrt(v.x * v.x + v.y * v.y)), yaw = std::atan2(v.y, v.x);
-  const double cp = std::cos(pitch), sp = std::sin(pitch), cy = std::cos(yaw), sy = std::sin(yaw);
+  const double hxy = std::sqrt(v.x * v.x + v.y * v.y), n3 = std::sqrt(hxy * hxy + v.z * v.z);
+  const double cp = n3 > 0 ? hxy / n3 : 1.0, sp = n3 > 0 ? -v.z / n3 : 0.0;
+  const double cy = hxy > 0 ? v.x / hxy : 1.0, sy = hxy > 0 ? v.y / hxy : 0.0;
   M3 r{};
   r.m[0][0] = cy * cp; r.m[0][1] = -sy; r.m[0][2] = cy * sp;
   r.m[1][0] = sy * cp; r.m[1][1] = cy;  r.m[1][2] = sy * sp;
   r.m[2][0] = -sp;     r.m[2][1] = 0;   r.m[2][2] = cp;
   return r;
 }
-inline M3 roll_about_x(double roll) {
-  const double c = std::cos(roll), s = std::sin(roll);
+// Rx(atan2(z, y))
+inline M3 roll_about_x(double z, double y) {
+  const double h = std::sqrt(y * y + z * z);
+  const double c = h > 0 ? y / h : 1.0, s = h > 0 ? z / h : 0.0;
   M3 r{};
   r.m[0][0] = 1; r.m[1][1] = c; r.m[1][2] = -s; r.m[2][1] = s; r.m[2][2] = c;
   return r;
@@ -180,7 +187,7 @@ private:
     while (!inside.empty()) {  // second axis (and the roll that puts the closest point in the x-y plane)
       const V3 pw = *closest(inside);
       V3 l = Ri.transposed() * (pw - ell_.d);
-      Rf = Ri * roll_about_x(std::atan2(l.z, l.y));
+      Rf = Ri * roll_about_x(l.z, l.y);
       l = Rf.transposed() * (pw - ell_.d);
       if (l.x < axes.x) axes.y = std::fabs(l.y) / std::sqrt(1 - (l.x / axes.x) * (l.x / axes.x));
       ell_.R = Rf;

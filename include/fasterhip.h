@@ -231,6 +231,17 @@ int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_clou
 int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const double* segments, int n_segments,
                        const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* faces, int32_t* counts);
 
+/* Corridors of a batch of paths, ready for fh_problem (faster.cpp:398-399: cvxEllipsoidDecomp of the path kept by createMoreVertexes /
+ * deleteVertexes, then setPolytopes).  d_paths / d_n_points are what fh_map_plan_batch_device wrote with max_vertex_dist / max_poly
+ * set (at most max_poly legs per path).  Pair i gets one polytope per leg; its rows are stored back to back at
+ * d_faces[i * faces_per_problem ...] with d_face_off[i][0..8] exactly as fh_problem.face_off wants them (face_begin =
+ * i * faces_per_problem) and d_n_poly[i] = number of legs — 0 when the pair has no path, or a polytope exceeds FH_MAX_FACES_POLY rows,
+ * or the rows do not fit faces_per_problem.  d_goal (may be NULL): the last vertex kept, the solver's E (faster.cpp:393-394).
+ * Asynchronous on the context stream. */
+int fh_corridor_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_paths, const int32_t* d_n_points, int n,
+                             int max_points, int max_poly, const double local_bbox[3], double drone_radius, double z_ground,
+                             int faces_per_problem, fh_face* d_faces, int32_t* d_face_off, int32_t* d_n_poly, double* d_goal);
+
 /* Whole solve -> hand-off -> safe solve of every pair in ONE launch: a wavefront takes a pair through fh_solve_batch_device,
  * fh_pair_glue_device and fh_solve_batch_device back to back (the per-pair dependency of Faster::replan, faster.cpp:427 -> :475 ->
  * :521-536), so no safe solve waits for the slowest whole solve of the batch.  Arguments and results are those of the three calls

@@ -9,6 +9,7 @@ import time
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libfasterhip.so is loaded: one HIP runtime per process)
 
 from faster_amd import abi, capi, corridor
 
@@ -325,10 +326,7 @@ def _compare_plans(host, dev, refined=False):
     assert np.array_equal(hn, dn), "vertex counts differ at %s" % np.nonzero(hn != dn)[0][:8]
     assert np.array_equal(hex_, dex), "the device expanded other cells than the host (same total order => same expansions)"
     for i in np.nonzero(hn > 0)[0]:
-        if refined:   # createMoreVertexes divides by a computed norm: last-bit differences of sqrt are allowed
-            np.testing.assert_allclose(dp[i, :hn[i]], hp[i, :hn[i]], rtol=0, atol=1e-12)
-        else:         # cell centres and the requested end points: exact
-            assert np.array_equal(dp[i, :hn[i]], hp[i, :hn[i]]), i
+        assert np.array_equal(dp[i, :hn[i]], hp[i, :hn[i]]), (i, refined)   # bit for bit, createMoreVertexes' inserted vertices included
 
 
 @pytest.mark.gpu
@@ -403,3 +401,23 @@ def test_device_path_search_edge_cases(case):
     _compare_plans(frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals, max_points=24, max_vertex_dist=0.7, max_poly=0),
                    m.plan_batch(starts, goals, max_points=24, max_vertex_dist=0.7, max_poly=0), refined=True)
     m.close()
+
+
+@pytest.mark.gpu
+def test_device_corridor_front_end_equals_host(ctx):
+    """The whole front-end of config C5 on the device (map -> path search -> createMoreVertexes/deleteVertexes -> decomposition -> rows in
+    fh_problem's layout) against the CPU front-end: the same pairs kept and every polytope row BIT FOR BIT (both sides use only
+    correctly rounded operations — no libm trigonometry, no fused multiply-adds — and the same tie rules), hence identical problems
+    and identical solver results."""
+    from faster_amd import frontend
+
+    n = 3072
+    hp, hf, hi = frontend.forest_batch(n, 31)
+    vmap = capi.Map(0)
+    dp, df, di = frontend.forest_batch(n, 31, front="device", ctx=ctx, vmap=vmap)
+    vmap.close()
+    assert np.array_equal(hi["kept"], di["kept"]) and len(hp) > 0.95 * n
+    for f in abi.problem_dtype.names:
+        assert np.array_equal(hp[f], dp[f]), f
+    assert hf.shape == df.shape and np.array_equal(hf["a"], df["a"]) and np.array_equal(hf["b"], df["b"])
+    assert di["front_timing"]["expansions"] > 1000 * n
