@@ -30,8 +30,9 @@ struct fh_ctx {
   // slot 5: snapshot workspace, 6: work-sharing control block + ring sequence numbers, 7: decomposition workspace,
   // 8: task slots of the ring, 9: share records
   // 10: corridor segments, 11: per-segment polytope rows, 12: per-segment row counts (fh_corridor_batch_device)
-  void* d_buf[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // 13: launch order of a batch (order_kernel)
+  void* d_buf[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
   size_t lds_attr[6] = {0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
@@ -156,6 +157,19 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     FH_HIP(hipGetLastError());
   }
   ctx->ctl_ready = false;  // (true again once the launch below has been issued: it resets the block when it ends)
+  // big batches are started hardest corridors first (order_kernel); results do not depend on the order
+  ka.order = nullptr;
+  if (n >= 2048 && !getenv("FH_DEBUG_NO_ORDER")) {
+    if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 64))) != FH_OK) return rc;
+    int* counters = (int*)ctx->d_buf[13];
+    int* order = counters + 64;
+    FH_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 64, ctx->stream));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(fh::order_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters);
+    hipLaunchKernelGGL(fh::order_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters, order);
+    FH_HIP(hipGetLastError());
+    ka.order = order;
+  }
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, d_results, ka);
@@ -240,7 +254,7 @@ void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 13; i++)
+    for (int i = 0; i < 14; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
     if (ctx->h_report) (void)hipHostFree(ctx->h_report);
