@@ -1,0 +1,50 @@
+// jps_hip.hpp — the path-search half of JPS_Manager on the device, behind the calls the reference makes.
+//
+// Reference: JPS_Manager (/root/reference/faster/include/jps_manager.hpp:40-59, src/jps_manager.cpp): setNumCells / setFactorJPS /
+// setResolution / setInflationJPS / setZGroundAndZMax configure the map (:42-68), updateJPSMap(cloud, center) reads it (:129-139),
+// solveJPS3D(start, goal, &solved, i) searches it (:141-200).  JpsHip keeps those names and meanings over the C ABI's fh_map_*
+// (include/fasterhip.h).  The device searches one query per wavefront, so the call that pays is solveJPS3DBatch (Monte-Carlo goals,
+// many agents sharing a map); a single solveJPS3D is a batch of one (tens of milliseconds: the CPU search of
+// corridor_frontend.cpp takes ~1 ms and stays the better choice for one replan).  No CPU fallback: without a device every search
+// reports solved = false and lastError() says why.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/fasterhip.h"
+#include "corridor_frontend.hpp"
+
+class JpsHip {
+public:
+  JpsHip() = default;
+  ~JpsHip();
+  JpsHip(const JpsHip&) = delete;
+  JpsHip& operator=(const JpsHip&) = delete;
+
+  void setNumCells(int cells_x, int cells_y, int cells_z) { cells_[0] = cells_x; cells_[1] = cells_y; cells_[2] = cells_z; }
+  void setFactorJPS(double factor_jps) { factor_jps_ = factor_jps; }
+  void setResolution(double res) { res_ = res; }
+  void setInflationJPS(double inflation_jps) { inflation_jps_ = inflation_jps; }
+  void setZGroundAndZMax(double z_ground, double z_max) { z_ground_ = z_ground; z_max_ = z_max; }
+
+  // MapUtil::readMap with cell size factor_jps * res (jps_manager.cpp:135-136); returns false on a device error
+  bool updateJPSMap(const std::vector<fhfront::V3>& cloud, const fhfront::V3& center);
+  // one query (jps_manager.cpp:141-200): empty path and *solved = false when there is none
+  std::vector<fhfront::V3> solveJPS3D(const fhfront::V3& start, const fhfront::V3& goal, bool* solved);
+  // n queries over the current map in one launch; solved[i] as above.  max_vertex_dist > 0 adds Faster::createMoreVertexes
+  // (faster.cpp:80-97) and, with max_poly > 0, deleteVertexes (utils.cpp:1117-1124): the vertices cvxEllipsoidDecomp gets.
+  std::vector<std::vector<fhfront::V3>> solveJPS3DBatch(const std::vector<fhfront::V3>& starts, const std::vector<fhfront::V3>& goals,
+                                                        std::vector<char>* solved, double max_vertex_dist = 0.0, int max_poly = 0);
+
+  const std::string& lastError() const { return err_; }
+  int deviceStatus() const { return rc_; }
+
+private:
+  bool ensureMap();
+  fh_map* map_ = nullptr;
+  bool create_failed_ = false;
+  int rc_ = FH_OK;
+  std::string err_;
+  int32_t cells_[3] = {200, 200, 20};
+  double factor_jps_ = 1.0, res_ = 0.1, inflation_jps_ = 0.0, z_ground_ = 0.0, z_max_ = 3.0;
+};

@@ -409,7 +409,8 @@ def test_forest_corridors_config_c5(ctx, oracle):
 
 def test_gpu_decomposition_matches_host_frontend(ctx):
     """Next row N1 on the device: fh_decompose_batch against the host front-end (faster_amd/host/corridor_frontend.hpp) on random
-    scenes and on forest paths; polytopes compared as sets of rows (the order of two touching points is a last-bit tie)."""
+    scenes and on forest paths; rows compared bit for bit and in order (both sides: correctly rounded operations only — no libm
+    trigonometry, no fused multiply-adds — and lowest-index tie rules)."""
     from faster_amd import build as fb, frontend
 
     fb.build_frontend()
@@ -436,7 +437,7 @@ def test_gpu_decomposition_matches_host_frontend(ctx):
         for i, (A, b) in enumerate(ref):
             assert counts[i] == len(b), (scene, i, counts[i], len(b))
             got = np.column_stack([faces["a"][i, :counts[i]], faces["b"][i, :counts[i]]])
-            np.testing.assert_allclose(key(got), key(np.column_stack([A, b])), atol=1e-9)
+            assert np.array_equal(got, np.column_stack([A, b])), (scene, i)   # same rows, same order, bit for bit
             total += 1
     assert total >= 20
     # overflow reporting: too few rows allowed
@@ -499,7 +500,7 @@ def test_gpu_decomposition_edge_cases(ctx):
         for i, (A, b) in enumerate(ref):
             assert counts[i] == len(b), (i, counts[i], len(b))
             got = np.column_stack([faces["a"][i, :counts[i]], faces["b"][i, :counts[i]]])
-            np.testing.assert_allclose(key(got), key(np.column_stack([A, b])), atol=1e-9)
+            assert np.array_equal(got, np.column_stack([A, b])), (scene, i)   # same rows, same order, bit for bit
         return counts
 
     path = np.array([[0.0, 0.0, 1.0], [1.5, 0.5, 1.2], [1.5, 0.5, 2.4], [3.0, 0.0, 2.0]])  # middle leg is vertical

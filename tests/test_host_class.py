@@ -156,3 +156,55 @@ def test_device_decomposition_through_the_host_class():
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["polytopes"] == 2 and out["error"] == 0 and all(7 <= n <= 12 for n in out["rows"])
+
+
+def _jps_scene(path, n_q=96, seed=9):
+    from faster_amd import frontend
+
+    cloud, cells, center, starts, goals = frontend.forest_queries(n_q, seed)
+    with open(path, "w") as f:
+        f.write("%d %d %d 0.2 0.3 0.0 3.0 %r %r %r %d %d\n" % (cells[0], cells[1], cells[2], float(center[0]), float(center[1]), float(center[2]), len(cloud), n_q))
+        for p in cloud:
+            f.write("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
+        for s, g in zip(starts, goals):
+            f.write("%r %r %r %r %r %r\n" % tuple(float(v) for v in (*s, *g)))
+
+
+def _build_jps_test():
+    from faster_amd import build as fb
+
+    fb.build_all()
+    exe = os.path.join(ROOT, "tests", "cpp", "test_jps_hip")
+    src = exe + ".cpp"
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(fb.HOST_SO)):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fopenmp", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "faster_amd", "host"),
+                               src, os.path.join(ROOT, "faster_amd", "host", "corridor_frontend.cpp"), "-o", exe, "-L", os.path.join(ROOT, "faster_amd"),
+                               "-lsolverhip", "-lfasterhip", "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
+    return exe
+
+
+def test_jps_hip_mirrors_jps_manager_and_fails_loudly_without_gpu(tmp_path):
+    """JpsHip has JPS_Manager's path-search surface (jps_manager.hpp:40-59); without a device updateJPSMap reports failure."""
+    import torch
+
+    hdr = open(os.path.join(ROOT, "faster_amd", "host", "jps_hip.hpp")).read()
+    for name in ("setNumCells", "setFactorJPS", "setResolution", "setInflationJPS", "setZGroundAndZMax", "updateJPSMap", "solveJPS3D"):
+        assert name in hdr, name
+    exe = _build_jps_test()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    sc = tmp_path / "scene.txt"
+    _jps_scene(sc, n_q=4)
+    r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "updateJPSMap failed" in r.stdout and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_jps_hip_equals_host_search(tmp_path):
+    """The JPS_Manager-shaped C++ class over fh_map_*: every path vertex for vertex as fhfront::plan_path (tests/cpp/test_jps_hip.cpp)."""
+    exe = _build_jps_test()
+    sc = tmp_path / "scene.txt"
+    _jps_scene(sc, n_q=256)
+    r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "JPS_OK 256" in r.stdout and int(r.stdout.split()[-1]) > 240
