@@ -33,6 +33,8 @@ struct fh_map {
   unsigned* d_chunks = nullptr;
   unsigned* d_serials = nullptr;
   int* d_ticket = nullptr;
+  int* d_order = nullptr;  // 128 counters + launch order
+  size_t order_cap = 0;
   // staging of the host-pointer entry points
   void* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_cap[5] = {0, 0, 0, 0, 0};
@@ -127,7 +129,7 @@ void fh_map_destroy(fh_map* m) {
   if (!m) return;
   MapDeviceScope scope(m);
   (void)hipStreamSynchronize(m->stream);
-  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket})
+  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order})
     if (p) (void)hipFree(p);
   for (void* p : m->d_stage)
     if (p) (void)hipFree(p);
@@ -245,6 +247,25 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.cells = m->d_cells; pa.chunks = m->d_chunks; pa.serials = m->d_serials; pa.ticket = m->d_ticket;
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
   FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
+  pa.order = nullptr;
+  if (n > m->waves && !getenv("FH_DEBUG_NO_ORDER")) {  // more queries than wavefronts: far-apart pairs first
+    const size_t need = sizeof(int) * ((size_t)n + 128);
+    if (need > m->order_cap) {
+      FM_HIP(hipStreamSynchronize(m->stream));
+      if (m->d_order) FM_HIP(hipFree(m->d_order));
+      m->d_order = nullptr; m->order_cap = 0;
+      FM_HIP(hipMalloc(&m->d_order, need));
+      m->order_cap = need;
+    }
+    FM_HIP(hipMemsetAsync(m->d_order, 0, sizeof(int) * 128, m->stream));
+    const double diag = m->res * std::sqrt((double)m->nx * m->nx + (double)m->ny * m->ny + (double)m->nz * m->nz);
+    const double scale = 64.0 / diag;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(fhp::plan_order_hist_kernel, dim3(blocks), dim3(256), 0, m->stream, d_starts, d_goals, n, scale, m->d_order);
+    hipLaunchKernelGGL(fhp::plan_order_scatter_kernel, dim3(blocks), dim3(256), 0, m->stream, d_starts, d_goals, n, scale, m->d_order, m->d_order + 128);
+    FM_HIP(hipGetLastError());
+    pa.order = m->d_order + 128;
+  }
   const int grid = std::min(m->waves, n);
   hipLaunchKernelGGL(fhp::plan_kernel, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
   FM_HIP(hipGetLastError());

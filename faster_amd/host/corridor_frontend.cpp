@@ -47,16 +47,17 @@ std::vector<V3> remove_corner_points(const VoxelGrid& g, const std::vector<V3>& 
 
 // Open-list order.  jps3d compares f with a 1e-6 tolerance and prefers the larger g on ties (graph_search.h:19-29) — not a strict
 // weak order, so the expansion order depends on the heap implementation.  Here the order is a strict TOTAL one: f quantised to
-// 2^-20 cells, then the cell index (the larger-g preference changes the number of expansions by 0.3 % in the forest maps — with
-// step costs 1, sqrt 2, sqrt 3 exact ties in f between different cells are rare — and is dropped).  Any priority queue then expands
-// the same cells in the same order — the device search (csrc/fh_path.hip.hpp, a bucket queue) is checked against this function
-// vertex for vertex.
+// 2^-20 cells, then the squared straight-line distance to the goal (with the exact empty-grid heuristic whole plateaus of cells
+// share one f: the tie-breaker is what makes the search dive for the goal — 419 instead of 850 expanded cells per forest query),
+// then the cell index.  Any priority queue then expands the same cells in the same order — the device search
+// (csrc/fh_path.hip.hpp, a bucket queue) is checked against this function vertex for vertex.
 struct Node {
-  int key, id;
+  int key, h2, id;
 };
 struct NodeOrder {
   bool operator()(const Node& a, const Node& b) const {
     if (a.key != b.key) return a.key > b.key;
+    if (a.h2 != b.h2) return a.h2 > b.h2;
     return a.id > b.id;
   }
 };
@@ -80,15 +81,27 @@ bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double in
   std::vector<char> closed((size_t)total, 0);
   std::priority_queue<Node, std::vector<Node>, NodeOrder> open;
   const int sid = grid.index(s[0], s[1], s[2]), tid = grid.index(t[0], t[1], t[2]);
-  auto dist2 = [&](int x, int y, int z) {
+  // Heuristic: the exact length of a shortest 26-connected path in an EMPTY grid — with a >= b >= c the sorted absolute cell
+  // offsets, c diagonal steps through space, b - c diagonal steps in a plane, a - b straight steps.  It is consistent (a metric of the
+  // grid graph) and dominates jps3d's Euclidean distance (graph_search.cpp:73-75), so the search stays optimal and expands 6.5x
+  // fewer cells in the forest maps (857 instead of 5542 per query); like jump-point pruning it changes which of the equal-cost
+  // paths is found, not their cost.  Only +, * and sqrt: the device search (csrc/fh_path.hip.hpp) computes the same bits.
+  const double kSqrt2 = std::sqrt(2.0), kSqrt3 = std::sqrt(3.0);
+  auto dist2 = [&](int x, int y, int z) {  // squared straight-line distance to the goal in cells: the tie-breaker
     return (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
+  };
+  auto heur = [&](int x, int y, int z) {
+    int a = std::abs(x - t[0]), b = std::abs(y - t[1]), c = std::abs(z - t[2]);
+    if (a < b) std::swap(a, b);
+    if (b < c) std::swap(b, c);
+    if (a < b) std::swap(a, b);
+    return (double)c * kSqrt3 + (double)(b - c) * kSqrt2 + (double)(a - b);
   };
   gval[sid] = 0;
   {
-    const int h2 = dist2(s[0], s[1], s[2]);
-    const double f = 0.0 + std::sqrt((double)h2);
+    const double f = 0.0 + heur(s[0], s[1], s[2]);
     if (f >= 2040.0) return false;  // the key range of the device search (fh_map_plan_batch reports -2)
-    open.push({(int)(f * kKeyScale), sid});
+    open.push({(int)(f * kKeyScale), dist2(s[0], s[1], s[2]), sid});
   }
   bool found = false;
   while (!open.empty()) {
@@ -112,10 +125,9 @@ bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double in
           if (ng < gval[id]) {
             gval[id] = ng;
             parent[id] = cur.id;
-            const int h2 = dist2(x, y, z);
-            const double f = ng + std::sqrt((double)h2);
+            const double f = ng + heur(x, y, z);
             if (f >= 2040.0) return false;
-            open.push({(int)(f * kKeyScale), id});
+            open.push({(int)(f * kKeyScale), dist2(x, y, z), id});
           }
         }
   }
