@@ -9,18 +9,18 @@
 //
 // One query per 64-lane wavefront, persistent wavefronts pulling queries from a counter.  The search is A*; what a GPU needs is a
 // priority queue without a serial heap:
-//   * the open list is a MONOTONE BUCKET QUEUE: the key of an entry is its f = g + h quantised to 2^-20 cells; a consistent
-//     heuristic makes the keys of expanded cells non-decreasing and a child's key at most 2*sqrt(3) above its parent's, so a
-//     circular window of 256 buckets of 1/32 cell is all that is ever live;
-//   * a bucket is a list of 64-entry chunks in HBM (SoA, one coalesced load per chunk); a pop scans the lowest non-empty bucket
-//     with one entry per lane and reduces (key, squared distance to the goal, cell index) lexicographically on the DPP network —
-//     a strict total order, so the expansion order does not depend on the container (the host restatement uses std::priority_queue
-//     with the same order and produces the same paths);
-//   * the popped entry is replaced by the last entry of the bucket's head chunk; the 26 neighbours are relaxed one per lane and
-//     appended to their buckets in parallel (lanes grouped by bucket with ballots);
+//   * the open list is 256 unsorted sub-lists (a hash of the cell index picks the sub-list) of 64-entry chunks in HBM; every lane keeps
+//     the minima of its 4 sub-lists in registers, so the next cell to expand is a lexicographic reduction of (key = f quantised to 2^-20
+//     cells, squared distance to the goal, cell index) over the lanes on the DPP network — a strict total order, so the expansion
+//     order does not depend on the container (the host restatement uses std::priority_queue with the same order and produces the
+//     same paths);
+//   * only the sub-list that held the minimum is scanned (one coalesced load per 64 entries) to remove the entry — the last entry
+//     of the head chunk takes its place — and to find the next minimum of that sub-list;
+//   * the 26 neighbours are relaxed one per lane; their state loads are issued before the scan (they depend on the popped index
+//     only); relaxed neighbours are appended to their sub-lists by wave-uniform code;
 //   * per-cell state (g, parent, open/closed) lives in a per-wavefront array in HBM that is never cleared: entries carry the serial
 //     number of the query that wrote them.
-// All bucket bookkeeping (heads, fill counts, chunk links, free list) is wave-uniform state in LDS.
+// Chunk links and the free stack are wave-uniform state in LDS (8 KB).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,10 +29,9 @@
 
 namespace fhp {
 
-constexpr int NBK = 256;        // circular bucket window
-constexpr int BK_SHIFT = 15;    // bucket = key >> 15: 2^-5 cell per bucket
 constexpr int NCHUNK = 2048;    // chunks of 64 open-list entries per wavefront (131072 entries)
 constexpr int CHUNK_WORDS = 192;  // 64 keys, 64 tie-breakers, 64 cells
+constexpr int NSL_LOG2 = 2, NSL = 1 << NSL_LOG2;  // sub-lists per lane (256 in all)
 constexpr int MAXRAW = 4096;    // longest raw cell path (the clean-up lists live in the chunk pool, which is dead by then)
 constexpr double KEY_SCALE = 1048576.0;
 
@@ -91,8 +90,6 @@ struct Planner {
   int lane;
   int s[3], t[3];  // start / goal cells (uniform)
   // LDS
-  short* bhead;  // [NBK]   head chunk of each bucket, -1 empty
-  short* bcnt;   // [NBK]   entries in the head chunk
   short* cnext;  // [NCHUNK] next chunk of a bucket
   short* fstack; // [NCHUNK] free chunks (stack)
   int ftop;
@@ -103,9 +100,7 @@ struct Planner {
 
   __device__ Planner(const MapView& m, char* lds) : mv(m) {
     lane = lane_id();
-    bhead = (short*)lds;
-    bcnt = bhead + NBK;
-    cnext = bcnt + NBK;
+    cnext = (short*)lds;
     fstack = cnext + NCHUNK;
     raw = va = vb = nullptr;
   }
@@ -148,6 +143,7 @@ struct Planner {
     c[2] = (z + 0.5) * mv.res + mv.oz;
   }
 
+  __device__ __forceinline__ static int sub_of(int id) { return (int)(((unsigned)id * 2654435761u) >> (32 - 6 - NSL_LOG2)); }
   __device__ __forceinline__ int dist2(int x, int y, int z) const {  // tie-breaker: squared straight-line distance to the goal
     return (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
   }
@@ -227,29 +223,44 @@ struct Planner {
   }
 
   // One query.  Returns the number of cells of the cleaned path in va[] (start -> goal), 0 = no path, -2 = limit.
+  //
+  // Open list: 256 unsorted SUB-LISTS (a hash of the cell index picks the sub-list), NSL per lane: a lane keeps, in registers, the
+  // minimum (key, tie-breaker, cell) of each of its sub-lists, its head chunk and fill count.  A pop is
+  //   1. a lexicographic reduction of the minima (no memory access) -> the cell to expand; the loads of the expansion (states of
+  //      the cell and of its 26 neighbours, occupancy words) depend on that index only and are issued at once;
+  //   2. a scan of THAT sub-list (1/256 of the open list; one coalesced load per 64 entries) to remove the entry and find the
+  //      sub-list's next minimum, while the loads of step 1 are in flight;
+  //   3. the relaxed neighbours are inserted one by one by wave-uniform code (entry appended to the head chunk of its sub-list,
+  //      the owning lane's minimum updated).
+  // The expansion order is that of the strict total order (key, tie-breaker, cell) whatever the container: the same cells in the
+  // same order as the host's std::priority_queue.
   __device__ int search(const PlanArgs& pa, CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
     const unsigned st_open = serial * 2u, st_closed = serial * 2u + 1u;
-    for (int i = lane; i < NBK; i += 64) { bhead[i] = -1; bcnt[i] = 0; }
     for (int i = lane; i < NCHUNK; i += 64) fstack[i] = (short)(NCHUNK - 1 - i);  // chunk 0 on top
     ftop = NCHUNK;
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     int limit = 0;
-    int cur_abs;
+    // this lane's NSL sub-lists
+    int m_key[NSL], m_h2[NSL], m_id[NSL], m_head[NSL], m_cnt[NSL];
+#pragma unroll
+    for (int q = 0; q < NSL; q++) { m_key[q] = 0x7fffffff; m_h2[q] = 0x7fffffff; m_id[q] = 0x7fffffff; m_head[q] = -1; m_cnt[q] = 0; }
     // the start cell
     {
       const double f = 0.0 + heur(s[0], s[1], s[2]);
       if (f >= 2040.0) return -2;
-      const int key = (int)(f * KEY_SCALE);
+      const int key = (int)(f * KEY_SCALE), h2 = dist2(s[0], s[1], s[2]);
       const int c = rfl((int)fstack[--ftop]);
-      unsigned* e = chunks + (size_t)c * CHUNK_WORDS;
       if (lane == 0) {
-        e[0] = (unsigned)key; e[64] = (unsigned)dist2(s[0], s[1], s[2]); e[128] = (unsigned)sid;
+        unsigned* e = chunks + (size_t)c * CHUNK_WORDS;
+        e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)sid;
         CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = st_open;
         cells[sid] = cs;
       }
-      cur_abs = key >> BK_SHIFT;
-      const int b = cur_abs & (NBK - 1);
-      bhead[b] = (short)c; bcnt[b] = 1; cnext[c] = -1;
+      const int ssub = sub_of(sid);
+#pragma unroll
+      for (int q = 0; q < NSL; q++)
+        if (lane == (ssub & 63) && q == (ssub >> 6)) { m_key[q] = key; m_h2[q] = h2; m_id[q] = sid; m_head[q] = c; m_cnt[q] = 1; }
+      cnext[c] = -1;
     }
     int n_open = 1;
     bool found = false;
@@ -260,47 +271,22 @@ struct Planner {
     const int nxy = mv.nx * mv.ny;
 
     while (n_open > 0) {
-      // ---- lowest non-empty bucket (head and fill count of 64 buckets per look)
-      int hc, cnt;
-      for (;;) {
-        const int bl = (cur_abs + lane) & (NBK - 1);
-        const int hb = bhead[bl], cb = bcnt[bl];
-        const unsigned long long m = __ballot(hb >= 0);
-        if (m) {
-          const int l = (int)__builtin_ctzll(m);
-          cur_abs += l;
-          hc = __builtin_amdgcn_readlane(hb, l);
-          cnt = __builtin_amdgcn_readlane(cb, l);
-          break;
+      // ---- 1. the minimum of the sub-list minima: first over this lane's, then over the lanes
+      int lk = m_key[0], lh = m_h2[0], lid = m_id[0], lhead = m_head[0], lcnt = m_cnt[0], lq = 0;
+#pragma unroll
+      for (int q = 1; q < NSL; q++)
+        if (m_key[q] < lk || (m_key[q] == lk && (m_h2[q] < lh || (m_h2[q] == lh && m_id[q] < lid)))) {
+          lk = m_key[q]; lh = m_h2[q]; lid = m_id[q]; lhead = m_head[q]; lcnt = m_cnt[q]; lq = q;
         }
-        cur_abs += 64;
-      }
-      const int b = cur_abs & (NBK - 1);
-      // ---- minimum of (key, cell) over the bucket
-      int bf = 0x7fffffff, bh = 0x7fffffff, bi = 0x7fffffff, bslot = -1;
-      int hf = 0, hh = 0, hid = 0;
-      {
-        int cc = hc, ccnt = cnt;
-        bool first = true;
-        while (cc >= 0) {
-          const unsigned* e = chunks + (size_t)cc * CHUNK_WORDS;
-          int f = 0x7fffffff, h = 0x7fffffff, id = 0x7fffffff;
-          if (lane < ccnt) { f = (int)e[lane]; h = (int)e[64 + lane]; id = (int)e[128 + lane]; }
-          if (first) { hf = f; hh = h; hid = id; first = false; }
-          if (f < bf || (f == bf && (h < bh || (h == bh && id < bi)))) { bf = f; bh = h; bi = id; bslot = cc * 64 + lane; }
-          cc = rfl((int)cnext[cc]);
-          ccnt = 64;
-        }
-      }
-      const int mf = wave_min_i32(bf);
-      bool cand = bf == mf;
-      const int mh = wave_min_i32(cand ? bh : 0x7fffffff);
-      cand = cand && bh == mh;
-      const int id = wave_min_i32(cand ? bi : 0x7fffffff);
-      cand = cand && bi == id;
-      const int wl = (int)__builtin_ctzll(__ballot(cand));
-      const int wslot = __builtin_amdgcn_readlane(bslot, wl);
-      // ---- the cell and its 26 neighbours: every load depends on `id` only, so they all go out together
+      const int mf = wave_min_i32(lk);
+      bool cand = lk == mf;
+      const int mh = wave_min_i32(cand ? lh : 0x7fffffff);
+      cand = cand && lh == mh;
+      const int id = wave_min_i32(cand ? lid : 0x7fffffff);
+      cand = cand && lid == id;
+      const int ws = (int)__builtin_ctzll(__ballot(cand));  // the lane and (wq) the sub-list that hold it
+      const int hc = __builtin_amdgcn_readlane(lhead, ws), cnt = __builtin_amdgcn_readlane(lcnt, ws), wq = __builtin_amdgcn_readlane(lq, ws);
+      // the loads of the expansion depend on `id` only: issue them now
       int cx, cy, cz;
       {
         cz = id / nxy;
@@ -311,32 +297,76 @@ struct Planner {
       const int x = cx + dx, y = cy + dy, z = cz + dz;
       const bool inside = lane < 26 && !outside(x, y, z);
       const int nid = inside ? index(x, y, z) : id;
+      // Entries and cell states written by one lane in the previous iteration are read by other lanes now: the stores must have
+      // completed (loads and stores of a wavefront are not ordered with respect to each other across lanes; without this wait
+      // one query in a thousand read an entry before it had landed)
+      settle();
       const CellState cs = cells[id];
       const CellState ns = cells[nid];
       const unsigned occw = mv.bits[nid >> 5];
-      // ---- remove the popped entry: the last entry of the head chunk takes its place
-      const int last = cnt - 1;
-      if (wslot != hc * 64 + last) {
-        const int lf = __builtin_amdgcn_readlane(hf, last), lh = __builtin_amdgcn_readlane(hh, last), li = __builtin_amdgcn_readlane(hid, last);
-        if (lane == 0) {
-          unsigned* e = chunks + (size_t)(wslot >> 6) * CHUNK_WORDS + (wslot & 63);
-          e[0] = (unsigned)lf; e[64] = (unsigned)lh; e[128] = (unsigned)li;
+      // ---- 2. the sub-list: find the entry, the minimum of the others
+      int bf = 0x7fffffff, bh = 0x7fffffff, bi = 0x7fffffff;  // this lane's best among the entries that stay
+      int hf = 0, hh = 0, hid = 0;                            // the head chunk's entries
+      int tslot = -1, matches = 0;
+      {
+        int cc = hc, ccnt = cnt;
+        bool first = true;
+        while (cc >= 0) {
+          const unsigned* e = chunks + (size_t)cc * CHUNK_WORDS;
+          int f = 0x7fffffff, h = 0x7fffffff, eid = 0x7fffffff;
+          if (lane < ccnt) { f = (int)e[lane]; h = (int)e[64 + lane]; eid = (int)e[128 + lane]; }
+          if (first) { hf = f; hh = h; hid = eid; first = false; }
+          if (f == mf && h == mh && eid == id) {  // the entry (a duplicate of it stays: counted)
+            if (tslot < 0) tslot = cc * 64 + lane;
+            matches++;
+          } else if (f < bf || (f == bf && (h < bh || (h == bh && eid < bi)))) { bf = f; bh = h; bi = eid; }
+          cc = rfl((int)cnext[cc]);
+          ccnt = 64;
         }
       }
-      if (last == 0) {
-        const int nh = rfl((int)cnext[hc]);
-        bhead[b] = (short)nh;
-        bcnt[b] = (short)(nh >= 0 ? 64 : 0);
-        fstack[ftop++] = (short)hc;
-      } else bcnt[b] = (short)last;
+      const unsigned long long tm = __ballot(tslot >= 0);
+      if (!tm) return -2;  // (cannot happen: the minimum of a sub-list is one of its entries)
+      const int wslot = __builtin_amdgcn_readlane(tslot, (int)__builtin_ctzll(tm));
+      const bool copy_stays = __popcll(tm) > 1 || __ballot(matches > 1) != 0ull;
+      int nk, nh, ni;  // the sub-list's minimum once the entry is gone
+      if (copy_stays) { nk = mf; nh = mh; ni = id; }
+      else {
+        nk = wave_min_i32(bf);
+        bool c2 = bf == nk;
+        nh = wave_min_i32(c2 ? bh : 0x7fffffff);
+        c2 = c2 && bh == nh;
+        ni = wave_min_i32(c2 ? bi : 0x7fffffff);
+      }
+      // remove: the last entry of the head chunk takes the place
+      const int last = cnt - 1;
+      if (wslot != hc * 64 + last) {
+        const int lf = __builtin_amdgcn_readlane(hf, last), lh2 = __builtin_amdgcn_readlane(hh, last), li = __builtin_amdgcn_readlane(hid, last);
+        if (lane == 0) {
+          unsigned* e = chunks + (size_t)(wslot >> 6) * CHUNK_WORDS + (wslot & 63);
+          e[0] = (unsigned)lf; e[64] = (unsigned)lh2; e[128] = (unsigned)li;
+        }
+      }
+      {
+        int nhead = hc, ncnt = last;
+        if (last == 0) {
+          nhead = rfl((int)cnext[hc]);
+          ncnt = nhead >= 0 ? 64 : 0;
+          fstack[ftop++] = (short)hc;
+        }
+#pragma unroll
+        for (int q = 0; q < NSL; q++)
+          if (q == wq) {
+            if (lane == ws) { m_key[q] = nk; m_h2[q] = nh; m_id[q] = ni; m_head[q] = nhead; m_cnt[q] = ncnt; }
+          }
+      }
       n_open--;
+      // ---- the cell
       if (cs.stamp == st_closed) continue;  // a stale duplicate: the cell was expanded from a better entry
       if (lane == 0) cells[id].stamp = st_closed;
       if (id == tid) { found = true; break; }
       expansions++;
-      // ---- relax, one neighbour per lane
       bool ok = inside && (freed(x, y, z) || !((occw >> (nid & 31)) & 1u));
-      int key = 0, h2 = 0, babs = 0x7fffffff;
+      int key = 0, h2 = 0;
       if (ok) {
         const bool visited = (ns.stamp >> 1) == serial;
         const double ng = cs.g + step;
@@ -347,53 +377,48 @@ struct Planner {
           h2 = dist2(x, y, z);
           const double f = ng + heur(x, y, z);
           if (f >= 2040.0) { limit = 1; ok = false; }
-          else { key = (int)(f * KEY_SCALE); babs = key >> BK_SHIFT; }
+          else key = (int)(f * KEY_SCALE);
         }
       }
+      // ---- 3. insert the relaxed neighbours, one per iteration of a wave-uniform loop
       unsigned long long pend = __ballot(ok);
-      if (__ballot(ok && babs < cur_abs)) cur_abs = wave_min_i32(babs);  // (rounding can put a child one bucket below its parent)
-      // ---- append, lanes grouped by bucket; bucket state and the next free chunks are fetched for all groups at once
-      const int my_b = babs & (NBK - 1);
-      const int my_head = ok ? (int)bhead[my_b] : -1, my_cnt = ok ? (int)bcnt[my_b] : 0;
       const int my_free = (lane < 32 && lane < ftop) ? (int)fstack[ftop - 1 - lane] : -1;
       int used = 0;
       while (pend) {
         const int l0 = (int)__builtin_ctzll(pend);
-        const int bb = __builtin_amdgcn_readlane(babs, l0);
-        const bool mine = ok && babs == bb;
-        const unsigned long long grp = __ballot(mine);
-        pend &= ~grp;
-        const int kk = (int)__popcll(grp), rank = rank_in(grp);
-        const int bidx = bb & (NBK - 1);
-        int c0 = __builtin_amdgcn_readlane(my_head, l0), cn = __builtin_amdgcn_readlane(my_cnt, l0);
+        pend &= pend - 1ull;
+        const int ck = __builtin_amdgcn_readlane(key, l0), ch = __builtin_amdgcn_readlane(h2, l0), ci = __builtin_amdgcn_readlane(nid, l0);
+        const int csub = sub_of(ci), cl = csub & 63, cq = csub >> 6;
+        int c0 = -1, cn = 0;
+#pragma unroll
+        for (int q = 0; q < NSL; q++)
+          if (q == cq) {  // (wave-uniform: one of the NSL bodies runs)
+            c0 = __builtin_amdgcn_readlane(m_head[q], cl);
+            cn = __builtin_amdgcn_readlane(m_cnt[q], cl);
+          }
         if (c0 < 0 || cn == 64) {
           const int nc = used < 32 ? __builtin_amdgcn_readlane(my_free, used) : -1;
           used++;
           if (nc < 0) { limit = 1; break; }
           cnext[nc] = (short)c0;
           c0 = nc; cn = 0;
-          bhead[bidx] = (short)c0;
         }
-        const int space = 64 - cn;
-        if (mine && rank < space) {
-          unsigned* e = chunks + (size_t)c0 * CHUNK_WORDS + cn + rank;
-          e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+        if (lane == cl) {
+          unsigned* e = chunks + (size_t)c0 * CHUNK_WORDS + cn;
+          e[0] = (unsigned)ck; e[64] = (unsigned)ch; e[128] = (unsigned)ci;
         }
-        if (kk > space) {
-          const int nc = used < 32 ? __builtin_amdgcn_readlane(my_free, used) : -1;
-          used++;
-          if (nc < 0) { limit = 1; break; }
-          cnext[nc] = (short)c0;
-          bhead[bidx] = (short)nc;
-          if (mine && rank >= space) {
-            unsigned* e = chunks + (size_t)nc * CHUNK_WORDS + (rank - space);
-            e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+#pragma unroll
+        for (int q = 0; q < NSL; q++)
+          if (q == cq) {
+            const bool less = ck < m_key[q] || (ck == m_key[q] && (ch < m_h2[q] || (ch == m_h2[q] && ci < m_id[q])));
+            if (lane == cl) {
+              if (less) { m_key[q] = ck; m_h2[q] = ch; m_id[q] = ci; }
+              m_head[q] = c0; m_cnt[q] = cn + 1;
+            }
           }
-          bcnt[bidx] = (short)(kk - space);
-        } else bcnt[bidx] = (short)(cn + kk);
-        n_open += kk;
+        n_open++;
       }
-      ftop -= used;
+      ftop -= used < 32 ? used : 32;
       if (__ballot(limit != 0)) return -2;
     }
     if (!found) return 0;
@@ -453,7 +478,7 @@ struct Planner {
   }
 };
 
-constexpr int PLAN_LDS_BYTES = NBK * 2 * 2 + NCHUNK * 2 * 2;
+constexpr int PLAN_LDS_BYTES = NCHUNK * 2 * 2;
 
 // One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
 // (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
