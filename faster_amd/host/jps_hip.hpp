@@ -4,8 +4,8 @@
 // setResolution / setInflationJPS / setZGroundAndZMax configure the map (:42-68), updateJPSMap(cloud, center) reads it (:129-139),
 // solveJPS3D(start, goal, &solved, i) searches it (:141-200).  JpsHip keeps those names and meanings over the C ABI's fh_map_*
 // (include/fasterhip.h).  The device searches one query per wavefront, so the call that pays is solveJPS3DBatch (Monte-Carlo goals,
-// many agents sharing a map); a single solveJPS3D is a batch of one (tens of milliseconds: the CPU search of
-// corridor_frontend.cpp takes ~1 ms and stays the better choice for one replan).  No CPU fallback: without a device every search
+// many agents sharing a map); a single solveJPS3D is a batch of one (~0.5 ms on its one wavefront: the CPU search of
+// corridor_frontend.cpp takes ~0.1 ms and stays the better choice for one replan).  No CPU fallback: without a device every search
 // reports solved = false and lastError() says why.
 #pragma once
 #include <string>
