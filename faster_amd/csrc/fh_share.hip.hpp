@@ -44,7 +44,7 @@ namespace fh {
 struct ShareCtl {
   // ---- line 0: polled by hungry workers; zeroed before every launch ----
   unsigned int done;         // units (problems, or pairs) whose final result has been written
-  unsigned int pad00;
+  unsigned int done_iters;   // active-set iterations of those units (the running mean decides who may publish ahead: giant_factor)
   unsigned int error;        // != 0: protocol failure / watchdog, everybody leaves        } one aligned 8-byte pair: the busy
   unsigned int interrupted;  // a worker has seen the host's abort word / the deadline    } workers read both with one load
   unsigned int pad0[12];
@@ -137,6 +137,7 @@ struct ShareArgs {
                               // for the fresh problems to run out before it gets help — every workgroup looks for a pending frame
                               // before it draws its next problem (the hard problems started early otherwise finish last, alone)
   int giant_nodes;            // ... but only a problem that has already needed this many nodes publishes ahead of the takers
+  int giant_factor;           // ... or this many times the mean number of active-set iterations of the units finished so far (0: off)
 };
 
 #define FH_AGENT __HIP_MEMORY_SCOPE_AGENT

@@ -300,7 +300,7 @@ struct Solver {
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
-         TB_T0 = 14, TB_WORDS = 16 };
+         TB_T0 = 14, TB_WORK = 16, TB_WORDS = 18 };  // TB_WORK: active-set iterations of the unit in hand (reported with `done`)
   signed char* stk_order;                             // [NSEG][FH_MAX_POLY] child order per tree level
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
@@ -1286,7 +1286,7 @@ struct Solver {
   // Every FH_LOOK_EVERY-th node of a tree the worker looks around: has the host (StopExecution, another thread) or the deadline
   // asked to stop (a12, solverGurobi.cpp:15-39: the reference polls its flag in a Gurobi callback)?  Is somebody out of work?
   // returns bit 0: stop, bit 1: a frame may be published, bit 2: a workgroup without work is waiting right now, bits 8..13: how many
-  __device__ int look_around(const ShareArgs& sa, int local_nodes) {
+  __device__ int look_around(const ShareArgs& sa, int local_nodes, int iters_so_far = 0) {
     FH_SP_T0();
     int flags = 0;
     if (lane == 0) {
@@ -1303,8 +1303,15 @@ struct Solver {
         if (stop) ast(&sa.ctl->interrupted, stop);
       }
       if (stop) flags = 1;
-      else if (sa.enabled && tail < waiters + (unsigned int)sa.backlog)
+      else if (sa.enabled && tail < waiters + (unsigned int)sa.backlog) {
         flags = 2 | ((int)(waiters - tail) > 0 ? 4 : 0) | (min((int)(waiters - tail), 63) << 8);  // a taker is waiting (4: idle right now; count), or the backlog has room
+        if (!(flags & 4) && sa.giant_factor > 0 && iters_so_far > 0) {
+          // nobody idle, room in the backlog: has this problem used giant_factor times the mean of the units finished so far?
+          const unsigned long long dw = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->done));
+          const unsigned long long done = dw & 0xffffffffull, sum = dw >> 32;
+          if (done >= 256ull && (unsigned long long)iters_so_far * done >= (unsigned long long)sa.giant_factor * sum) flags |= 8;
+        }
+      }
     }
     FH_SP_ADD(prof, 0, 1);
     return uniform_i32(flags);
@@ -1530,7 +1537,7 @@ struct Solver {
     if (uniform_u64(cc_load(&hp->w[TH_KIND])) != 0ull) {  // the remaining trials of a problem: header only
       const unsigned long long w_ts = cc_load(&hp->w[TH_TRIALS_SEG]);
       if (lane == 0) {
-        tb[TB_REC] = (int)(unsigned)w_rec_b; tb[TB_B] = (int)(w_rec_b >> 32);
+        tb[TB_REC] = (int)(unsigned)w_rec_b; tb[TB_B] = (int)(w_rec_b >> 32); tb[TB_WORK] = 0; tb[TB_WORK] = 0;
         tb[TB_PHASE] = (int)(unsigned)w_phase_depth;
         tb[TB_TRIALS] = (int)(unsigned)w_ts;
         tb[TB_DEPTH0] = (int)(w_ts >> 32);  // (trial frames: the end of the range)
@@ -1552,7 +1559,7 @@ struct Solver {
     if (lane == 0) {
       stk_seg[0] = (int)(w_trials_seg >> 32); stk_cnt[0] = (int)(unsigned)w_cnt_next; stk_next[0] = (int)(w_cnt_next >> 32);
       stk_q[0] = (int)(unsigned)w_q_qe;
-      tb[TB_REC] = (int)(unsigned)w_rec_b; tb[TB_B] = (int)(w_rec_b >> 32);
+      tb[TB_REC] = (int)(unsigned)w_rec_b; tb[TB_B] = (int)(w_rec_b >> 32); tb[TB_WORK] = 0;
       tb[TB_PHASE] = (int)(unsigned)w_phase_depth; tb[TB_DEPTH0] = (int)(w_phase_depth >> 32);
       tb[TB_TRIALS] = (int)(unsigned)w_trials_seg;
       tb[TB_QE] = (int)(w_q_qe >> 32);
@@ -1759,13 +1766,13 @@ struct Solver {
       // a problem that is already shared looks around twice as often; a taker looks before its first node (it hands the other
       // children of its frame, or the following trials, on at once if more takers are waiting)
       if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (rec >= 0 && local_nodes == 1 && (entry == 1 || trial + 1 < trial_end))) {
-        int fl = look_around(sa, local_nodes);
+        int fl = look_around(sa, local_nodes, iters);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }
         // somebody is out of work: a problem that has proved hard (it already has a share record, or sa.min_nodes nodes so far)
         // gives its shallowest open frame away, and — once it is shared — the factor trials after this one, or a second frame.
         // (sa.enabled is 0 with a work cap or a MIP gap.)
         // (idle takers: nothing to lose by sharing early; no idle taker but room in the backlog: only the giants publish ahead)
-        if ((fl & 2) && ((fl & 4) ? (rec >= 0 || nodes + local_nodes >= 2) : (nodes + local_nodes >= sa.giant_nodes))) {
+        if ((fl & 2) && ((fl & 4) ? (rec >= 0 || nodes + local_nodes >= 2) : (nodes + local_nodes >= sa.giant_nodes || (fl & 8)))) {
           if (depth > 0) donate(sa, ws, depth, best_cost);
           // ... and the factor trials after this one (a narrow tree may never have an open frame to give, but its trials are
           // independent), or, when it has none left to give, a second frame
@@ -2079,6 +2086,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     res.status = status;
     res.nodes = nodes;
     res.qp_iters = iters;
+    sv.tb[sv.TB_WORK] += iters;
     res.kflops = kf > 0x7fffffffull ? 0x7fffffff : (int32_t)kf;
     res.factor = solved ? factor : 0.0;
     res.dt = dt;
@@ -2163,7 +2171,7 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
         continue;
       } else {
         unit = ka.order ? ka.order[b] : (int)b;
-        if (threadIdx.x == 0) { sv.tb[sv.TB_B] = unit; sv.tb[sv.TB_PHASE] = 0; }
+        if (threadIdx.x == 0) { sv.tb[sv.TB_B] = unit; sv.tb[sv.TB_PHASE] = 0; sv.tb[sv.TB_WORK] = 0; }
       }
     }
     // (wave-uniform by construction; said explicitly because the divergence analysis loses it across this loop nest and would keep
@@ -2212,7 +2220,10 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
           continue;
         }
       }
-      if (threadIdx.x == 0) aadd(&sa.ctl->done, 1u);
+      if (threadIdx.x == 0) {  // one more unit done, and what it cost (both words of one 8-byte add)
+        const unsigned long long it = (unsigned long long)(unsigned)sv.tb[sv.TB_WORK];
+        aadd(reinterpret_cast<unsigned long long*>(&sa.ctl->done), 1ull | (min(it, 0xfffffull) << 32));
+      }
       break;
     }
   }
