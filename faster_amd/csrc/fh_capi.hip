@@ -168,10 +168,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // big batches are started hardest corridors first (order_kernel); results do not depend on the order
   ka.order = nullptr;
   if (n >= 2048 && !getenv("FH_DEBUG_NO_ORDER")) {
+    const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 64);
     if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 64))) != FH_OK) return rc;
     int* counters = (int*)ctx->d_buf[13];
     int* order = counters + 64;
-    FH_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 64, ctx->stream));
+    if (fresh) FH_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 64, ctx->stream));  // afterwards the scatter kernel leaves them zeroed
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(fh::order_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters);
     hipLaunchKernelGGL(fh::order_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters, order);

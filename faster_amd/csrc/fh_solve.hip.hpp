@@ -2268,6 +2268,7 @@ __global__ void __launch_bounds__(256) order_hist_kernel(const fh_problem* __res
 __global__ void __launch_bounds__(256) order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters,
                                                             int* __restrict__ order) {
   __shared__ int cnt[FH_MAX_POLY + 1], base[FH_MAX_POLY + 1];
+  __shared__ int last_block;
   if (threadIdx.x <= FH_MAX_POLY) cnt[threadIdx.x] = 0;
   __syncthreads();
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
@@ -2284,6 +2285,12 @@ __global__ void __launch_bounds__(256) order_scatter_kernel(const fh_problem* __
   }
   __syncthreads();
   if (i < n) order[base[k] + mine] = i;
+  // the last block to finish leaves the counters zeroed for the next launch (no memset in the stream: on a chip whose registers are
+  // all held by persistent workgroups every extra stream operation waits milliseconds for a slot)
+  __syncthreads();
+  if (threadIdx.x == 0) last_block = atomicAdd(&counters[2 * (FH_MAX_POLY + 1)], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last_block && threadIdx.x <= 2 * (FH_MAX_POLY + 1)) counters[threadIdx.x] = 0;
 }
 
 // FP64 vector peak of the device as this code can reach it: independent v_fma_f64 chains, 8 per lane, no memory traffic

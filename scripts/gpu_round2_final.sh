@@ -23,6 +23,8 @@ run literal_if8 --r-margin -1
 run literal_split12 --r-margin -1 --pipeline split --inflight 12
 run literal_if1 --r-margin -1 --inflight 1
 run c5_65536 --workload c5 --pairs 65536 --steps 8 --warmup 2
+run c5_host_front --workload c5 --front host --pairs 65536 --steps 8 --warmup 2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke
 echo "== profiles"; bash scripts/profile_round.sh r02 2>&1 | tail -8
 echo "== parity sweep"; timeout 400 python tests/tools/parity_sweep.py 150000 240 2>&1 | tail -3 | tee $O/r02_parity_sweep.txt
 cp $O/r02_parity_sweep.txt $R/gpurun_out/profiles_r02/ 2>/dev/null
