@@ -81,17 +81,19 @@ def test_empty_cloud_gives_the_local_box():
     assert np.all(A @ np.array([4.9, 1.9, 1.9]) <= b + 1e-12) and np.any(A @ np.array([5.1, 0, 1.0]) > b)
 
 
-def test_path_search_properties():
-    """Voxel path search: endpoints forced onto start/goal (jps_manager.cpp:175-186), every leg passes jps3d's ray test, and the
+@pytest.mark.parametrize("seed,start,goal", [(7, (0.8, 0.9, 1.0), (9.1, 9.2, 1.1)), (8, (9.0, 0.8, 0.4), (1.0, 9.3, 1.7)),
+                                             (9, (5.0, 0.7, 1.6), (5.2, 9.4, 0.3))])
+def test_path_search_properties(seed, start, goal):
+    """Voxel path search (exact empty-grid heuristic, total order on the open list): endpoints forced onto start/goal (jps_manager.cpp:175-186), every leg passes jps3d's ray test, and the
     cleaned path is no longer than an independently computed optimal 26-connected grid path (scipy Dijkstra)."""
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import dijkstra
 
-    cloud, centres = frontend.forest_cloud(7, size=(10.0, 10.0, 2.0), density=0.15)
+    cloud, centres = frontend.forest_cloud(seed, size=(10.0, 10.0, 2.0), density=0.15)
     res, infl = 0.25, 0.25
     cells = (44, 44, 8)
     center = np.array([5.0, 5.0, 1.0])
-    start, goal = np.array([0.8, 0.9, 1.0]), np.array([9.1, 9.2, 1.1])
+    start, goal = np.array(start), np.array(goal)
     path = frontend.plan(cloud, cells, res, center, 0.0, 2.0, infl, start, goal)
     assert path is not None and len(path) >= 2
     np.testing.assert_allclose(path[0], start)
@@ -117,12 +119,29 @@ def test_path_search_properties():
         occ[max(c[0] - m, 0):c[0] + m + 1, max(c[1] - m, 0):c[1] + m + 1, max(c[2] - m, 0):c[2] + m + 1] = False
     for v in path:
         assert not occ[tuple(cell(v))], "path vertex in an occupied cell"
-    for a, b in zip(path[1:-2], path[2:-1]):   # interior legs (the two end legs are re-anchored on start/goal afterwards)
+    def ray_clear(a, b):
         steps = int(np.max(np.abs(b - a)) / res / 0.8)  # jps3d's ray test samples every 0.8 cell (map_util.h:348-382)
         for k in range(1, steps):
             c = cell(a + (b - a) * (k / steps))
-            if np.all(c >= 0) and np.all(c < [nx, ny, nz]):
-                assert not occ[tuple(c)], "path leg fails jps3d's ray test"
+            if not (np.all(c >= 0) and np.all(c < [nx, ny, nz])):
+                break
+            if occ[tuple(c)]:
+                return False
+        return True
+
+    # interior legs (the two end legs are re-anchored on start/goal afterwards).  removeCornerPts runs forwards and then on the
+    # reversed path (jps_planner.cpp:286-291) and the samples of a ray depend on the end it starts from: a leg was accepted in one
+    # of the two directions
+    def grid_run(a, b):   # a straight run of the raw cell path (removeLinePts keeps its ends): unit steps through free cells
+        ca, cb = cell(a), cell(b)
+        d = cb - ca
+        n = int(np.max(np.abs(d)))
+        if n == 0 or np.any((np.abs(d) != 0) & (np.abs(d) != n)):
+            return False
+        return all(not occ[tuple(ca + (d // n) * k)] for k in range(n + 1))
+
+    for a, b in zip(path[1:-2], path[2:-1]):
+        assert ray_clear(a, b) or ray_clear(b, a) or grid_run(a, b), "path leg is neither a run of free cells nor an accepted shortcut"
     # optimal grid distance
     free = ~occ
     ids = -np.ones(occ.shape, int)
