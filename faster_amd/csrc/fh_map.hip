@@ -75,11 +75,11 @@ int stage(fh_map* m, int slot, size_t bytes) {
   return FH_OK;
 }
 
-// per-wavefront search state: sized by the grid; at most 16 wavefronts per CU (4 per SIMD) and 48 GB
+// per-wavefront search state: sized by the grid; at most 12 wavefronts per CU (3 per SIMD) and 48 GB
 int ensure_workspace(fh_map* m) {
   const size_t total = (size_t)m->nx * m->ny * m->nz;
   const size_t per_wave = total * sizeof(fhp::CellState) + (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS * 4;
-  int waves = m->n_cu * 16;
+  int waves = m->n_cu * 12;  // LDS: 12.5 KB per wavefront
   if (const char* e = getenv("FH_DEBUG_PLAN_WAVES_PER_CU")) waves = m->n_cu * std::max(1, atoi(e));
   const size_t budget = (size_t)48 << 30;
   if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);

@@ -9,8 +9,8 @@
 //
 // One query per 64-lane wavefront, persistent wavefronts pulling queries from a counter.  The search is A*; what a GPU needs is a
 // priority queue without a serial heap:
-//   * the open list is 256 unsorted sub-lists (a hash of the cell index picks the sub-list) of 64-entry chunks in HBM; every lane keeps
-//     the minima of its 4 sub-lists in registers, so the next cell to expand is a lexicographic reduction of (key = f quantised to 2^-20
+//   * the open list is 256 unsorted sub-lists (a hash of the cell index picks the sub-list) of 64-entry chunks in HBM; the minimum
+//     of every sub-list, its head chunk and fill count are a 16-byte record in LDS, so the next cell to expand is a lexicographic reduction of (key = f quantised to 2^-20
 //     cells, squared distance to the goal, cell index) over the lanes on the DPP network — a strict total order, so the expansion
 //     order does not depend on the container (the host restatement uses std::priority_queue with the same order and produces the
 //     same paths);
@@ -20,7 +20,7 @@
 //     only); relaxed neighbours are appended to their sub-lists by wave-uniform code;
 //   * per-cell state (g, parent, open/closed) lives in a per-wavefront array in HBM that is never cleared: entries carry the serial
 //     number of the query that wrote them.
-// Chunk links and the free stack are wave-uniform state in LDS (8 KB).
+// Chunk links, the free stack and the sub-list records are in LDS (12.5 KB).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +31,7 @@ namespace fhp {
 
 constexpr int NCHUNK = 2048;    // chunks of 64 open-list entries per wavefront (131072 entries)
 constexpr int CHUNK_WORDS = 192;  // 64 keys, 64 tie-breakers, 64 cells
-constexpr int NSL_LOG2 = 2, NSL = 1 << NSL_LOG2;  // sub-lists per lane (256 in all)
+constexpr int NS_LOG2 = 8, NS = 1 << NS_LOG2;  // sub-lists of the open list
 constexpr int MAXRAW = 4096;    // longest raw cell path (the clean-up lists live in the chunk pool, which is dead by then)
 constexpr double KEY_SCALE = 1048576.0;
 
@@ -92,6 +92,11 @@ struct Planner {
   // LDS
   short* cnext;  // [NCHUNK] next chunk of a bucket
   short* fstack; // [NCHUNK] free chunks (stack)
+  int* r_key;    // [NS] per sub-list: the minimum (key, tie-breaker, cell) ...
+  int* r_h2;
+  int* r_id;
+  int* r_hc;     // [NS] ... head chunk << 8 | entries in the head chunk (1..64); 0: empty
+  short* claim;  // [NS] which lane inserts into a sub-list in this round
   int ftop;
   // HBM (the wavefront's chunk pool, once the search is over)
   int* raw;      // [MAXRAW]
@@ -102,6 +107,11 @@ struct Planner {
     lane = lane_id();
     cnext = (short*)lds;
     fstack = cnext + NCHUNK;
+    r_key = (int*)(fstack + NCHUNK);
+    r_h2 = r_key + NS;
+    r_id = r_h2 + NS;
+    r_hc = r_id + NS;
+    claim = (short*)(r_hc + NS);
     raw = va = vb = nullptr;
   }
   // stores of some lanes are read back by others: the clean-up lists are tiny, so simply wait for the stores
@@ -143,7 +153,7 @@ struct Planner {
     c[2] = (z + 0.5) * mv.res + mv.oz;
   }
 
-  __device__ __forceinline__ static int sub_of(int id) { return (int)(((unsigned)id * 2654435761u) >> (32 - 6 - NSL_LOG2)); }
+  __device__ __forceinline__ static int sub_of(int id) { return (int)(((unsigned)id * 2654435761u) >> (32 - NS_LOG2)); }
   __device__ __forceinline__ int dist2(int x, int y, int z) const {  // tie-breaker: squared straight-line distance to the goal
     return (x - t[0]) * (x - t[0]) + (y - t[1]) * (y - t[1]) + (z - t[2]) * (z - t[2]);
   }
@@ -224,14 +234,14 @@ struct Planner {
 
   // One query.  Returns the number of cells of the cleaned path in va[] (start -> goal), 0 = no path, -2 = limit.
   //
-  // Open list: 256 unsorted SUB-LISTS (a hash of the cell index picks the sub-list), NSL per lane: a lane keeps, in registers, the
-  // minimum (key, tie-breaker, cell) of each of its sub-lists, its head chunk and fill count.  A pop is
-  //   1. a lexicographic reduction of the minima (no memory access) -> the cell to expand; the loads of the expansion (states of
+  // Open list: 256 unsorted SUB-LISTS (a hash of the cell index picks the sub-list); LDS holds the minimum (key, tie-breaker,
+  // cell) of each, its head chunk and fill count.  A pop is
+  //   1. a lexicographic reduction of the minima (4 per lane from LDS, then the DPP network; no HBM access) -> the cell to expand; the loads of the expansion (states of
   //      the cell and of its 26 neighbours, occupancy words) depend on that index only and are issued at once;
   //   2. a scan of THAT sub-list (1/256 of the open list; one coalesced load per 64 entries) to remove the entry and find the
   //      sub-list's next minimum, while the loads of step 1 are in flight;
-  //   3. the relaxed neighbours are inserted one by one by wave-uniform code (entry appended to the head chunk of its sub-list,
-  //      the owning lane's minimum updated).
+  //   3. the relaxed neighbours are inserted by all lanes at once (entry appended to the head chunk of its sub-list, the record
+  //      updated; two neighbours that hash to one sub-list take turns).
   // The expansion order is that of the strict total order (key, tie-breaker, cell) whatever the container: the same cells in the
   // same order as the host's std::priority_queue.
   __device__ int search(const PlanArgs& pa, CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
@@ -240,10 +250,8 @@ struct Planner {
     ftop = NCHUNK;
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     int limit = 0;
-    // this lane's NSL sub-lists
-    int m_key[NSL], m_h2[NSL], m_id[NSL], m_head[NSL], m_cnt[NSL];
-#pragma unroll
-    for (int q = 0; q < NSL; q++) { m_key[q] = 0x7fffffff; m_h2[q] = 0x7fffffff; m_id[q] = 0x7fffffff; m_head[q] = -1; m_cnt[q] = 0; }
+    // the sub-list records: all empty
+    for (int i = lane; i < NS; i += 64) { r_key[i] = 0x7fffffff; r_h2[i] = 0x7fffffff; r_id[i] = 0x7fffffff; r_hc[i] = 0; }
     // the start cell
     {
       const double f = 0.0 + heur(s[0], s[1], s[2]);
@@ -257,9 +265,7 @@ struct Planner {
         cells[sid] = cs;
       }
       const int ssub = sub_of(sid);
-#pragma unroll
-      for (int q = 0; q < NSL; q++)
-        if (lane == (ssub & 63) && q == (ssub >> 6)) { m_key[q] = key; m_h2[q] = h2; m_id[q] = sid; m_head[q] = c; m_cnt[q] = 1; }
+      r_key[ssub] = key; r_h2[ssub] = h2; r_id[ssub] = sid; r_hc[ssub] = (c << 8) | 1;
       cnext[c] = -1;
     }
     int n_open = 1;
@@ -271,21 +277,23 @@ struct Planner {
     const int nxy = mv.nx * mv.ny;
 
     while (n_open > 0) {
-      // ---- 1. the minimum of the sub-list minima: first over this lane's, then over the lanes
-      int lk = m_key[0], lh = m_h2[0], lid = m_id[0], lhead = m_head[0], lcnt = m_cnt[0], lq = 0;
+      // ---- 1. the minimum of the sub-list minima: first over this lane's NS / 64 records, then over the lanes
+      int lk = r_key[lane], lh = r_h2[lane], lid = r_id[lane], ls = lane;
 #pragma unroll
-      for (int q = 1; q < NSL; q++)
-        if (m_key[q] < lk || (m_key[q] == lk && (m_h2[q] < lh || (m_h2[q] == lh && m_id[q] < lid)))) {
-          lk = m_key[q]; lh = m_h2[q]; lid = m_id[q]; lhead = m_head[q]; lcnt = m_cnt[q]; lq = q;
-        }
+      for (int q = 1; q < NS / 64; q++) {
+        const int sq = lane + 64 * q;
+        const int qk = r_key[sq], qh = r_h2[sq], qi = r_id[sq];
+        if (qk < lk || (qk == lk && (qh < lh || (qh == lh && qi < lid)))) { lk = qk; lh = qh; lid = qi; ls = sq; }
+      }
       const int mf = wave_min_i32(lk);
       bool cand = lk == mf;
       const int mh = wave_min_i32(cand ? lh : 0x7fffffff);
       cand = cand && lh == mh;
       const int id = wave_min_i32(cand ? lid : 0x7fffffff);
       cand = cand && lid == id;
-      const int ws = (int)__builtin_ctzll(__ballot(cand));  // the lane and (wq) the sub-list that hold it
-      const int hc = __builtin_amdgcn_readlane(lhead, ws), cnt = __builtin_amdgcn_readlane(lcnt, ws), wq = __builtin_amdgcn_readlane(lq, ws);
+      const int wsub = __builtin_amdgcn_readlane(ls, (int)__builtin_ctzll(__ballot(cand)));  // the sub-list that holds it
+      const int whc = rfl(r_hc[wsub]);
+      const int hc = whc >> 8, cnt = whc & 255;
       // the loads of the expansion depend on `id` only: issue them now
       int cx, cy, cz;
       {
@@ -347,17 +355,13 @@ struct Planner {
         }
       }
       {
-        int nhead = hc, ncnt = last;
+        int nhc = (hc << 8) | last;
         if (last == 0) {
-          nhead = rfl((int)cnext[hc]);
-          ncnt = nhead >= 0 ? 64 : 0;
+          const int nhead = rfl((int)cnext[hc]);
+          nhc = nhead >= 0 ? ((nhead << 8) | 64) : 0;
           fstack[ftop++] = (short)hc;
         }
-#pragma unroll
-        for (int q = 0; q < NSL; q++)
-          if (q == wq) {
-            if (lane == ws) { m_key[q] = nk; m_h2[q] = nh; m_id[q] = ni; m_head[q] = nhead; m_cnt[q] = ncnt; }
-          }
+        r_key[wsub] = nk; r_h2[wsub] = nh; r_id[wsub] = ni; r_hc[wsub] = nhc;
       }
       n_open--;
       // ---- the cell
@@ -380,45 +384,36 @@ struct Planner {
           else key = (int)(f * KEY_SCALE);
         }
       }
-      // ---- 3. insert the relaxed neighbours, one per iteration of a wave-uniform loop
-      unsigned long long pend = __ballot(ok);
-      const int my_free = (lane < 32 && lane < ftop) ? (int)fstack[ftop - 1 - lane] : -1;
-      int used = 0;
-      while (pend) {
-        const int l0 = (int)__builtin_ctzll(pend);
-        pend &= pend - 1ull;
-        const int ck = __builtin_amdgcn_readlane(key, l0), ch = __builtin_amdgcn_readlane(h2, l0), ci = __builtin_amdgcn_readlane(nid, l0);
-        const int csub = sub_of(ci), cl = csub & 63, cq = csub >> 6;
-        int c0 = -1, cn = 0;
-#pragma unroll
-        for (int q = 0; q < NSL; q++)
-          if (q == cq) {  // (wave-uniform: one of the NSL bodies runs)
-            c0 = __builtin_amdgcn_readlane(m_head[q], cl);
-            cn = __builtin_amdgcn_readlane(m_cnt[q], cl);
-          }
-        if (c0 < 0 || cn == 64) {
-          const int nc = used < 32 ? __builtin_amdgcn_readlane(my_free, used) : -1;
-          used++;
-          if (nc < 0) { limit = 1; break; }
+      // ---- 3. insert the relaxed neighbours, all lanes at once: a lane claims its sub-list (two neighbours of one expansion rarely
+      //         share one: the loser goes in the next round), appends its entry to the head chunk and updates the record
+      const int csub = sub_of(nid);
+      bool pending = ok;
+      while (__ballot(pending)) {
+        if (pending) claim[csub] = (short)lane;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the read below must come from LDS: another lane may have overwritten the claim)
+        const bool win = pending && claim[csub] == (short)lane;
+        const int rhc = win ? r_hc[csub] : 0;
+        int c0 = rhc ? (rhc >> 8) : -1, cn = rhc & 255;
+        const bool need = win && (c0 < 0 || cn == 64);
+        const unsigned long long nm = __ballot(need);
+        const int total_new = (int)__popcll(nm);
+        if (total_new > ftop) { limit = 1; break; }
+        if (need) {
+          const int nc = (int)fstack[ftop - 1 - rank_in(nm)];
           cnext[nc] = (short)c0;
           c0 = nc; cn = 0;
         }
-        if (lane == cl) {
+        ftop -= total_new;
+        if (win) {
           unsigned* e = chunks + (size_t)c0 * CHUNK_WORDS + cn;
-          e[0] = (unsigned)ck; e[64] = (unsigned)ch; e[128] = (unsigned)ci;
+          e[0] = (unsigned)key; e[64] = (unsigned)h2; e[128] = (unsigned)nid;
+          const int rk = r_key[csub], rh = r_h2[csub], ri = r_id[csub];
+          if (key < rk || (key == rk && (h2 < rh || (h2 == rh && nid < ri)))) { r_key[csub] = key; r_h2[csub] = h2; r_id[csub] = nid; }
+          r_hc[csub] = (c0 << 8) | (cn + 1);
         }
-#pragma unroll
-        for (int q = 0; q < NSL; q++)
-          if (q == cq) {
-            const bool less = ck < m_key[q] || (ck == m_key[q] && (ch < m_h2[q] || (ch == m_h2[q] && ci < m_id[q])));
-            if (lane == cl) {
-              if (less) { m_key[q] = ck; m_h2[q] = ch; m_id[q] = ci; }
-              m_head[q] = c0; m_cnt[q] = cn + 1;
-            }
-          }
-        n_open++;
+        n_open += (int)__popcll(__ballot(win));
+        pending = pending && !win;
       }
-      ftop -= used < 32 ? used : 32;
       if (__ballot(limit != 0)) return -2;
     }
     if (!found) return 0;
@@ -478,7 +473,7 @@ struct Planner {
   }
 };
 
-constexpr int PLAN_LDS_BYTES = NCHUNK * 2 * 2;
+constexpr int PLAN_LDS_BYTES = NCHUNK * 2 * 2 + NS * 4 * 4 + NS * 2;
 
 // One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
 // (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
