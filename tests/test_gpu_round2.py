@@ -421,3 +421,51 @@ def test_device_corridor_front_end_equals_host(ctx):
         assert np.array_equal(hp[f], dp[f]), f
     assert hf.shape == df.shape and np.array_equal(hf["a"], df["a"]) and np.array_equal(hf["b"], df["b"])
     assert di["front_timing"]["expansions"] > 300 * n
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
+    """The scheduling devices of a big launch — hardest corridors first (a device-side sort), hard problems publishing frames ahead of
+    the idle takers, work sharing itself — decide who explores what and when, never what comes out: 8192 fused pairs solved with each
+    of them switched off in turn give the same result fields bit for bit."""
+    import torch
+
+    B, N = 8192, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=77, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    safe_t = corridor.safe_templates(whole)
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    dev = "cuda:0"
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    d_whole, d_faces = to_dev(whole), to_dev(faces)
+
+    def run(c):
+        d_safe, d_sf = to_dev(safe_t), torch.zeros_like(d_faces)
+        d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+        d_sr = torch.zeros_like(d_wr)
+        c.set_pair_margin(0.05)
+        c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(), d_sf.data_ptr(),
+                             d_sr.data_ptr())
+        c.sync()
+        return d_wr.cpu().numpy().view(abi.result_dtype).copy(), d_sr.cpu().numpy().view(abi.result_dtype).copy()
+
+    ref = run(ctx)
+    assert (ref[1]["solved"] == 1).mean() > 0.7
+    variants = {"FH_DEBUG_NO_ORDER": "1", "FH_DEBUG_GIANT_FACTOR": "0", "FH_DEBUG_BACKLOG": "0"}
+    for k, v in variants.items():
+        os.environ[k] = v
+        try:
+            got = run(ctx)
+        finally:
+            del os.environ[k]
+        for a, b in zip(ref, got):
+            for f in RESULT_FIELDS:
+                assert np.array_equal(a[f], b[f]), (k, f)
+    solo = capi.Context(0)
+    par = abi.default_params()
+    par["share"] = 0
+    solo.set_params(par)
+    got = run(solo)
+    solo.close()
+    for a, b in zip(ref, got):
+        for f in RESULT_FIELDS:
+            assert np.array_equal(a[f], b[f]), ("share=0", f)
