@@ -469,3 +469,49 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
     for a, b in zip(ref, got):
         for f in RESULT_FIELDS:
             assert np.array_equal(a[f], b[f]), ("share=0", f)
+
+
+@pytest.mark.gpu
+def test_independent_models_against_the_gpu_output_directly(ctx):
+    """The independent legs — SciPy SLSQP on the reference's own unreduced 12N-coefficient model (oracle/py_model.py, written row by
+    row as solverGurobi.cpp adds them), exhaustive enumeration of all P^N assignments with it, HiGHS on the mixed-integer constraint
+    set — applied to what the GPU returned, not to the C oracle: the optimum of the GPU's assignment, its global optimality at the
+    accepted dt, and the infeasibility of the factor before it."""
+    from oracle import py_model
+
+    def polys_of(p, faces):
+        fb = int(p["face_begin"])
+        return [(faces["a"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy(), faces["b"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy())
+                for q in range(int(p["n_poly"]))]
+
+    def args_of(p, faces):
+        return (p["x0"], p["xf"], float(p["v_max"]), float(p["a_max"]), float(p["j_max"]), bool(p["force_final_pos"]), polys_of(p, faces))
+
+    # (1) the GPU's coefficients are the optimum of the unreduced model under the GPU's assignment
+    pr, faces, _ = corridor.whole_batch(16, seed=203, n_seg=6, p_choices=(1, 2, 3))
+    res = ctx.solve_batch(pr, faces)
+    done = 0
+    for i in np.nonzero(res["solved"])[0][:8]:
+        p, r = pr[i], res[i]
+        N = int(p["n_seg"])
+        s = py_model.solve_fixed(N, float(r["dt"]), *args_of(p, faces), [int(a) for a in r["assign"][:N]])
+        assert s is not None
+        assert s[0] == pytest.approx(r["cost"], rel=1e-7, abs=1e-8)
+        np.testing.assert_allclose(s[1], r["coeff"][:N], atol=5e-6)
+        done += 1
+    assert done >= 5
+    # (2) no other assignment is better at the accepted dt (all P^N of them), and (3) the factor before the accepted one is infeasible
+    pr, faces, _ = corridor.whole_batch(24, seed=204, n_seg=4, p_choices=(2, 3), speed=3.5, lateral=1.0)
+    res = ctx.solve_batch(pr, faces)
+    solved = np.nonzero(res["solved"])[0]
+    assert len(solved) >= 6
+    for i in solved[:4]:
+        p, r = pr[i], res[i]
+        best, barg, nfeas = py_model.enumerate_miqp(4, float(r["dt"]), *args_of(p, faces))
+        assert nfeas >= 1 and best == pytest.approx(r["cost"], rel=1e-6, abs=1e-8), (i, best, r["cost"], barg, r["assign"][:4])
+    later = [i for i in solved if res[i]["trials"] >= 2][:3]
+    assert later, "no problem needed a second factor: make the corridors tighter"
+    for i in later:
+        p, r = pr[i], res[i]
+        dt_before = float(r["dt"]) * (float(r["factor"]) - float(p["f_inc"])) / float(r["factor"])
+        assert py_model.milp_feasible(4, dt_before, *args_of(p, faces), time_limit=30.0) is False, i
