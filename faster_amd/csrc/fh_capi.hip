@@ -30,9 +30,9 @@ struct fh_ctx {
   // slot 5: snapshot workspace, 6: work-sharing control block + ring sequence numbers, 7: decomposition workspace,
   // 8: task slots of the ring, 9: share records
   // 10: corridor segments, 11: per-segment polytope rows, 12: per-segment row counts (fh_corridor_batch_device)
-  // 13: launch order of a batch (order_kernel)
-  void* d_buf[14] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // 13: launch order of a batch (order_kernel), 14: bounding boxes of the cloud's blocks (decomposition)
+  void* d_buf[15] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
   size_t lds_attr[6] = {0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
@@ -263,7 +263,7 @@ void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 14; i++)
+    for (int i = 0; i < 15; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
     if (ctx->h_report) (void)hipHostFree(ctx->h_report);
@@ -631,12 +631,21 @@ int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_clou
   if (n_segments == 0) return FH_OK;
   if (!d_segments || !d_faces || !d_counts || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
   if (!(local_bbox[0] > 0) || !(local_bbox[1] > 0) || !(local_bbox[2] > 0) || !(drone_radius >= 0)) return FH_ERR_ARG;
-  const int grid = std::min(n_segments, ctx->n_cu * 4);  // LDS: 25 KB per workgroup
+  const int grid = std::min(n_segments, ctx->n_cu * 4);  // LDS: 29 KB per workgroup
   int rc;
   if ((rc = ensure(ctx, 7, sizeof(double) * (size_t)grid * (3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8))) != FH_OK) return rc;
+  // bounding boxes of the blocks of 64 cloud points: most blocks cannot touch a segment's local box and are skipped (same results)
+  double* d_blocks = nullptr;
+  const int n_blocks = (n_cloud + 63) / 64;
+  if (n_blocks >= 8 && !getenv("FH_DEBUG_NO_CLOUD_BLOCKS")) {
+    if ((rc = ensure(ctx, 14, sizeof(double) * 6 * (size_t)n_blocks)) != FH_OK) return rc;
+    d_blocks = (double*)ctx->d_buf[14];
+    hipLaunchKernelGGL(fh::cloud_blocks_kernel, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_cloud_xyz, n_cloud, d_blocks);
+    FH_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(fh::decomp_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_cloud_xyz, n_cloud, d_segments, n_segments,
                      local_bbox[0], local_bbox[1], local_bbox[2], drone_radius, z_ground, max_faces, (double*)ctx->d_buf[7], d_faces,
-                     d_counts);
+                     d_counts, d_blocks);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }

@@ -106,6 +106,7 @@ __device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt,
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+#define FH_DECOMP_BLIST 1024  // candidate blocks per segment (more: full sweep)
 #define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the list lives in the HBM workspace (dense clouds); more => count = -1
 
 // The decomposition of one segment with its list of box points at px/py/pz/flag (LDS for <= FH_DECOMP_CAP points, else the
@@ -113,14 +114,16 @@ __device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt,
 template <class PD, class PF>
 __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
                                const D3* bn, double inflate, double z_ground, int max_faces, fh_face* __restrict__ out,
-                               int32_t* __restrict__ count_out, int lane) {
+                               int32_t* __restrict__ count_out, int lane, const int* blist, int nb) {
   const D3 dvec = p2 - p1;
   const double f = norm(dvec) / 2;
   const Rot Ri = rot_onto(dvec);
   const D3 c = (p1 + p2) * 0.5;
   // ---- sweep the cloud: keep the points inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
   int cnt = 0;
-  for (int base = 0; base < n_cloud; base += 64) {
+  const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;  // (the blocks of 64 cloud points that can touch the box, in cloud order)
+  for (int j = 0; j < n_sweep; j++) {
+    const int base = (nb >= 0 ? blist[j] : j) * 64;
     const int i = base + lane;
     bool in = false;
     D3 q = d3(0, 0, 0);
@@ -215,14 +218,27 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
   if (lane == 0) *count_out = too_many ? -1 : rows;
 }
 
+// Bounding boxes of the blocks of 64 consecutive cloud points: blocks[b] = (min x, y, z, max x, y, z).  One wavefront per block.
+__global__ void __launch_bounds__(64) cloud_blocks_kernel(const double* __restrict__ cloud, int n_cloud, double* __restrict__ blocks) {
+  const int b = (int)blockIdx.x, lane = (int)threadIdx.x, i = b * 64 + lane;
+  double v[3] = {INFINITY, INFINITY, INFINITY}, w[3] = {INFINITY, INFINITY, INFINITY};  // w: negated, so that one min reduction does both
+  if (i < n_cloud)
+    for (int k = 0; k < 3; k++) { v[k] = cloud[3 * i + k]; w[k] = -v[k]; }
+  for (int k = 0; k < 3; k++) {
+    const double mn = wave_min(v[k]), mx = -wave_min(w[k]);
+    if (lane == 0) { blocks[6 * (size_t)b + k] = mn; blocks[6 * (size_t)b + 3 + k] = mx; }
+  }
+}
+
 // Persistent workgroups of one wavefront, segments taken in a grid-stride loop.  segments: [n][6] = p1, p2.  faces: [n][max_faces] rows
 // (a, b); counts[n] = rows written, -1 on overflow.  workspace: per workgroup 3 * CAP_GLOBAL doubles + CAP_GLOBAL bytes.
 __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
                                                     int n_segments, double bx, double by, double bz, double inflate, double z_ground,
                                                     int max_faces, double* __restrict__ workspace, fh_face* __restrict__ faces,
-                                                    int32_t* __restrict__ counts) {
+                                                    int32_t* __restrict__ counts, const double* __restrict__ blocks) {
   __shared__ double lpx[FH_DECOMP_CAP], lpy[FH_DECOMP_CAP], lpz[FH_DECOMP_CAP];
   __shared__ unsigned char lflag[FH_DECOMP_CAP];  // bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
+  __shared__ int lblist[FH_DECOMP_BLIST];         // blocks of the cloud that can touch the local box, ascending
   const int lane = threadIdx.x;
   double* gpx = workspace + (size_t)blockIdx.x * (size_t)(3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8);
   double* gpy = gpx + FH_DECOMP_CAP_GLOBAL;
@@ -254,8 +270,42 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
     bp[4] = p1 + dv * bz; bn[4] = dv;
     bp[5] = p1 - dv * bz; bn[5] = dv * -1.0;
     // first sweep: how many cloud points fall in the box decides where the list lives
+    // Blocks of 64 consecutive cloud points whose bounding box (blocks: cloud_blocks_kernel) misses the bounding box of the local box
+    // hold no point of interest: a mapper's cloud is spatially coherent, so most blocks are skipped.  The candidates are visited in
+    // cloud order, so the list of points — and with it every tie rule — is the one of the full sweep.
+    int nb = -1;
+    if (blocks) {
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        const D3 e = (corner & 1 ? p2 + dir * bx : p1 - dir * bx) + dh * (corner & 2 ? by : -by) + dv * (corner & 4 ? bz : -bz);
+        lo[0] = fmin(lo[0], e.x); lo[1] = fmin(lo[1], e.y); lo[2] = fmin(lo[2], e.z);
+        hi[0] = fmax(hi[0], e.x); hi[1] = fmax(hi[1], e.y); hi[2] = fmax(hi[2], e.z);
+      }
+      const int n_blocks = (n_cloud + 63) / 64;
+      nb = 0;
+      for (int b0 = 0; b0 < n_blocks && nb >= 0; b0 += 64) {
+        const int b = b0 + lane;
+        bool hit = false;
+        if (b < n_blocks) {
+          const double* bb = blocks + 6 * (size_t)b;
+          hit = bb[0] <= hi[0] + 1e-6 && bb[3] >= lo[0] - 1e-6 && bb[1] <= hi[1] + 1e-6 && bb[4] >= lo[1] - 1e-6 && bb[2] <= hi[2] + 1e-6 &&
+                bb[5] >= lo[2] - 1e-6;
+        }
+        const unsigned long long hm = __ballot(hit);
+        const int k = (int)__popcll(hm);
+        if (nb + k > FH_DECOMP_BLIST) nb = -1;  // too many candidates: the full sweep
+        else {
+          if (hit) lblist[nb + (int)__popcll(hm & ((1ull << lane) - 1ull))] = b;
+          nb += k;
+        }
+      }
+      __syncthreads();
+    }
     int cnt = 0;
-    for (int base = 0; base < n_cloud; base += 64) {
+    const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;
+    for (int j = 0; j < n_sweep; j++) {
+      const int base = (nb >= 0 ? lblist[j] : j) * 64;
       const int i = base + lane;
       bool in = false;
       if (i < n_cloud) {
@@ -267,9 +317,9 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
       cnt += __popcll(__ballot(in));
     }
     if (cnt <= FH_DECOMP_CAP)
-      decomp_segment(lpx, lpy, lpz, lflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane);
+      decomp_segment(lpx, lpy, lpz, lflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb);
     else if (cnt <= FH_DECOMP_CAP_GLOBAL)
-      decomp_segment(gpx, gpy, gpz, gflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane);
+      decomp_segment(gpx, gpy, gpz, gflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb);
     else if (lane == 0)
       counts[seg] = -1;
   }
