@@ -53,7 +53,8 @@ struct ShareCtl {
   unsigned int rec_next;      // share records handed out
   unsigned int donated, stolen, q_full, rec_full, lock_spins, max_fill;  // statistics
   unsigned int exited;        // workgroups that have left the kernel: the last one re-initialises this block for the next launch
-  unsigned int pad1[6];
+  unsigned int started;       // workgroups that have begun: publishing ahead is for a launch that has the device to itself (all begun)
+  unsigned int pad1[5];
   // ---- line 2: the hand-off counters (zeroed before every launch; written only when a worker runs out of problems or a frame
   // is published, read by the busy workers every few nodes) ----
   unsigned int wait_ticket;  // wait tickets drawn: takers committed to frame numbers 0 .. wait_ticket-1   } one aligned 8-byte

@@ -1309,7 +1309,11 @@ struct Solver {
           // nobody idle, room in the backlog: has this problem used giant_factor times the mean of the units finished so far?
           const unsigned long long dw = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->done));
           const unsigned long long done = dw & 0xffffffffull, sum = dw >> 32;
-          if (done >= 256ull && (unsigned long long)iters_so_far * done >= (unsigned long long)sa.giant_factor * sum) flags |= 8;
+          // ... and only in a launch whose workgroups are all resident: with other launches in flight the tail of this one is hidden
+          // behind their bulk and a hop is pure overhead
+          if (done >= 256ull && (unsigned long long)iters_so_far * done >= (unsigned long long)sa.giant_factor * sum &&
+              ald(&sa.ctl->started) == gridDim.x)
+            flags |= 8;
         }
       }
     }
@@ -2131,7 +2135,10 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
   sv.qe = 0;
   const ShareArgs& sa = ka.sa;
   double* ws = ka.workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
-  if (threadIdx.x == 0) sv.tb_put64(sv.TB_T0, wall_ticks());
+  if (threadIdx.x == 0) {
+    sv.tb_put64(sv.TB_T0, wall_ticks());
+    aadd(&sa.ctl->started, 1u);
+  }
   bool tickets_left = true;
 #ifdef FH_SHARE_PROFILE
   unsigned long long sp_dry__ = 0;
