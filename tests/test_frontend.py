@@ -181,3 +181,36 @@ def test_forest_batch_feeds_the_solver(oracle):
         assert np.all(faces["a"][f0:f1] @ p["xf"][:3] <= faces["b"][f0:f1] + 1e-9)
     res = oracle.solve_batch(pr, faces)
     assert res["solved"].mean() > 0.7
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_path_search_equals_pure_python_restatement(seed):
+    """The C++ front-end's map and path search against an independent pure-Python implementation (oracle/path_oracle.py: lists,
+    heapq): same occupancy grid, same vertices, same number of expanded cells — the order on the open list is total, so the container
+    cannot matter, and all arithmetic is +, *, /, sqrt on doubles."""
+    from oracle import path_oracle
+
+    cloud, centres = frontend.forest_cloud(seed, size=(8.0, 8.0, 2.0), density=0.2)
+    res, infl, zg, zmax = 0.25, 0.25, 0.0, 2.0
+    cells, center = (34, 34, 8), np.array([4.0, 4.0, 1.0])
+    rng = np.random.default_rng(seed)
+    n = 10
+    starts = np.column_stack([rng.uniform(0.5, 2.5, n), rng.uniform(0.5, 7.5, n), rng.uniform(0.3, 1.7, n)])
+    goals = np.column_stack([rng.uniform(5.5, 7.5, n), rng.uniform(0.5, 7.5, n), rng.uniform(0.3, 1.7, n)])
+    goals[0] = starts[0] + 0.01            # same cell
+    starts[1] = [-20.0, 4.0, 1.0]          # outside the map
+    starts[2, 2] = -0.4                    # clamped to the ground
+    hp, hn, hex_, occ, dims, origin = frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals, want_grid=True)
+    g = path_oracle.Grid(cloud.tolist(), cells, res, center.tolist(), zg, zmax, infl)
+    assert (g.nx, g.ny, g.nz) == tuple(int(v) for v in dims) and np.array_equal(np.array(g.origin), origin)
+    assert np.array_equal(np.frombuffer(bytes(g.occ), dtype=np.int8).reshape(occ.shape), occ)
+    solved = 0
+    for i in range(n):
+        path, ex = path_oracle.plan(g, starts[i].tolist(), goals[i].tolist())
+        if path is None:
+            assert hn[i] == 0, i
+            continue
+        solved += 1
+        assert hn[i] == len(path) and ex == hex_[i], (i, hn[i], len(path), ex, hex_[i])
+        assert np.array_equal(np.array(path), hp[i, :hn[i]]), i
+    assert solved >= 7

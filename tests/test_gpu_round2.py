@@ -515,3 +515,34 @@ def test_independent_models_against_the_gpu_output_directly(ctx):
         p, r = pr[i], res[i]
         dt_before = float(r["dt"]) * (float(r["factor"]) - float(p["f_inc"])) / float(r["factor"])
         assert py_model.milp_feasible(4, dt_before, *args_of(p, faces), time_limit=30.0) is False, i
+
+
+@pytest.mark.gpu
+def test_device_path_search_against_pure_python_restatement():
+    """fh_map_* against oracle/path_oracle.py directly (not through the C++ front-end): occupancy grid, vertices and expansion counts."""
+    from faster_amd import frontend
+    from oracle import path_oracle
+
+    cloud, _ = frontend.forest_cloud(6, size=(8.0, 8.0, 2.0), density=0.2)
+    res, infl, zg, zmax = 0.25, 0.25, 0.0, 2.0
+    cells, center = (34, 34, 8), np.array([4.0, 4.0, 1.0])
+    rng = np.random.default_rng(6)
+    n = 16
+    starts = np.column_stack([rng.uniform(0.5, 2.5, n), rng.uniform(0.5, 7.5, n), rng.uniform(0.3, 1.7, n)])
+    goals = np.column_stack([rng.uniform(5.5, 7.5, n), rng.uniform(0.5, 7.5, n), rng.uniform(0.3, 1.7, n)])
+    g = path_oracle.Grid(cloud.tolist(), cells, res, center.tolist(), zg, zmax, infl)
+    m = capi.Map(0)
+    m.read(cloud, cells, res, center, zg, zmax, infl)
+    assert np.array_equal(m.occupancy().reshape(-1), np.frombuffer(bytes(g.occ), dtype=np.int8))
+    dp, dn, dex = m.plan_batch(starts, goals)
+    m.close()
+    solved = 0
+    for i in range(n):
+        path, ex = path_oracle.plan(g, starts[i].tolist(), goals[i].tolist())
+        if path is None:
+            assert dn[i] == 0
+            continue
+        solved += 1
+        assert dn[i] == len(path) and dex[i] == ex, (i, dn[i], len(path), dex[i], ex)
+        assert np.array_equal(dp[i, :dn[i]], np.array(path)), i
+    assert solved >= 12
