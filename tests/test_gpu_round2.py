@@ -357,7 +357,7 @@ def test_device_map_and_path_search_equal_host_frontend():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["wall", "empty", "coarse", "tall"])
+@pytest.mark.parametrize("case", ["wall", "empty", "coarse", "tall", "large"])
 def test_device_path_search_edge_cases(case):
     from faster_amd import frontend
 
@@ -373,10 +373,14 @@ def test_device_path_search_edge_cases(case):
         cloud, _ = frontend.forest_cloud(4, size=(10.0, 10.0, 2.0), density=0.2)
         res, infl = 0.5, 0.2
         cells = (20, 20, 4)
-    else:                   # map centred high above the ground: z clipping of readMap on both sides
+    elif case == "tall":    # map centred high above the ground: z clipping of readMap on both sides
         cloud, _ = frontend.forest_cloud(5, size=(10.0, 10.0, 2.0), density=0.2)
         center = np.array([5.0, 5.0, 1.7])
         cells = (40, 40, 12)
+    else:                   # FASTER's own resolution: 0.1 m cells, 115 x 115 x 20 = 264 500 of them, paths of ~100 cells
+        cloud, _ = frontend.forest_cloud(8, size=(10.0, 10.0, 2.0), density=0.25)
+        res, infl = 0.1, 0.3
+        cells = (100, 100, 30)
     n = 256
     starts = np.column_stack([rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
     goals = np.column_stack([rng.uniform(6.0, 9.5, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
