@@ -42,6 +42,7 @@ struct fh_ctx {
   bool ctl_ready = false;                   // the device-side control block is in its initial state (left so by the previous launch)
   bool launched = false;                    // a solve launch has been issued since the control block was last checked
   int last_grid = 0;
+  bool order_ready = false;                 // the launch-order counters are zero (left so by the previous scatter kernel)
 };
 
 #define FH_HIP(call)                                                                            \
@@ -168,7 +169,8 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // big batches are started hardest corridors first (order_kernel); results do not depend on the order
   ka.order = nullptr;
   if (n >= 2048 && !getenv("FH_DEBUG_NO_ORDER")) {
-    const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 64);
+    const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 64) || !ctx->order_ready;
+    ctx->order_ready = false;  // (true again once all three launches below have been issued: a failed launch must not leave dirty counters behind)
     if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 64))) != FH_OK) return rc;
     int* counters = (int*)ctx->d_buf[13];
     int* order = counters + 64;
@@ -187,6 +189,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   ctx->ev_used += 2;
   ctx->launched = true;
   ctx->ctl_ready = true;
+  ctx->order_ready = ka.order != nullptr ? true : ctx->order_ready;
   ctx->last_grid = grid;
   return FH_OK;
 }
