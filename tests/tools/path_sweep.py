@@ -1,0 +1,67 @@
+"""Randomized parity sweep of the device front-end (fh_map_* + fh_corridor_batch_device) against the CPU front-end: maps of different
+size, resolution, inflation and tree density; per configuration the occupancy grid, every path vertex, every expansion count and every
+polytope row are compared bit for bit.  usage (GPU box, PYTHONPATH = repo root): path_sweep.py [queries_per_config] [configs]"""
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401
+
+from faster_amd import abi, capi, frontend
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+rng = np.random.default_rng(2024)
+ctx, vmap = capi.Context(0), capi.Map(0)
+tot_q = tot_exp = bad = 0
+t0 = time.time()
+for c in range(ncfg):
+    side = float(rng.choice([8.0, 12.0, 20.0]))
+    height = float(rng.choice([2.0, 3.0]))
+    res = float(rng.choice([0.15, 0.2, 0.25, 0.3]))
+    infl = float(rng.choice([0.0, 0.2, 0.3, 0.45]))
+    dens = float(rng.choice([0.05, 0.1, 0.2, 0.3]))
+    mvd = float(rng.choice([0.8, 1.5, 2.5]))
+    max_poly = int(rng.choice([4, 6, 8]))
+    size = (side, side, height)
+    cloud, _ = frontend.forest_cloud(100 + c, size=size, density=dens)
+    cells = (int(side / res) + 6, int(side / res) + 6, int(height / res))
+    center = np.array([side / 2, side / 2, height / 2])
+    starts = np.column_stack([rng.uniform(0.3, side - 0.3, nq), rng.uniform(0.3, side - 0.3, nq), rng.uniform(-0.2, height, nq)])
+    goals = np.column_stack([rng.uniform(0.3, side - 0.3, nq), rng.uniform(0.3, side - 0.3, nq), rng.uniform(-0.2, height, nq)])
+    hp, hn, hex_, hocc, hdims, horig = frontend.plan_batch(cloud, cells, res, center, 0.0, height, infl, starts, goals, max_points=max_poly + 1,
+                                                          max_vertex_dist=mvd, max_poly=max_poly, want_grid=True)
+    vmap.read(cloud, cells, res, center, 0.0, height, infl)
+    ok = np.array_equal(vmap.occupancy(), hocc)
+    dp, dn, dex = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=mvd, max_poly=max_poly)
+    ok = ok and np.array_equal(hn, dn) and np.array_equal(hex_, dex)
+    if ok:
+        for i in np.nonzero(hn > 0)[0]:
+            if not np.array_equal(hp[i, :hn[i]], dp[i, :hn[i]]):
+                ok = False
+                break
+    # corridors: the decomposition of the same vertices on the device against the host's
+    fpp = abi.FH_MAX_FACES
+    hf = np.zeros((nq, fpp, 4)); hoff = np.zeros((nq, 9), dtype=np.int32); hnp = np.zeros(nq, dtype=np.int32); hgoal = np.zeros((nq, 3))
+    frontend.lib().ff_corridor_batch(abi.ptr(frontend._c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(frontend._c(center)), 0.0, height,
+                                     infl, 0.05, abi.ptr(frontend._c(starts)), abi.ptr(frontend._c(goals)), nq, max_poly, mvd, fpp, abi.ptr(hf),
+                                     abi.ptr(hoff), abi.ptr(hnp), abi.ptr(hgoal))
+    df, doff, dnp, dgoal, _ = frontend.corridor_batch_device(ctx, vmap, cloud, cells, res, center, height, infl, starts, goals, max_poly, mvd, fpp, 0.05)
+    same_np = np.array_equal(hnp, dnp)
+    rows_ok = same_np
+    if same_np:
+        sel = hnp > 0
+        rows_ok = np.array_equal(hoff[sel], doff[sel])
+        if rows_ok:
+            for i in np.nonzero(sel)[0]:
+                k = hoff[i, hnp[i]]
+                if not np.array_equal(hf[i, :k], df[i, :k]):
+                    rows_ok = False
+                    break
+    bad += 0 if (ok and rows_ok) else 1
+    tot_q += nq
+    tot_exp += int(hex_.sum())
+    print("cfg %2d side %4.0f res %.2f infl %.2f dens %.2f mvd %.1f P<=%d | grid %s paths %.2f | search %s corridors %s | %ds" % (
+        c, side, res, infl, dens, mvd, max_poly, tuple(int(v) for v in hdims), (hn > 0).mean(), "OK" if ok else "MISMATCH",
+        "OK" if rows_ok else "MISMATCH", time.time() - t0), flush=True)
+print("PATH SWEEP DONE: %d configurations, %d queries, %d expanded cells, %d configurations with a mismatch" % (ncfg, tot_q, tot_exp, bad))
