@@ -131,13 +131,13 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   sa.min_nodes = 16;
   // Frames published AHEAD of the takers (served by workgroups between two problems).  What a launch ends on are problems with
   // 1200-4300 active-set iterations (C4: ~140 of 32768 pairs, mostly safe problems that are infeasible for all ten factors) that
-  // started early and ran on ONE wavefront until the fresh problems were exhausted.  A problem that has used 6x the mean number of
+  // started early and ran on ONE wavefront until the fresh problems were exhausted.  A problem that has used 4x the mean number of
   // iterations of the units finished so far may therefore publish up to 32 frames / trial ranges ahead: one launch alone 6.7 -> 6.1 ms,
   // 8 in flight -1 %.
   // (Publishing ahead from every problem with 64 nodes cost 13-25 % at any number of launches in flight: hop overhead in the bulk.)
   sa.backlog = 32;
   sa.giant_nodes = 1 << 30;
-  sa.giant_factor = 6;
+  sa.giant_factor = 4;
   if (const char* gi = getenv("FH_DEBUG_GIANT_FACTOR")) sa.giant_factor = atoi(gi);
   if (const char* bl = getenv("FH_DEBUG_BACKLOG")) sa.backlog = atoi(bl);
   if (const char* gn = getenv("FH_DEBUG_GIANT")) sa.giant_nodes = atoi(gn);
