@@ -31,10 +31,11 @@ struct fh_ctx {
   // 8: task slots of the ring, 9: share records
   // 10: corridor segments, 11: per-segment polytope rows, 12: per-segment row counts (fh_corridor_batch_device)
   // 13: launch order of a batch (order_kernel), 14: bounding boxes of the cloud's blocks (decomposition)
-  void* d_buf[15] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // 15: reduced-space basis tables (fh_basis.hip.hpp), uploaded once by fh_create
+  void* d_buf[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
-  size_t lds_attr[6] = {0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
+  size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
   unsigned int* d_abort = nullptr;          // its device address
   unsigned int* h_report = nullptr;         // pinned: the control block's report words of the last launch (copied with the results)
@@ -101,7 +102,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   if (const char* pad = getenv("FH_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
   auto kern = fh::solve_kernel<NSEG, PAIRS>;
   // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU)
-  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+  int per_cu = (int)std::min<size_t>(FH_WAVES_PER_SIMD * 4, (160 * 1024) / lds);
   if (per_cu < 1) per_cu = 1;
   const int resident = ctx->n_cu * per_cu;
   const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;
@@ -145,8 +146,9 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   if (const char* mn = getenv("FH_DEBUG_MIN_NODES")) sa.min_nodes = atoi(mn);
   ka.par = ctx->par;
   ka.workspace = (double*)ctx->d_buf[5];
+  ka.basis = (const double*)ctx->d_buf[15];
   {  // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it
-    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : 2)) + (PAIRS ? 3 : 0)];
+    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : (NSEG <= 15 ? 2 : 3))) + (PAIRS ? 4 : 0)];
     if (lds > have) {
       FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       have = lds;
@@ -259,6 +261,12 @@ int fh_create(fh_ctx** out, int device) {
   *ctx->h_abort = 0u;
   FH_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->d_abort), ctx->h_abort, 0));
   FH_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_report), 64, hipHostMallocDefault));
+  {  // the reduced-space basis tables: constants of N = 1..FH_MAX_SEG, computed here once and only read by the kernels
+    const std::vector<double> tab = fh::build_basis_tables();
+    int rc = ensure(ctx, 15, sizeof(double) * tab.size());
+    if (rc != FH_OK) return rc;
+    FH_HIP(hipMemcpy(ctx->d_buf[15], tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+  }
   return FH_OK;
 }
 
@@ -266,7 +274,7 @@ void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 15; i++)
+    for (int i = 0; i < 16; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
     if (ctx->h_report) (void)hipHostFree(ctx->h_report);
@@ -402,6 +410,7 @@ int fh_solve_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_fa
   ka.n = n; ka.max_faces = max_faces;
   if (max_seg <= 6) return launch_solve<6, false>(ctx, d_problems, d_faces, d_results, ka);
   if (max_seg <= 10) return launch_solve<10, false>(ctx, d_problems, d_faces, d_results, ka);
+  if (max_seg <= 15) return launch_solve<15, false>(ctx, d_problems, d_faces, d_results, ka);
   return launch_solve<FH_MAX_SEG, false>(ctx, d_problems, d_faces, d_results, ka);
 }
 
@@ -601,6 +610,7 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   ka.r_frac = r_frac; ka.shrink = shrink; ka.max_safe_poly = max_safe_poly; ka.r_margin = ctx->pair_margin;
   if (max_seg <= 6) return launch_solve<6, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   if (max_seg <= 10) return launch_solve<10, true>(ctx, d_whole, d_faces, d_whole_results, ka);
+  if (max_seg <= 15) return launch_solve<15, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   return launch_solve<FH_MAX_SEG, true>(ctx, d_whole, d_faces, d_whole_results, ka);
 }
 

@@ -19,15 +19,20 @@
 //   * the constraint matrix is never formed: rows are (face normal) x (Toeplitz weight of the triple integrator)
 //     and are evaluated from the control points (3 FMAs per row).
 //
-// Algorithm (same as the CPU oracle restates, oracle/faster_oracle.c): jerk-space QP min |x|^2, dual active-set
-// (Goldfarb-Idnani with identity Hessian, thin QR by re-orthogonalised Gram-Schmidt, Givens on removal), exact
-// branch and bound over "segment t in polytope p" with lazily branched segments; the first child of a node is
-// warm-started from its parent's factorisation (the dual method stays dual feasible when rows are added).
+// Algorithm (the model the CPU oracle restates, oracle/faster_oracle.c): jerk-space QP min |x|^2, solved in the REDUCED space
+// of the final-state equalities (setConstraintsXf, solverGurobi.cpp:332-357): x = xp + (Z (x) I3) y with Z the orthonormal
+// complement of the 2 (safe) or 3 (whole) end-state functionals per axis — it depends on N only, fh_basis.hip.hpp — and xp the
+// minimum-norm solution of the equalities, so a QP has 3(N-2) or 3(N-3) unknowns, cost |xp|^2 + |y|^2, and no equality rows in
+// its factorisation (N = 10: 24 / 21 unknowns instead of 30 + 6 / 9 rows).  Dual active-set (Goldfarb-Idnani with identity
+// Hessian, thin QR by re-orthogonalised Gram-Schmidt, Givens on removal), exact branch and bound over "segment t in polytope p"
+// with lazily branched segments; the first child of a node is warm-started from its parent's factorisation (the dual method
+// stays dual feasible when rows are added).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/fasterhip.h"
+#include "fh_basis.hip.hpp"
 #include "fh_share.hip.hpp"
 
 namespace fh {
@@ -54,6 +59,10 @@ namespace fh {
 #define FH_T1(slot)
 #endif
 #define FH_MAX_TRIALS 4096
+// Wavefronts per SIMD the solve kernels are compiled for (launch bounds: 512 / this many vector registers per lane, granule 8)
+#ifndef FH_WAVES_PER_SIMD
+#define FH_WAVES_PER_SIMD 3
+#endif
 // Gram-Schmidt is repeated when the first pass cancels more than this fraction of |g|^2 (Daniel-Gragg-Kaufman-Stewart use
 // 1/2; a smaller value trades a bounded loss of orthogonality, O(eps / sqrt(threshold)) per inserted row, for half the sweeps)
 #ifndef FH_REORTH_THRESHOLD
@@ -98,6 +107,10 @@ __device__ __forceinline__ void in_flight(double (&a)[10]) {
 __device__ __forceinline__ void in_flight(double (&a)[12]) {
   asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
                "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
+}
+__device__ __forceinline__ void in_flight(double (&a)[15]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+               "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]));
 }
 __device__ __forceinline__ void in_flight(double (&a)[16]) {
   asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
@@ -279,19 +292,24 @@ __device__ inline double dt_initial(const PR& pr) {
 // -----------------------------------------------------------------------------------------------------------------
 template <int NSEG>
 struct Solver {
-  static constexpr int NV = 3 * NSEG;
+  static constexpr int NX = 3 * NSEG;        // jerks of the trajectory (x space)
+  static constexpr int NXP = (NX + 7) & ~7;
+  static constexpr int KMAX = NSEG - 2;      // free dimensions per axis once the final-state equalities are eliminated (safe: N - 2)
+  static constexpr int NV = 3 * KMAX;        // unknowns y of a QP (reduced space)
   static constexpr int NVP = (NV + 7) & ~7;  // vectors / factor rows padded with zeros to a multiple of 8
   static constexpr int S = NVP + 1;          // odd row stride: conflict-free column AND row sweeps with ds_read_b64
   static constexpr int NT = NSEG + 1;
+  static constexpr int ZS = NSEG | 1;        // row stride of the basis Zm[s][l] (odd: lanes of different segments hit different banks)
+  static_assert(NSEG >= 3, "reduced space needs N - 2 > 0 columns");
   static constexpr int RPSZ = NVP * (NVP + 1) / 2;  // R is packed upper triangular, column major: R(r, c) = R[c(c+1)/2 + r]
   static __device__ __forceinline__ int rp(int r_, int c_) { return (c_ * (c_ + 1)) / 2 + r_; }
 
   // ---- LDS carve (doubles first) ----
   double *Q, *R;                                      // Q1 column major [NVP cols][S] (column c = active slot); R packed upper triangular [RPSZ]
-  double *x, *z, *g, *d, *r, *u, *rinv;               // [NVP] (r aliases d: only live inside the re-orthogonalisation pass)
+  double *x, *z, *g, *d, *r, *u, *rinv;               // [NVP] x = the reduced unknowns y (r aliases d: only live inside the re-orthogonalisation pass)
+  double* xs;                                         // [NXP] x-space scratch: Z y (compute_states), a row normal in x space (build_g)
+  double* Zm;                                         // [NSEG][ZS] orthogonal basis of this N (fh_basis.hip.hpp), kept across problems
   double *Pc, *Vc, *Ac;                               // [NT*3] current states at segment starts
-  double* CP;                                         // [NSEG][4][3] Bezier control points of the current x
-  double* wtab;                                       // [W_KINDS][NT] scratch (aliases z..): inverse row norms, read once per trial
   double* viol;                                       // [NSEG][FH_MAX_POLY]
   double* xfl;                                        // [9] goal state (+3 pad)
   double* tolf;                                       // [n_faces] feas_tol / |a_f|
@@ -300,24 +318,35 @@ struct Solver {
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
-         TB_T0 = 14, TB_WORK = 16, TB_WORDS = 18 };  // TB_WORK: active-set iterations of the unit in hand (reported with `done`)
+         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_WORDS = 18 };  // TB_WORK: active-set iterations of the unit in hand (reported with `done`);
+                                                                 // TB_ZN: the N whose basis is in Zm (0: none yet)
   signed char* stk_order;                             // [NSEG][FH_MAX_POLY] child order per tree level
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 3 * NVP + 3 * NT * 3 + NSEG * 12 + 12) +
+    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 3 * NVP + NXP + NSEG * ZS + 3 * NT * 3 + 12) +
            sizeof(int) * (9 * NSEG + FH_MAX_POLY + 1 + 3 + TB_WORDS) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
            (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
   }
 
   // ---- per-lane state kept in registers (LDS is what limits the number of resident solves) ----
-  double p0r, v0r, a0r;   // lane = (tt, i) < 3 NT: zero-jerk propagation of x0 to the start of segment tt (per trial)
-  double wbv, wba, wcp;   // inverse row norms of this lane's box rows (lane = (t, i)) and corridor rows (lane = (t, k)) (per trial)
-  double bestx_r;         // lane < n: incumbent jerks
+  double p0r, v0r, a0r;   // lane = (tt, i) < 3 NT: state at the start of segment tt for y = 0: zero-jerk propagation of x0 plus the
+                          //   contribution of xp (per trial)
+  double xpr;             // lane = (s, i) < 3 N: jerk xp of the minimum-norm solution of the final-state equalities (per trial)
+  double xj;              // lane = (s, i) < 3 N: current jerk xp + (Z y) (compute_states -> scan)
+  double wbj, wbv, wba, wcp;  // inverse row norms IN THE REDUCED SPACE of this lane's box rows (lane = (t, i)) and corridor rows
+                          //   (lane = (t, k)); 0: the row does not depend on y (per trial)
+  double bestx_r;         // lane < n: incumbent y
   double cp_r[3];         // lane = (t, k): control point k of segment t at the current x (compute_states -> scan)
   int scan_f0, scan_F;    // lane = (t, k): first row and row count of the polytope segment t is assigned to (0 rows: free) (per node)
   // ---- wave-uniform scalars ----
-  int lane, N, n, q, P;
-  int qe;  // number of equality rows: always the first columns of the factorisation
+  int lane, N, n, q, P;   // n = 3 K: unknowns of the reduced QP
+  int nx;                 // 3 N: jerks of the trajectory
+  int K, zc0;             // Z = columns zc0 .. zc0 + K - 1 of Zm (zc0 = 2 safe, 3 whole; K = max(N - zc0, 0))
+  int qe;                 // equality rows in the factorisation: always 0 (they are eliminated; kept in the frame header layout)
+  bool eq_ok;             // the final-state equalities of this trial are consistent (always, unless N < 3)
+  double c0;              // |xp|^2: cost of the trial at y = 0
+  double box_ub;          // 3N j_max^2 (1 + 1e-9): no feasible trajectory costs more
+  double gx2;             // |normal in jerk space|^2 of the row build_g built last
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
   unsigned poly_ok;  // polytopes without a violated zero-normal face (such a polytope can never hold a segment)
 #ifdef FH_PROFILE
@@ -342,11 +371,11 @@ struct Solver {
     act = reinterpret_cast<int*>(p); p += NVP / 2;
     // ---- end of the snapshot block ----
     z = p; p += NVP;  g = p; p += NVP;  d = p; p += NVP;  r = d;
+    xs = p; p += NXP;
+    Zm = p; p += NSEG * ZS;
     Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
-    CP = p; p += NSEG * 12;
-    viol = z;  // [NSEG][FH_MAX_POLY] aliases z,g,d: only live between two active-set runs (analyze, init_equalities)
-    wtab = z;  // [W_KINDS][NT], live inside setup_trial only
-    static_assert(NSEG * FH_MAX_POLY <= 3 * NVP && 3 * NT + 9 <= 3 * NVP && W_KINDS * NT <= 3 * NVP, "scratch must fit in z,g,d");
+    viol = z;  // [NSEG][FH_MAX_POLY] aliases z,g,d,xs: only live between two active-set runs (analyze)
+    static_assert(NSEG * FH_MAX_POLY <= 3 * NVP + NXP && 9 <= NVP, "scratch must fit in z,g,d,xs");
     xfl = p; p += 12;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
@@ -435,92 +464,176 @@ struct Solver {
     for (int i = lane; i < NVP * S; i += 64) Q[i] = 0.0;
     for (int i = lane; i < RPSZ; i += 64) R[i] = 0.0;
     if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
+    if (lane < NXP) xs[lane] = 0;
     q = 0;
     FH_SYNC();
   }
 
-  // ---- per trial: jerk-free states and row-norm table for step h ----
+  // ---- x-space jerks in xs[] -> their contribution to the state at the start of segment tt = lane / 3 (lane < 3 NT) ----
+  // sum_{s<tt} c(m) x_s with m = tt-1-s and c polynomial in m: three moments S_k = sum m^k x_s carry all three states
+  // (cP = h^3 (1/6 + m/2 + m^2/2), cV = h^2 (1/2 + m), cA = h); nothing per-(lane, s) to keep in registers.
+  __device__ __forceinline__ void moments(double& dp, double& dv, double& da) const {
+    const int tt = lane / 3, i = lane - 3 * tt;
+    const int ii = lane < 3 * NT ? i : 0;
+    double xr[NSEG];
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) xr[s] = xs[3 * s + ii];  // unpredicated (xs is zero beyond 3 N)
+    in_flight(xr);
+    double s0 = 0, s1 = 0, s2 = 0;
+    const double dm0 = opaque((double)(tt - 1));
+#pragma unroll
+    for (int s = 0; s < NSEG; s++) {
+      const double dm = dm0 - (double)s;
+      const double xv = xr[s] * fmin(fmax(dm + 1.0, 0.0), 1.0);  // segments s >= tt contribute nothing
+      const double t1 = dm * xv;
+      s0 += xv;
+      s1 += t1;
+      s2 = fma(dm, t1, s2);
+    }
+    const double h2 = h * h, h3 = h2 * h;
+    dp = h3 * (s0 * (1.0 / 6.0) + 0.5 * s1 + 0.5 * s2);
+    dv = h2 * (0.5 * s0 + s1);
+    da = h * s0;
+  }
+
+  // ---- per trial (step h): states for y = 0 and the inverse row norms.  bt: the basis table of this N (fh_basis.hip.hpp) ----
   template <class PR>
-  __device__ void setup_trial(const PR& pr) {
+  __device__ void setup_trial(const PR& pr, const double* __restrict__ bt) {
+    double p, v, a;
     {  // zero-jerk propagation of x0 to the start of segment tt = lane / 3 (same recurrence, step by step, as the oracle)
       const int tt = lane / 3, i = lane - 3 * tt;
       const bool on = lane < 3 * NT;
-      double p = on ? pr.x0[i] : 0.0, v = on ? pr.x0[3 + i] : 0.0;
-      const double a = on ? pr.x0[6 + i] : 0.0;
+      p = on ? pr.x0[i] : 0.0;
+      v = on ? pr.x0[3 + i] : 0.0;
+      a = on ? pr.x0[6 + i] : 0.0;
       for (int t = 0; t < N; t++) {
         const double pn = p + v * h + 0.5 * a * h * h, vn = v + a * h;
         p = (t < tt) ? pn : p;
         v = (t < tt) ? vn : v;
       }
-      p0r = p; v0r = v; a0r = a;
     }
-    FH_SYNC();  // the scratch below aliases z, g, d
-    for (int idx = lane; idx < W_KINDS * NT; idx += 64) {
-      const int kind = idx / NT, tt = idx % NT;
-      double s = 0;
-      for (int m = 0; m < tt && tt <= N; m++) {
-        const double c = wcoef(kind, m, h);
-        s += c * c;
+    // final-state equalities (setConstraintsXf :332-357): xp = Q[:, 0:3] (M rho), rho_j = (target_j - zero-jerk end state_j) / h^p_j
+    // for the rows in the reference's order ([pos], vel, accel).  One lane per axis; M, G and the mask of dependent rows (N < 3:
+    // a dependent row is skipped if consistent, else the trial is infeasible) come from the table.
+    typedef const __attribute__((address_space(4))) double cdouble;
+    const cdouble* E = (const cdouble*)(unsigned long long)(bt + BT_EQ + (force_final ? BT_EQ_WORDS : 0));
+    bool bad = false;
+    {
+      double endP = 0, endV = 0, endA = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const double ep = readlane_f64(p, 3 * N + i), ev = readlane_f64(v, 3 * N + i), ea = readlane_f64(a, 3 * N + i);
+        if (lane == i) { endP = ep; endV = ev; endA = ea; }
       }
-      const double w = sqrt(s);
-      wtab[idx] = w > 0.0 ? 1.0 / w : 0.0;
+      const int nrow = force_final ? 3 : 2, koff = 3 - nrow;
+      const double ih = 1.0 / h;
+      const double ihp[3] = {ih * ih * ih, ih * ih, ih};  // by kind: pos, vel, accel
+      const double hp[3] = {h * h * h, h * h, h};
+      const int axis = lane < 3 ? lane : 0;
+      double rho[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int kind = (j + koff) < 3 ? j + koff : 2;
+        const double base = kind == 0 ? endP : (kind == 1 ? endV : endA);
+        rho[j] = (j < nrow) ? (xfl[kind * 3 + axis] - base) * (kind == 0 ? ihp[0] : (kind == 1 ? ihp[1] : ihp[2])) : 0.0;
+      }
+      const int mask = (int)E[18];
+#pragma unroll
+      for (int l = 0; l < 3; l++) {
+        const double cl = E[l * 3 + 0] * rho[0] + E[l * 3 + 1] * rho[1] + E[l * 3 + 2] * rho[2];
+        if (lane < 3) z[l * 3 + lane] = cl;  // (scratch: z is rewritten before it is read by the solver)
+        if ((mask >> l) & 1) {
+          const int kind = (l + koff) < 3 ? l + koff : 2;
+          const double res = (kind == 0 ? hp[0] : (kind == 1 ? hp[1] : hp[2])) * (E[9 + l * 3 + 0] * rho[0] + E[9 + l * 3 + 1] * rho[1] + E[9 + l * 3 + 2] * rho[2]);
+          if (lane < 3 && fabs(res) > tol) bad = true;
+        }
+      }
+    }
+    eq_ok = !wave_any(bad);
+    FH_SYNC();
+    {
+      const int s = lane / 3, i = lane - 3 * s;
+      double xp = 0.0;
+      if (lane < nx) {
+        const int nl = N < 3 ? N : 3;
+        for (int l = 0; l < nl; l++) xp += Zm[s * ZS + l] * z[l * 3 + i];
+      }
+      xpr = xp;
+      if (lane < NXP) xs[lane] = xp;
+      c0 = wave_sum(xp * xp);
     }
     FH_SYNC();
-    {  // each lane keeps the inverse norms of the rows it scans
-      const int t = lane / 3;
-      const bool box = lane < n && t >= 1;  // t = 0 box rows are constants
-      wbv = box ? wtab[W_V * NT + t] : 0.0;
-      wba = box ? wtab[W_A * NT + t] : 0.0;
-      const int tc = lane >> 2, k = lane & 3;
-      wcp = (lane < 4 * N) ? wtab[(k == 3 ? W_P : k) * NT + tc + (k == 3 ? 1 : 0)] : 0.0;
+    {
+      double dp, dv, da;
+      moments(dp, dv, da);
+      p0r = p + dp; v0r = v + dv; a0r = a + da;
     }
-    FH_SYNC();  // (z, g, d are rewritten in full before they are read again)
+    {  // each lane keeps the inverse norms (reduced space) of the rows it scans; they scale with h^-3 (positions), h^-2, h^-1
+      const double ih = 1.0 / h;
+      const double* C = bt + BT_C + (force_final ? BT_C_WORDS : 0);
+      const double* CJ = bt + BT_CJ + (force_final ? BT_CJ_WORDS : 0);
+      const int t = lane / 3;
+      const bool box = lane < nx;
+      wbj = box ? CJ[t] : 0.0;
+      wbv = box ? C[W_V * BT_C_TT + t] * (ih * ih) : 0.0;
+      wba = box ? C[W_A * BT_C_TT + t] * ih : 0.0;
+      const int tc = lane >> 2, k = lane & 3;
+      wcp = (lane < 4 * N) ? C[(k == 3 ? W_P : k) * BT_C_TT + tc + (k == 3 ? 1 : 0)] * (ih * ih * ih) : 0.0;
+    }
+    FH_SYNC();  // (xs and z are rewritten in full before they are read again)
   }
 
-  // ---- states at segment starts and Bezier control points of the current x (getCP0..3, :833-862) ----
+  // Bezier control point k of a segment from the state (P, V, A) at its start and the position Pn at its end (getCP0..3, :833-862)
+  __device__ __forceinline__ double cp_of(int k, double P_, double V_, double A_, double Pn) const {
+    const double wv = k == 1 ? h / 3.0 : (k == 2 ? 2.0 * h / 3.0 : 0.0);
+    const double wa = k == 2 ? h * h / 6.0 : 0.0;
+    return k == 3 ? Pn : P_ + wv * V_ + wa * A_;
+  }
+
+  // ---- jerks x = xp + Z y, states at segment starts and Bezier control points of the current y ----
   __device__ void compute_states() {
-    if (lane < (N + 1) * 3) {
-      const int tt = lane / 3, i = lane - 3 * tt;
-      // sum_{s<tt} c(m) x_s with m = tt-1-s and c polynomial in m: three moments S_k = sum m^k x_s carry all three states
-      // (cP = h^3 (1/6 + m/2 + m^2/2), cV = h^2 (1/2 + m), cA = h); nothing per-(lane, s) to keep in registers.
-      double xr[NSEG];
+    {  // lane = (s, i): (Z y)_(s,i) = sum_k Zm[s][zc0 + k] y[3 k + i]
+      const int s = lane / 3, i = lane - 3 * s;
+      const bool on = lane < nx;
+      const double* zr = Zm + (on ? s : 0) * ZS + zc0;
+      const double* yr = x + (on ? i : 0);
+      double a0 = 0, a1 = 0;
+      const int kl = K > 0 ? K - 1 : 0;
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        double zv[4], yv[4];
 #pragma unroll
-      for (int s = 0; s < NSEG; s++) xr[s] = x[3 * s + i];  // unpredicated (x is zero padded)
-      in_flight(xr);
-      double s0 = 0, s1 = 0, s2 = 0;
-      const double dm0 = opaque((double)(tt - 1));
+        for (int j = 0; j < 4; j++) {
+          const int k = min(k0 + j, kl);
+          zv[j] = zr[k];
+          yv[j] = yr[3 * k];
+        }
 #pragma unroll
-      for (int s = 0; s < NSEG; s++) {
-        const double dm = dm0 - (double)s;
-        const double xs = xr[s] * fmin(fmax(dm + 1.0, 0.0), 1.0);  // segments s >= tt contribute nothing
-        const double t1 = dm * xs;
-        s0 += xs;
-        s1 += t1;
-        s2 = fma(dm, t1, s2);
+        for (int j = 0; j < 4; j += 2) {
+          a0 += (k0 + j < K) ? zv[j] * yv[j] : 0.0;
+          a1 += (k0 + j + 1 < K) ? zv[j + 1] * yv[j + 1] : 0.0;
+        }
       }
-      const double h2 = h * h, h3 = h2 * h;
-      const double p = p0r + h3 * (s0 * (1.0 / 6.0) + 0.5 * s1 + 0.5 * s2);
-      const double v = v0r + h2 * (0.5 * s0 + s1);
-      const double a = a0r + h * s0;
-      Pc[lane] = p; Vc[lane] = v; Ac[lane] = a;
+      const double xz = on ? a0 + a1 : 0.0;
+      xj = xpr + xz;
+      if (lane < NXP) xs[lane] = xz;
+    }
+    FH_SYNC();
+    if (lane < (N + 1) * 3) {
+      double dp, dv, da;
+      moments(dp, dv, da);
+      Pc[lane] = p0r + dp; Vc[lane] = v0r + dv; Ac[lane] = a0r + da;
     }
     FH_SYNC();
     if (lane < 4 * N) {  // lane = (segment, control point): three axes each, no integer divisions
       const int t = lane >> 2, k = lane & 3;
-      const int o = (t + (k == 3 ? 1 : 0)) * 3;
-      const double wv = k == 1 ? h / 3.0 : (k == 2 ? 2.0 * h / 3.0 : 0.0);
-      const double wa = k == 2 ? h * h / 6.0 : 0.0;
-      double st[9];
+      const int o = t * 3;
+      double st[12];
 #pragma unroll
-      for (int i = 0; i < 3; i++) { st[i] = Pc[o + i]; st[3 + i] = Vc[o + i]; st[6 + i] = Ac[o + i]; }
+      for (int i = 0; i < 3; i++) { st[i] = Pc[o + i]; st[3 + i] = Vc[o + i]; st[6 + i] = Ac[o + i]; st[9 + i] = Pc[o + 3 + i]; }
       in_flight(st);
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        cp_r[i] = st[i] + wv * st[3 + i] + wa * st[6 + i];
-        CP[lane * 3 + i] = cp_r[i];  // for the leaf analysis; the row scan of this iteration uses the registers
-      }
+      for (int i = 0; i < 3; i++) cp_r[i] = cp_of(k, st[i], st[3 + i], st[6 + i], st[9 + i]);
     }
-    FH_SYNC();
   }
 
   // assign[] only changes between two active-set runs: the scan lanes look their rows up once per run
@@ -549,18 +662,19 @@ struct Solver {
     double bs = 0, bv = 0;
     int bid = -1;
     bool bad = false;
-    if (lane < n) {
+    bool badb = false;  // a violated box row that does not depend on y (N < 4 only; the t = 0 rows are checked before the search)
+    if (lane < nx) {
       const int t = lane / 3, i = lane - 3 * t;
-      const double xv = x[lane];
+      const double xv = xj;
       const double V = Vc[lane], A = Ac[lane];
-      const double iV = wbv, iA = wba;  // (zero for the constant t = 0 rows)
       const double val[3] = {xv, V, A};
       const double lim[3] = {jmax, vmax, amax};
-      const double inv[3] = {1.0, iV, iA};
+      const double inv[3] = {wbj, wbv, wba};  // (zero for rows that do not depend on y: t = 0)
 #pragma unroll
       for (int c = 0; c < 3; c++) {  // |value| - limit: at most one of the two box rows of a quantity can be violated
         const double cv = fabs(val[c]) - lim[c];
         const double sc = cv * inv[c];
+        badb |= cv > tol && inv[c] == 0.0 && (c == 0 || t > 0);
         const bool take = cv > tol && sc > bs;
         bs = take ? sc : bs;
         bv = take ? cv : bv;
@@ -591,15 +705,15 @@ struct Solver {
         }
       }
       if (bf >= 0) {
-        if (wi == 0.0) bad = true;  // jerk-independent row (segment 0, control points 0..2) violated
+        if (wi == 0.0) bad = true;  // a row that does not depend on y (segment 0: control points 0..2; whole trajectory: 1..3 of the last segment) violated
         else {
           const double sc = bvt * wi;
           if (sc > bs) { bs = sc; bv = bvt + tolf[f0 + bf]; bid = mk_id(K_POLY, t, k, bf); }
         }
       }
     }
-    const_bad = wave_any(bad);
-    if (const_bad) conflict = wave_or(bad ? (1u << ((lane >> 2) & 31)) : 0u);  // (the jerk-independent rows of segment 0's polytope)
+    const_bad = wave_any(bad || badb);
+    if (const_bad) conflict = wave_or(bad ? (1u << ((lane >> 2) & 31)) : 0u);  // (the y-independent rows of a segment's polytope)
     const double mx = wave_max_nonneg(bs);
     id_out = -1;
     v_out = 0;
@@ -610,34 +724,54 @@ struct Solver {
     }
   }
 
-  // ---- normal of row `id` in jerk space: g[v], v = 3 s + i.  returns |g|^2 ----
+  // ---- normal of row `id` in the reduced space: g = (Z (x) I3)^T (normal in jerk space), lane = (k, i).  returns |g|^2 ----
   __device__ double build_g(int id) {
     const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
     double gv = 0;
-    if (lane < n) {
-      const int s = lane / 3, i = lane - 3 * s;
-      if (kind == K_JBOX) {
-        gv = (s == t && i == k) ? (f ? -1.0 : 1.0) : 0.0;
-      } else {
-        int wk, tt;
+    const int kk = lane / 3, ia = lane - 3 * kk;
+    if (kind == K_JBOX) {  // x-space normal +-e_(t,k): row t of Z
+      if (lane < n) gv = (ia == k) ? (f ? -Zm[t * ZS + zc0 + kk] : Zm[t * ZS + zc0 + kk]) : 0.0;
+      gx2 = 1.0;
+    } else {
+      int wk, tt;
+      {  // x-space normal: (3-vector) x (Toeplitz weight of the triple integrator), lane = (s, i)
         double gi;
         if (kind == K_POLY) {
           wk = (k == 3) ? W_P : k;
           tt = t + (k == 3 ? 1 : 0);
-          gi = faces[face_off[assign[t]] + f].a[i];
-        } else if (kind == K_EQ) {  // f = axis*3 + which (0 pos, 1 vel, 2 accel), state at the end (tt = N)
-          const int axis = f / 3, which = f - 3 * axis;
-          wk = which == 0 ? W_P : (which == 1 ? W_V : W_A);
-          tt = N;
-          gi = (i == axis) ? 1.0 : 0.0;
+          gi = faces[face_off[assign[t]] + f].a[ia];
         } else {
           wk = (kind == K_VBOX) ? W_V : W_A;
           tt = t;
-          gi = (i == k) ? (f ? -1.0 : 1.0) : 0.0;
+          gi = (ia == k) ? (f ? -1.0 : 1.0) : 0.0;
         }
-        const int m = tt - 1 - s;
-        gv = (m >= 0) ? gi * wcoef(wk, m, h) : 0.0;
+        const int m = tt - 1 - kk;  // (here kk is the segment s of the x-space lane)
+        const double gxv = (lane < nx && m >= 0) ? gi * wcoef(wk, m, h) : 0.0;
+        if (lane < NXP) xs[lane] = gxv;
+        gx2 = wave_sum(gxv * gxv);
       }
+      FH_SYNC();
+      const bool on = lane < n;
+      const double* zr = Zm + zc0 + (on ? kk : 0);
+      const double* gr = xs + (on ? ia : 0);
+      const int smax = min(tt, N);  // (the normal is zero from segment tt on)
+      const int sl = smax > 0 ? smax - 1 : 0;
+      double a0 = 0, a1 = 0;
+      for (int s0 = 0; s0 < smax; s0 += 4) {
+        double zv[4], xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int s_ = min(s0 + j, sl);
+          zv[j] = zr[s_ * ZS];
+          xv[j] = gr[3 * s_];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          a0 += (s0 + j < smax) ? zv[j] * xv[j] : 0.0;
+          a1 += (s0 + j + 1 < smax) ? zv[j + 1] * xv[j + 1] : 0.0;
+        }
+      }
+      gv = on ? a0 + a1 : 0.0;
     }
     if (lane < NVP) g[lane] = gv;
     FH_SYNC();
@@ -778,8 +912,7 @@ struct Solver {
   // Row-scaled recurrence: lane l carries (d_l - sum_{j>l} R_lj r_j) / R_ll, which is final (= r_l) once column l has been
   // consumed, so that the serial chain per column is one broadcast and one FMA; the scaled, masked coefficients
   // R_lc / R_ll do not depend on the recurrence and are prepared four columns ahead.
-  // The equality rows are always the first qe columns and their multipliers are never read (free sign, never dropped), so the
-  // recurrence stops at the first inequality column: lanes below qe return 0.
+  // (qe = 0: the final-state equalities are eliminated, every column is an inequality row.)
   __device__ double backsolve(double dc) {
     const int ll = lane < NVP ? lane : NVP - 1;
     const double ri = (lane < q && lane >= qe) ? rinv[lane] : 0.0;
@@ -867,130 +1000,6 @@ struct Solver {
     FH_SYNC();
   }
 
-  // ---- dual active set from the current (dual feasible) state.  eq_next: next equality to add (9 = none left).
-  // returns 0 optimal, 1 infeasible, 2 bounded out by `ub`, 3 iteration limit ----
-  // ---- final-state equalities (setConstraintsXf :332-357), built directly instead of by 6-9 active-set iterations.
-  // Their normals are the same three jerk->state functionals w_P, w_V, w_A (N-vectors, m = N-1-s) on every axis, and
-  // the axes have disjoint supports, so the thin QR of the 6/9 rows is a 3-vector Gram-Schmidt (lane = segment)
-  // replicated per axis, and the minimum-norm point is three triangular 3x3 solves.  Rows are taken in the oracle's
-  // order (per axis: [pos], vel, accel); a dependent row (N < 3) is skipped if consistent, else the node is infeasible.
-  // Leaves q = number of accepted rows, x = minimum-norm point.  Returns false if inconsistent. ----
-  __device__ bool init_equalities() {
-    const int nrow = force_final ? 3 : 2;
-    const int koff = 3 - nrow;  // row j uses functional kind j + koff: 0 pos, 1 vel, 2 accel
-    double* eqq = viol;          // [3][NT] orthonormal N-vectors, indexed by segment s
-    double* eqy = viol + 3 * NT; // [3][3]  coefficients y_j per axis
-    const bool on = lane < N;
-    const int m = N - 1 - lane;
-    double F[3], Qv[3] = {0.0, 0.0, 0.0};
-    bool acc[3] = {false, false, false};
-    double rd[3] = {1.0, 1.0, 1.0}, ro[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const int kind = j + koff;
-      F[j] = (on && j < nrow) ? wcoef(kind == 0 ? W_P : (kind == 1 ? W_V : W_A), m, h) : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      if (j < nrow) {
-        double zj = F[j];
-        double dd[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++)
-#pragma unroll
-          for (int jp = 0; jp < 3; jp++)
-            if (jp < j && acc[jp]) {
-              const double e = wave_sum(Qv[jp] * zj);
-              zj -= e * Qv[jp];
-              dd[jp] += e;
-            }
-        const double zz = wave_sum(zj * zj), ff = wave_sum(F[j] * F[j]);
-#pragma unroll
-        for (int jp = 0; jp < 3; jp++) ro[jp][j] = dd[jp];
-        if (zz > dep2 * ff) {
-          acc[j] = true;
-          rd[j] = sqrt(zz);
-          Qv[j] = zj / rd[j];
-        }
-      }
-    }
-    FH_SYNC();
-    if (on) {
-#pragma unroll
-      for (int j = 0; j < 3; j++) eqq[j * NT + lane] = Qv[j];
-    }
-    // zero-jerk end state of this lane's axis (registers of the lanes (N, i))
-    double endP = 0, endV = 0, endA = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const double ep = readlane_f64(p0r, 3 * N + i), ev = readlane_f64(v0r, 3 * N + i), ea = readlane_f64(a0r, 3 * N + i);
-      if (lane == i) { endP = ep; endV = ev; endA = ea; }
-    }
-    // per axis: forward substitution R^T y = rhs, consistency of skipped rows
-    bool bad = false;
-    if (lane < 3) {
-      double y[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        if (j < nrow) {
-          const int kind = j + koff;
-          const double base = kind == 0 ? endP : (kind == 1 ? endV : endA);
-          double rhs = xfl[kind * 3 + lane] - base;
-#pragma unroll
-          for (int jp = 0; jp < 3; jp++)
-            if (jp < j && acc[jp]) rhs -= ro[jp][j] * y[jp];
-          if (acc[j]) y[j] = rhs / rd[j];
-          else if (fabs(rhs) > tol) bad = true;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 3; j++) eqy[j * 3 + lane] = y[j];
-    }
-    if (wave_any(bad)) return false;
-    FH_SYNC();
-    int cnt = 0, rank[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) { rank[j] = cnt; cnt += acc[j] ? 1 : 0; }
-    if (lane < n) {  // x and the Q1 columns of this lane's axis
-      const int s = lane / 3, i = lane - 3 * s;
-      double xv = 0.0;
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-        if (acc[j]) {
-          const double qv = eqq[j * NT + s];
-          xv += qv * eqy[j * 3 + i];
-          Q[(i * cnt + rank[j]) * S + lane] = qv;
-        }
-      x[lane] = xv;
-    }
-    if (lane < 3 * cnt) {  // column `lane` of R (block diagonal per axis), bookkeeping
-      const int i = lane / cnt, rk = lane - i * cnt;
-      int j = 0;
-#pragma unroll
-      for (int jj = 0; jj < 3; jj++)
-        if (acc[jj] && rank[jj] == rk) j = jj;
-      for (int c2 = 0; c2 < lane; c2++) {
-        double v = 0.0;
-        const int i2 = c2 / cnt, rk2 = c2 - i2 * cnt;
-        if (i2 == i) {
-#pragma unroll
-          for (int jj = 0; jj < 3; jj++)
-            if (acc[jj] && rank[jj] == rk2) v = (j == 0) ? ro[jj][0] : (j == 1 ? ro[jj][1] : ro[jj][2]);
-        }
-        R[rp(c2, lane)] = v;
-      }
-      const double dg = j == 0 ? rd[0] : (j == 1 ? rd[1] : rd[2]);
-      R[rp(lane, lane)] = dg;
-      rinv[lane] = 1.0 / dg;
-      act[lane] = mk_id(K_EQ, 0, 0, i * 3 + j + koff);
-      u[lane] = 0.0;
-    }
-    q = 3 * cnt;
-    qe = q;
-    FH_SYNC();
-    return true;
-  }
-
   // ---- dual active set from the current (dual feasible) state.
   // returns 0 optimal, 1 infeasible, 2 bounded out by `ub`, 3 iteration limit ----
   // ub: prune when the dual objective (a lower bound at every iteration) exceeds it, or reaches it if `tie` (the incumbent
@@ -999,17 +1008,18 @@ struct Solver {
     int it = 0;
     bind_assignment();
     const int q0 = q;
-    const int st = qp_loop(ub, tie, max_iters, it, cost);
+    const int st = qp_loop(fmin(ub, box_ub), tie, max_iters, it, cost);
     iters += it;
     // FP64 flop estimate of this active-set run (useful lanes only; reported as fh_result.kflops), once per node so that the
     // iteration loop carries no bookkeeping (counting per iteration cost 3 % of the throughput).  Per outer iteration (at most
-    // it + 1 of them): states / control points (3(N+1) lanes x (5N + 9), 4N lanes x 12), the row scan (3N x 6 box rows, 7 per
-    // corridor row and control point) and the row normal (4n).  Per inner iteration, with the mean number of active rows
-    // qa = (q_before + q_after) / 2: the two Gram-Schmidt sweeps (4 n qa; a re-orthogonalisation is not counted), the
-    // back-substitution (qa^2 - qe^2), the step (3n + 4 qa) and the update of the factors (n + qa).
+    // it + 1 of them): the jerks Z y (2 x 3N x K), states / control points (3(N+1) lanes x (5N + 9), 4N lanes x 12), the row scan
+    // (3N x 6 box rows, 7 per corridor row and control point) and the row normal (4 x 3N in jerk space, 2 n N to reduce it).  Per
+    // inner iteration, with the mean number of active rows qa = (q_before + q_after) / 2 and n = 3K reduced unknowns: the two
+    // Gram-Schmidt sweeps (4 n qa; a re-orthogonalisation is not counted), the back-substitution (qa^2), the step (3n + 4 qa) and
+    // the update of the factors (n + qa).
     const int qa = (q0 + q) >> 1;
-    flops += (unsigned long long)(unsigned)(it + 1) * (unsigned)(3 * (N + 1) * (5 * N + 9) + 48 * N + 18 * N + 7 * rows4 + 4 * n) +
-             (unsigned long long)(unsigned)it * (unsigned)(4 * n * qa + qa * qa - qe * qe + 4 * n + 5 * qa);
+    flops += (unsigned long long)(unsigned)(it + 1) * (unsigned)(2 * nx * K + 3 * (N + 1) * (5 * N + 9) + 48 * N + 18 * N + 7 * rows4 + 4 * nx + 2 * n * N) +
+             (unsigned long long)(unsigned)it * (unsigned)(4 * n * qa + qa * qa + 4 * n + 5 * qa);
     return st;
   }
   __device__ int qp_loop(double ub, bool tie, int max_iters, int& it, double& cost) {
@@ -1019,20 +1029,22 @@ struct Solver {
       double vp;
       {
         FH_T0();
-        if (ub < INFINITY) {  // the dual objective is a lower bound: prune against the incumbent
+        {  // the dual objective is a lower bound: prune against the incumbent, and against the jerk box — every feasible trajectory
+           // has |x|^2 <= 3N j_max^2 (setMaxConstraints :403-405), so a node whose lower bound exceeds it is infeasible.  The second
+           // test also ends the divergence of an infeasible node before a numerically dependent row (|z| ~ 1e-10 |g|) can be
+           // mistaken for an independent one and answered with a step of 1e24.  (NaN-safe: !(cost <= ub).)
           const double xl = (lane < n) ? x[lane] : 0.0;
-          cost = wave_sum(xl * xl);
-          if (cost > ub || (tie && cost == ub)) return 2;
+          cost = c0 + wave_sum(xl * xl);
+          if (!(cost <= ub) || (tie && cost == ub)) return 2;
         }
         bool cbad;
         scan(id, vp, cbad);
         FH_T1(3);
+#ifdef FH_TRACE
+        if (cbad) { trace_src = 1; trace_id = id; trace_v = vp; }
+#endif
         if (cbad) return 1;
-        if (id < 0) {
-          const double xl = (lane < n) ? x[lane] : 0.0;
-          cost = wave_sum(xl * xl);
-          return 0;
-        }
+        if (id < 0) return 0;  // optimal (cost: above)
       }
       double gg;
       { FH_T0(); gg = build_g(id); FH_T1(4); }
@@ -1043,18 +1055,19 @@ struct Solver {
         { FH_T0(); zz = project(gg, dc, zi); FH_T1(5); }
         FH_T0();
         rc = backsolve(dc);
-        const bool dependent = zz <= dep2 * gg;
+        const bool dependent = zz <= dep2 * gx2;  // relative to the row's norm in JERK space: the rounding noise of z is eps |g_x|
         double ratio = INFINITY;
-        if (lane < q && (act[lane] >> 24) != K_EQ && rc > 0) ratio = u[lane] / rc;
+        if (lane < q && rc > 0) ratio = u[lane] / rc;
         const double t1 = wave_any(ratio < INFINITY) ? wave_min(ratio) : INFINITY;  // (no blocking row in most iterations)
         const int kb = (t1 < INFINITY) ? first_lane(ratio == t1) : -1;
         if (kb < 0 && dependent) {  // infeasible: row `id` is violated and a non-negative combination of active rows
           // The certificate: a_id = sum_c rc a_c over the active rows, and the remaining violation vp > 0.  Mathematically the
           // coefficient of a row that has nothing to do with the dependence is zero; on a warm-started factorisation it is
           // rounding noise, and counting such rows would put their segments into the conflict.  A corridor row may be left out of
-          // the certificate if the proof survives without it: for every x within the jerk box (rows of every node),
-          // |sum_dropped rc (a_c.x - b_c)| <= sum_dropped |rc| |a_c| (|x_now| + sqrt(n) j_max)   (a_c.x_now = b_c on active rows),
-          // so rows with |rc| |a_c| below thr = 1e-9 vp / (q (|x_now| + sqrt(n) j_max)) together cost at most 1e-9 vp, and the
+          // the certificate if the proof survives without it: for every y whose jerks lie within the jerk box (rows of every node;
+          // |y| <= |x| <= sqrt(3N) j_max because x = xp + Z y with xp orthogonal to the range of Z),
+          // |sum_dropped rc (a_c.y - b_c)| <= sum_dropped |rc| |a_c| (|y_now| + sqrt(3N) j_max)   (a_c.y_now = b_c on active rows),
+          // so rows with |rc| |a_c| below thr = 1e-9 vp / (q (|y_now| + sqrt(3N) j_max)) together cost at most 1e-9 vp, and the
           // remaining rows still prove a violation of vp (1 - 1e-9) > feas_tol.
           const int al = lane < NVP ? act[lane] : 0;
           bool in = lane < q && rc != 0.0;
@@ -1067,15 +1080,25 @@ struct Solver {
             }
             const double xl = (lane < n) ? x[lane] : 0.0;
             const double xn = sqrt(wave_sum(xl * xl));
-            const double thr = 1e-9 * vp / ((double)q * (xn + sqrt((double)n) * jmax));
+            const double thr = 1e-9 * vp / ((double)q * (xn + sqrt((double)nx) * jmax));
             in = in && fabs(rc) * sqrt(cn) > thr;
           }
           conflict = wave_or((in && (al >> 24) == K_POLY) ? (1u << ((al >> 16) & 31)) : 0u) |
                      ((id >> 24) == K_POLY ? (1u << ((id >> 16) & 31)) : 0u);
+#ifdef FH_TRACE
+          trace_src = 2; trace_id = id; trace_v = vp;
+#endif
           return 1;
         }
         const double t2 = dependent ? INFINITY : vp / zz;
         const double t = fmin(t1, t2);
+#if defined(FH_TRACE) && FH_TRACE == 2
+        if (lane == 0 && trace) {
+          double* tr = trace + 6 * (trace_it % 32);
+          tr[0] = (double)trace_it; tr[1] = (double)(unsigned)id; tr[2] = vp; tr[3] = zz; tr[4] = gg; tr[5] = t1 < INFINITY ? -t1 : t2;
+        }
+        trace_it++;
+#endif
         if (lane < q) u[lane] -= t * rc;
         up += t;
         if (!dependent) {
@@ -1159,9 +1182,16 @@ struct Solver {
       // every face row is read once for the four control points of the segment; rows beyond the polytope re-read its last
       // row (harmless for a maximum), so that the trip count is wave-uniform and four rows are in flight
       double c[12];
+      {
+        double st[12];
 #pragma unroll
-      for (int k = 0; k < 12; k++) c[k] = CP[t * 12 + k];
-      in_flight(c);
+        for (int i = 0; i < 3; i++) { st[i] = Pc[3 * t + i]; st[3 + i] = Vc[3 * t + i]; st[6 + i] = Ac[3 * t + i]; st[9 + i] = Pc[3 * t + 3 + i]; }
+        in_flight(st);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int i = 0; i < 3; i++) c[3 * k + i] = cp_of(k, st[i], st[3 + i], st[6 + i], st[9 + i]);
+      }
       const int fl = F > 0 ? F - 1 : 0;
       const fh_face* fp = faces + f0;
       double worst = -INFINITY;
@@ -1216,6 +1246,11 @@ struct Solver {
   // that level are infeasible for the same reason and are skipped (every complete assignment below them contains one of the
   // certificates).  Infeasible subtrees hold no leaf, so the result is unchanged; mostly-infeasible trials — the refutations that
   // dominate the hardest problems — shrink 2-6x (measured on the CPU restatement first).
+#ifdef FH_TRACE
+  double* trace;
+  int trace_src, trace_id, trace_it;
+  double trace_v;
+#endif
   unsigned conflict;                   // of the node just found infeasible
   unsigned allinf;                     // bit d: every child of stack frame d tried so far was infeasible (and none was given away)
 
@@ -1711,13 +1746,9 @@ struct Solver {
         }
         FH_SYNC();
       }
-      {
-        FH_T0();
-        reset_qp();
-        const bool eq_ok = init_equalities();
-        FH_T1(1);
-        if (!eq_ok) return FH_ST_INFEASIBLE;
-      }
+      reset_qp();  // y = 0: the minimum-norm point of the final-state equalities (setup_trial)
+      qe = 0;
+      if (!eq_ok) return FH_ST_INFEASIBLE;
     } else {
       depth = 1;
       backtrack = true;
@@ -1801,6 +1832,13 @@ struct Solver {
       if (st == 3) { status_limit = FH_ST_ITER_LIMIT; break; }
       carry_inf = st == 1;
       carry = conflict;
+#if defined(FH_TRACE) && FH_TRACE == 1
+      if (lane == 0 && trace && local_nodes <= 32) {  // diagnostic builds: one record per node of an UNSOLVED single-trial problem
+        double* tr = trace + 6 * (local_nodes - 1);
+        tr[0] = (double)st + 10.0 * (double)depth; tr[1] = (double)(st == 1 ? conflict : 0u); tr[2] = (double)q + 100.0 * (double)iters;
+        tr[3] = cost; tr[4] = (double)trace_src * 1e10 + (double)(unsigned)trace_id; tr[5] = trace_v;
+      }
+#endif
       if (st == 0) {
         int bseg;
         { FH_T0(); bseg = analyze(pr); FH_T1(9); }
@@ -1872,8 +1910,8 @@ __device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
 // still being explored elsewhere (returns false: the worker that finishes the last part continues the problem).
 template <int NSEG, class PR>
 __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
-                            const fh_params& par, const ShareArgs& sa, double* __restrict__ ws, int entry, bool interrupted,
-                            fh_result& res) {
+                            const fh_params& par, const ShareArgs& sa, const double* __restrict__ basis, double* __restrict__ ws, int entry,
+                            bool interrupted, fh_result& res) {
   const int lane = sv.lane;
 #ifdef FH_SHARE_PROFILE
   const unsigned long long sp_tp__ = wall_ticks();
@@ -1898,16 +1936,34 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     res.coeff[FH_MAX_SEG - 1][8] = (double)(wall_ticks() - t00) / 100.0;
   }
 #endif
+#ifdef FH_TRACE
+  sv.trace = &res.coeff[0][0];
+  sv.trace_it = 0;
+#endif
   sv.N = pr.n_seg;
-  sv.n = 3 * pr.n_seg;
+  sv.nx = 3 * pr.n_seg;
+  sv.zc0 = pr.force_final_pos ? 3 : 2;
+  sv.K = max(pr.n_seg - sv.zc0, 0);
+  sv.n = 3 * sv.K;
   sv.P = pr.n_poly;
   sv.tol = par.feas_tol;
   sv.dep2 = par.dep_tol * par.dep_tol;
   sv.vmax = pr.v_max; sv.amax = pr.a_max; sv.jmax = pr.j_max;
+  sv.box_ub = (double)(3 * pr.n_seg) * pr.j_max * pr.j_max * (1.0 + 1e-9);
   sv.force_final = pr.force_final_pos;
   FH_SYNC();  // the previous problem of this workgroup is completely done with LDS
   if (lane < 9) sv.xfl[lane] = pr.xf[lane];
   sv.init_problem();
+  // the orthogonal basis of this N (fh_basis.hip.hpp) stays in LDS from problem to problem: reloaded only when N changes
+  const double* bt = reinterpret_cast<const double*>(sv.uniform_u64((unsigned long long)(basis + (size_t)(pr.n_seg - 1) * BT_STRIDE)));
+  if (uniform_i32(sv.tb[sv.TB_ZN]) != pr.n_seg) {
+    const int nn = pr.n_seg * pr.n_seg;
+    for (int idx = lane; idx < nn; idx += 64) {
+      const int s_ = idx / pr.n_seg;
+      sv.Zm[s_ * sv.ZS + (idx - s_ * pr.n_seg)] = bt[BT_Z + idx];
+    }
+    if (lane == 0) sv.tb[sv.TB_ZN] = pr.n_seg;
+  }
 
   // stage the corridor once: coalesced 32-B face rows HBM -> LDS, and |a_f|
   const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
@@ -1973,7 +2029,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     last_trial = !(f + pr.f_inc <= pr.f_final);
     sv.h = dt;
     if (lane == 0) sv.tb_put64(sv.TB_F, sv.f64_bits(f));  // (what a frame given away by this trial has to say about it)
-    { FH_T0(); sv.setup_trial(pr);
+    { FH_T0(); sv.setup_trial(pr, bt);
 #ifdef FH_PROFILE
       sv.prof[1] += __builtin_readcyclecounter() - t0__; sv.cnt[1] += 1;
 #endif
@@ -2030,7 +2086,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
       if (lane < sv.n) sv.bestx_r = cc_load(&R_->x[lane]);
       if (lane < NSEG) sv.bestassign[lane] = sv.unpack_byte(alo, ahi, lane);
       sv.h = dt;
-      sv.setup_trial(pr);  // the zero-jerk states of the winning step (this worker may have been exploring another trial)
+      sv.setup_trial(pr, bt);  // the y = 0 states of the winning step (this worker may have been exploring another trial)
     } else {  // no factor of the window is feasible (or the search was cut short): trials_ and dt_ of the last trial of the window
       // (a limit in the winning trial disqualifies its leaves — the sequential search would have gone on to the next factor, which
       // cannot be reconstructed here: reported as not solved.  Otherwise the status of the last trial, as the sequential loop leaves it.)
@@ -2048,6 +2104,9 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
     FH_SYNC();
     sv.compute_states();
+    FH_SYNC();
+    if (lane < sv.NXP) sv.xs[lane] = (lane < sv.nx) ? sv.xj : 0.0;  // the jerks xp + Z y
+    FH_SYNC();
   }
   // every word of the result is written by the kernel (no memset of the result buffer is needed)
   for (int idx = lane; idx < FH_MAX_SEG * 12; idx += 64) {
@@ -2055,10 +2114,13 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     double v = 0.0;
     if (solved && t < sv.N) {
       const int o = 3 * t + i;
-      v = kind == 0 ? sv.x[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
+      v = kind == 0 ? sv.xs[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
     }
 #ifdef FH_SHARE_PROFILE
     if (idx == (FH_MAX_SEG - 1) * 12 + 8) continue;  // (diagnostic: the owner's start time, written when the problem was begun)
+#endif
+#ifdef FH_TRACE
+    if (!solved) continue;
 #endif
     res.coeff[t][rem] = v;
   }
@@ -2103,6 +2165,7 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
   int n, max_faces;
   fh_params par;
   double* workspace;
+  const double* basis;  // [FH_MAX_SEG][BT_STRIDE] reduced-space basis tables (fh_basis.hip.hpp), read-only
   ShareArgs sa;
   // pair launches only (solve -> hand-off -> safe solve)
   fh_problem* safe;
@@ -2125,7 +2188,7 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
 // for the stragglers of a batch-wide whole launch before the safe solves start.  The safe problem record and its face rows are
 // written and read back through L2 inside the launch (possibly by another workgroup): agent-scope fences order the two.
 template <int NSEG, bool PAIRS>
-__global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
+__global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
                                                    fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Solver<NSEG> sv;
@@ -2133,6 +2196,7 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
   sv.lane = threadIdx.x;
   sv.q = 0;
   sv.qe = 0;
+  if (threadIdx.x == 0) sv.tb[sv.TB_ZN] = 0;
   const ShareArgs& sa = ka.sa;
   double* ws = ka.workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   if (threadIdx.x == 0) {
@@ -2199,7 +2263,7 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(phase ? &ka.safe[unit] : &problems[unit]));
         const fh_face* fcs = reinterpret_cast<const fh_face*>(sv.uniform_u64((unsigned long long)(phase ? ka.sfaces : faces)));
         fh_result* out = reinterpret_cast<fh_result*>(sv.uniform_u64((unsigned long long)(phase ? &ka.sres[unit] : &results[unit])));
-        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ws, entry, interrupted, *out);
+        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out);
       }
       else {
         // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
@@ -2207,7 +2271,7 @@ __global__ void __launch_bounds__(64, 2) solve_kernel(const fh_problem* __restri
         // compiler no longer treats `const __restrict__` global memory as unclobbered (132 vector loads instead of 28 scalar ones).
         typedef const __attribute__((address_space(4))) fh_problem const_problem;
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(problems + unit));  // (provably wave-uniform)
-        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ws, entry, interrupted,
+        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
                                                     results[unit]);
       }
       if (!finished) break;  // the unit continues in another workgroup
