@@ -230,59 +230,65 @@ __device__ inline double polish3(double c3, double c2, double c1, double c0, dou
   }
   return t;
 }
-__device__ inline double min_pos_add(double best, double v) {  // MinPositiveElement, solverGurobi_utils.hpp:19-32
-  return (v > 0 && (best == 0 || v < best)) ? v : best;
-}
-__device__ inline double min_pos_root_cubic(double c3, double c2, double c1, double c0) {
+// One candidate root per lane: lane = 3 * axis + j evaluates root j of its axis' cubic / quadratic (same arithmetic per root as
+// the CPU oracle's sequential loops; the minimum over the positive roots and the maximum over the axes do not depend on the
+// order).  The double-precision cbrt / acos / cos behind a cubic are hundreds of instructions each: done once per wavefront
+// instead of once per axis and root, they are ~4 % instead of ~25 % of a typical problem.  0: no positive root.
+__device__ inline double cubic_root_of_lane(double c3, double c2, double c1, double c0, int j) {
   const double B = c2 / c3, C = c1 / c3, D = c0 / c3;
   const double p = C - B * B / 3.0;
   const double q = 2.0 * B * B * B / 27.0 - B * C / 3.0 + D;
   const double disc = q * q / 4.0 + p * p * p / 27.0;
-  double best = 0;
+  double cand = 0;
   if (disc > 0) {
     const double sq = sqrt(disc);
     const double u = cbrt(-q / 2.0 + sq), v = cbrt(-q / 2.0 - sq);
-    best = min_pos_add(best, polish3(c3, c2, c1, c0, u + v - B / 3.0));
-    if (0.5 * sqrt(3.0) * fabs(u - v) < 1e-12) best = min_pos_add(best, -(u + v) / 2.0 - B / 3.0);
+    if (j == 0) cand = polish3(c3, c2, c1, c0, u + v - B / 3.0);
+    else if (j == 1 && 0.5 * sqrt(3.0) * fabs(u - v) < 1e-12) cand = -(u + v) / 2.0 - B / 3.0;
   } else if (p == 0) {
-    best = min_pos_add(best, -B / 3.0);
+    if (j == 0) cand = -B / 3.0;
   } else {
     const double m = 2.0 * sqrt(-p / 3.0);
     double arg = 3.0 * q / (p * m);
     arg = fmin(1.0, fmax(-1.0, arg));
     const double phi = acos(arg) / 3.0;
-    for (int j = 0; j < 3; j++)
-      best = min_pos_add(best, polish3(c3, c2, c1, c0, m * cos(phi - 2.0 * 3.14159265358979323846 * j / 3.0) - B / 3.0));
+    cand = polish3(c3, c2, c1, c0, m * cos(phi - 2.0 * 3.14159265358979323846 * (double)j / 3.0) - B / 3.0);
   }
-  return best;
+  return cand;
 }
-__device__ inline double min_pos_root_quad(double c2, double c1, double c0) {
+__device__ inline double quad_root_of_lane(double c2, double c1, double c0, int j) {
   const double disc = c1 * c1 - 4.0 * c2 * c0;
-  double best = 0;
-  if (disc < 0) {
-    if (sqrt(-disc) / fabs(2.0 * c2) < 1e-12) best = min_pos_add(best, -c1 / (2.0 * c2));
-    return best;
-  }
+  if (disc < 0) return (j == 0 && sqrt(-disc) / fabs(2.0 * c2) < 1e-12) ? -c1 / (2.0 * c2) : 0.0;
   const double s = sqrt(disc);
   const double qq = -0.5 * (c1 + (c1 >= 0 ? s : -s));
-  if (qq != 0) {
-    best = min_pos_add(best, qq / c2);
-    best = min_pos_add(best, c0 / qq);
-  }
-  return best;
+  if (qq == 0) return 0.0;
+  return j == 0 ? qq / c2 : (j == 1 ? c0 / qq : 0.0);
 }
 template <class PR>
-__device__ inline double dt_initial(const PR& pr) {
+__device__ inline double dt_initial(const PR& pr, int lane) {
+  const int ax = lane / 3, j = lane - 3 * ax;
+  const int i = ax < 3 ? ax : 2;  // (lanes beyond 8 repeat axis 2: harmless duplicates)
+  const double x0p = i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2]);
+  const double x0v = i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5]);
+  const double x0a = i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8]);
+  const double xfp = i == 0 ? pr.xf[0] : (i == 1 ? pr.xf[1] : pr.xf[2]);
+  const double dx = xfp - x0p;
+  const float tv = (float)(fabs(dx) / pr.v_max);                     // :672-674
+  const float jerk = (float)(copysign(1.0, dx) * pr.j_max);          // :679-681
+  const float a0 = (float)x0a, v0 = (float)x0v;                      // :682-687
+  const double rj = cubic_root_of_lane((double)jerk / 6.0, (double)a0 / 2.0, (double)v0, -dx, j);  // :691-713
+  const float acc = (float)(copysign(1.0, dx) * pr.a_max);           // :718-720
+  const double ra = quad_root_of_lane(0.5 * (double)acc, (double)v0, -dx, j);                       // :724-746
+  // MinPositiveElement (solverGurobi_utils.hpp:19-32) over the roots of an axis, cast to float as the reference stores them; then
+  // the maximum over the nine values
   float mx = 0.f;
-  for (int i = 0; i < 3; i++) {
-    const double dx = pr.xf[i] - pr.x0[i];
-    const float tv = (float)(fabs(dx) / pr.v_max);                     // :672-674
-    const float jerk = (float)(copysign(1.0, dx) * pr.j_max);          // :679-681
-    const float a0 = (float)pr.x0[6 + i], v0 = (float)pr.x0[3 + i];    // :682-687
-    const float tj = (float)min_pos_root_cubic((double)jerk / 6.0, (double)a0 / 2.0, (double)v0, -dx);  // :691-713
-    const float acc = (float)(copysign(1.0, dx) * pr.a_max);           // :718-720
-    const float ta = (float)min_pos_root_quad(0.5 * (double)acc, (double)v0, -dx);                      // :724-746
-    mx = fmaxf(mx, fmaxf(tv, fmaxf(ta, tj)));
+#pragma unroll
+  for (int aa = 0; aa < 3; aa++) {
+    const double bj = wave_min((i == aa && rj > 0) ? rj : INFINITY);
+    const double ba = wave_min((i == aa && ra > 0) ? ra : INFINITY);
+    const float tj = (float)(bj < INFINITY ? bj : 0.0), ta = (float)(ba < INFINITY ? ba : 0.0);
+    const float tva = (float)readlane_f64((double)tv, 3 * aa);
+    mx = fmaxf(mx, fmaxf(tva, fmaxf(ta, tj)));
   }
   double dt0 = (double)(mx / (float)pr.n_seg);  // :751  (float / int)
   if (dt0 > 10000) dt0 = 0;                     // :752-756
@@ -350,8 +356,8 @@ struct Solver {
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
   unsigned poly_ok;  // polytopes without a violated zero-normal face (such a polytope can never hold a segment)
 #ifdef FH_PROFILE
-  unsigned long long prof[14];
-  unsigned int cnt[14];
+  unsigned long long prof[16];
+  unsigned int cnt[16];
 #endif
   unsigned allowed_first, allowed_last;  // polytopes not excluded for segment 0 / N-1 by jerk-independent rows
   double h, tol, dep2;
@@ -473,6 +479,7 @@ struct Solver {
   // sum_{s<tt} c(m) x_s with m = tt-1-s and c polynomial in m: three moments S_k = sum m^k x_s carry all three states
   // (cP = h^3 (1/6 + m/2 + m^2/2), cV = h^2 (1/2 + m), cA = h); nothing per-(lane, s) to keep in registers.
   __device__ __forceinline__ void moments(double& dp, double& dv, double& da) const {
+#pragma clang fp contract(off)  // (inlined at several sites: the same roundings at each of them)
     const int tt = lane / 3, i = lane - 3 * tt;
     const int ii = lane < 3 * NT ? i : 0;
     double xr[NSEG];
@@ -499,18 +506,31 @@ struct Solver {
   // ---- per trial (step h): states for y = 0 and the inverse row norms.  bt: the basis table of this N (fh_basis.hip.hpp) ----
   template <class PR>
   __device__ void setup_trial(const PR& pr, const double* __restrict__ bt) {
+    // Inlined twice — the trial loop, and the worker that writes the result of a shared problem — and results must not depend on
+    // which copy ran: no contraction into fused multiply-adds left to the optimiser's choice per site.
+#pragma clang fp contract(off)
+    // the inverse row norms of this lane's rows at h = 1 (reduced space): requested first, used last
+    double cj_, cv_, ca_, cc_;
+    {
+      const double* C = bt + BT_C + (force_final ? BT_C_WORDS : 0);
+      const double* CJ = bt + BT_CJ + (force_final ? BT_CJ_WORDS : 0);
+      const int t = lane < nx ? lane / 3 : 0;
+      const int tc = lane < 4 * N ? (lane >> 2) : 0, k = lane & 3;
+      cj_ = CJ[t];
+      cv_ = C[W_V * BT_C_TT + t];
+      ca_ = C[W_A * BT_C_TT + t];
+      cc_ = C[(k == 3 ? W_P : k) * BT_C_TT + tc + (k == 3 ? 1 : 0)];
+    }
     double p, v, a;
-    {  // zero-jerk propagation of x0 to the start of segment tt = lane / 3 (same recurrence, step by step, as the oracle)
+    {  // zero-jerk propagation of x0 to the start of segment tt = lane / 3
       const int tt = lane / 3, i = lane - 3 * tt;
       const bool on = lane < 3 * NT;
-      p = on ? pr.x0[i] : 0.0;
-      v = on ? pr.x0[3 + i] : 0.0;
-      a = on ? pr.x0[6 + i] : 0.0;
-      for (int t = 0; t < N; t++) {
-        const double pn = p + v * h + 0.5 * a * h * h, vn = v + a * h;
-        p = (t < tt) ? pn : p;
-        v = (t < tt) ? vn : v;
-      }
+      const double p0 = on ? (i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2])) : 0.0;
+      const double v0 = on ? (i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5])) : 0.0;
+      a = on ? (i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8])) : 0.0;
+      const double T = (double)tt * h;
+      p = p0 + T * (v0 + 0.5 * T * a);
+      v = v0 + T * a;
     }
     // final-state equalities (setConstraintsXf :332-357): xp = Q[:, 0:3] (M rho), rho_j = (target_j - zero-jerk end state_j) / h^p_j
     // for the rows in the reference's order ([pos], vel, accel).  One lane per axis; M, G and the mask of dependent rows (N < 3:
@@ -570,15 +590,11 @@ struct Solver {
     }
     {  // each lane keeps the inverse norms (reduced space) of the rows it scans; they scale with h^-3 (positions), h^-2, h^-1
       const double ih = 1.0 / h;
-      const double* C = bt + BT_C + (force_final ? BT_C_WORDS : 0);
-      const double* CJ = bt + BT_CJ + (force_final ? BT_CJ_WORDS : 0);
-      const int t = lane / 3;
       const bool box = lane < nx;
-      wbj = box ? CJ[t] : 0.0;
-      wbv = box ? C[W_V * BT_C_TT + t] * (ih * ih) : 0.0;
-      wba = box ? C[W_A * BT_C_TT + t] * ih : 0.0;
-      const int tc = lane >> 2, k = lane & 3;
-      wcp = (lane < 4 * N) ? C[(k == 3 ? W_P : k) * BT_C_TT + tc + (k == 3 ? 1 : 0)] * (ih * ih * ih) : 0.0;
+      wbj = box ? cj_ : 0.0;
+      wbv = box ? cv_ * (ih * ih) : 0.0;
+      wba = box ? ca_ * ih : 0.0;
+      wcp = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
     }
     FH_SYNC();  // (xs and z are rewritten in full before they are read again)
   }
@@ -1723,7 +1739,7 @@ struct Solver {
       {
         FH_T0();
         screen_constant_rows(pr);
-        FH_T1(1);
+        FH_T1(13);
       }
       if (P > 0) {
         if (allowed_mask(0) == 0u || allowed_mask(N - 1) == 0u) return FH_ST_INFEASIBLE;
@@ -1917,7 +1933,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
   const unsigned long long sp_tp__ = wall_ticks();
 #endif
 #ifdef FH_PROFILE
-  for (int i = 0; i < 14; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
+  for (int i = 0; i < 16; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
   const unsigned long long tstart__ = __builtin_readcyclecounter();
 #endif
   if (entry == 0 && (interrupted || bad_input(pr, NSEG, max_faces))) {
@@ -2000,10 +2016,13 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
   sv.poly_ok = ~badpoly;
   FH_SYNC();
 
-  const double dt0 = dt_initial(pr);
-  const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
 #ifdef FH_PROFILE
   sv.prof[0] = __builtin_readcyclecounter() - tstart__;
+#endif
+  const double dt0 = dt_initial(pr, lane);
+  const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
+#ifdef FH_PROFILE
+  sv.prof[14] = __builtin_readcyclecounter() - tstart__ - sv.prof[0]; sv.cnt[14] = 1;
 #endif
   // entry 0: a fresh problem, from its first factor.  entry 1: a stack frame of the tree of trial tb[TB_TRIALS] - 1 taken from the
   // queue.  entry 2: the trials of the problem from number tb[TB_TRIALS] - 1 (factor tb[TB_F]) on, taken from the queue.
@@ -2042,7 +2061,13 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     const int sp_n0__ = nodes;
     if (sp_taken__ && lane == 0) { aadd(&sa.ctl->prof2[0], sp_ts__ - sp_tp__); aadd(&sa.ctl->prof2[1], 1ull); }
 #endif
+#ifdef FH_PROFILE
+    const unsigned long long ts0__ = __builtin_readcyclecounter();
+#endif
     const int st = sv.search(pr, par, sa, ws, entry == 1 ? 1 : 0, best, nodes, iters);
+#ifdef FH_PROFILE
+    sv.prof[15] += __builtin_readcyclecounter() - ts0__; sv.cnt[15] += 1;
+#endif
 #ifdef FH_SHARE_PROFILE
     if (sp_taken__ && lane == 0) { aadd(&sa.ctl->prof2[2], wall_ticks() - sp_ts__); aadd(&sa.ctl->prof2[3], (unsigned long long)(nodes - sp_n0__)); }
 #endif
@@ -2134,6 +2159,13 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     unsigned int cv = 0;
     for (int i = 0; i < 12; i++) cv = (i == lane) ? sv.cnt[i] : cv;
     res.coeff[FH_MAX_SEG - 2][lane] = (double)cv;
+    if (lane < 4) {  // slots 12..15 (12: the whole problem, 13: screening, 14: dt_initial)
+      unsigned long long pw = 0;
+      unsigned int cw = 0;
+      for (int i = 0; i < 4; i++) { pw = (i == lane) ? sv.prof[12 + i] : pw; cw = (i == lane) ? sv.cnt[12 + i] : cw; }
+      res.coeff[FH_MAX_SEG - 3][lane] = (double)pw;
+      res.coeff[FH_MAX_SEG - 3][4 + lane] = (double)cw;
+    }
   }
 #endif
 #ifdef FH_SHARE_PROFILE
