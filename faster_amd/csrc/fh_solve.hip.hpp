@@ -427,6 +427,7 @@ struct Solver {
     }
   }
   __device__ void snapshot_save(double* __restrict__ ws_level) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     FH_SYNC();
     copy_out(ws_level, x, SNAP_TAIL);
     copy_out(ws_level + SNAP_QOFF, Q, q * S);
@@ -434,6 +435,7 @@ struct Solver {
   }
   // q_saved: number of active rows in the snapshot; the current q may be larger (columns to clear) or smaller
   __device__ void snapshot_restore(const double* __restrict__ ws_level, int q_saved) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     // the workspace was written by this same wavefront (snapshot_save of an ancestor node): drain its outstanding stores
     // before reading them back
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -467,6 +469,7 @@ struct Solver {
   // Invariant kept by reset_qp/add_row/drop_row: Q[i][c] == 0 for i >= n or c >= q, and g, d, z, x are zero
   // beyond n (resp. q), so that the factor sweeps below can run in unpredicated blocks of 8.
   __device__ void init_problem() {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     for (int i = lane; i < NVP * S; i += 64) Q[i] = 0.0;
     for (int i = lane; i < RPSZ; i += 64) R[i] = 0.0;
     if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
@@ -480,6 +483,7 @@ struct Solver {
   // (cP = h^3 (1/6 + m/2 + m^2/2), cV = h^2 (1/2 + m), cA = h); nothing per-(lane, s) to keep in registers.
   __device__ __forceinline__ void moments(double& dp, double& dv, double& da) const {
 #pragma clang fp contract(off)  // (inlined at several sites: the same roundings at each of them)
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const int tt = lane / 3, i = lane - 3 * tt;
     const int ii = lane < 3 * NT ? i : 0;
     double xr[NSEG];
@@ -509,6 +513,7 @@ struct Solver {
     // Inlined twice — the trial loop, and the worker that writes the result of a shared problem — and results must not depend on
     // which copy ran: no contraction into fused multiply-adds left to the optimiser's choice per site.
 #pragma clang fp contract(off)
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     // the inverse row norms of this lane's rows at h = 1 (reduced space): requested first, used last
     double cj_, cv_, ca_, cc_;
     {
@@ -608,6 +613,7 @@ struct Solver {
 
   // ---- jerks x = xp + Z y, states at segment starts and Bezier control points of the current y ----
   __device__ void compute_states() {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     {  // lane = (s, i): (Z y)_(s,i) = sum_k Zm[s][zc0 + k] y[3 k + i]
       const int s = lane / 3, i = lane - 3 * s;
       const bool on = lane < nx;
@@ -654,6 +660,7 @@ struct Solver {
 
   // assign[] only changes between two active-set runs: the scan lanes look their rows up once per run
   __device__ void bind_assignment() {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const bool live = lane < 4 * N;
     const int p = live ? assign[lane >> 2] : -1;
     scan_f0 = p >= 0 ? face_off[p] : 0;
@@ -675,6 +682,7 @@ struct Solver {
   // segment's polytope (4 lanes share each face read).  Sets const_bad if a jerk-independent row (segment 0,
   // control points 0..2) is violated.
   __device__ void scan(int& id_out, double& v_out, bool& const_bad) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     double bs = 0, bv = 0;
     int bid = -1;
     bool bad = false;
@@ -742,6 +750,7 @@ struct Solver {
 
   // ---- normal of row `id` in the reduced space: g = (Z (x) I3)^T (normal in jerk space), lane = (k, i).  returns |g|^2 ----
   __device__ double build_g(int id) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const int kind = id >> 24, t = (id >> 16) & 255, k = (id >> 8) & 255, f = id & 255;
     double gv = 0;
     const int kk = lane / 3, ia = lane - 3 * kk;
@@ -833,6 +842,7 @@ struct Solver {
   // rounded up to 16, which stays inside the zero padding.)
   static constexpr int SPLIT_U = (NVP % 16 == 0) ? 8 : 4;
   __device__ __forceinline__ double col_dot2(const double* __restrict__ M, int col, const double* __restrict__ v, int n8) const {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const int hh = (lane >> 5) * 4;
     const double* Mc = M + hh * S + col;
     const double* vv = v + hh;
@@ -855,6 +865,7 @@ struct Solver {
     return halves_sum(a0 + a1);
   }
   __device__ __forceinline__ double row_dot2(const double* __restrict__ M, int row, const double* __restrict__ v, int q8) const {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const int hh = (lane >> 5) * 4;
     const double* Mr = M + row * S + hh;
     const double* vv = v + hh;
@@ -880,6 +891,7 @@ struct Solver {
   // ---- z = (I - Q1 Q1^T) g, d = Q1^T g (lane c holds d_c, lane i holds z_i). Re-orthogonalises when the first
   // pass cancels more than half of |g|^2 (Daniel-Gragg-Kaufman-Stewart).  returns |z|^2 ----
   __device__ double project(double gg, double& dc, double& zi) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const int n8 = (n + 7) & ~7, q8 = (q + 7) & ~7;
     if constexpr (NVP <= 32) {
       const int l5 = lane & 31;
@@ -930,6 +942,7 @@ struct Solver {
   // R_lc / R_ll do not depend on the recurrence and are prepared four columns ahead.
   // (qe = 0: the final-state equalities are eliminated, every column is an inequality row.)
   __device__ double backsolve(double dc) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const int ll = lane < NVP ? lane : NVP - 1;
     const double ri = (lane < q && lane >= qe) ? rinv[lane] : 0.0;
     double dh = dc * ri;
@@ -951,6 +964,7 @@ struct Solver {
   }
 
   __device__ void add_row(int id, double zi, double zz, double dc, double up) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     const double rho = sqrt(zz);
     const double inv = 1.0 / rho;
     if (lane < n) Q[q * S + lane] = zi * inv;
@@ -966,6 +980,7 @@ struct Solver {
   }
 
   __device__ void drop_row(int kpos) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     // shift the bookkeeping and the columns of R left
     int a_next = 0;
     double u_next = 0;
@@ -1008,6 +1023,7 @@ struct Solver {
   }
 
   __device__ void reset_qp() {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     if (lane < NVP) {
       for (int c = 0; c < q; c++) Q[c * S + lane] = 0.0;  // columns >= q are zero already
       x[lane] = 0;
@@ -1146,6 +1162,7 @@ struct Solver {
   // 1..3 of the last segment depend on xf and h only.  One lane per polytope. ----
   template <class PR>
   __device__ void screen_constant_rows(const PR& pr) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     allowed_first = allowed_last = 0xffffffffu;
     if (P == 0) return;
     // one lane per face row (all polytopes side by side), six wave-uniform points per row; a violated row marks its polytope
@@ -1184,6 +1201,7 @@ struct Solver {
   // ---- leaf test / branching choice for the node just solved. returns branch segment or -1 (leaf) ----
   template <class PR>
   __device__ int analyze(const PR& pr) {
+    const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     if (P == 0) {
       if (lane < N) fullassign[lane] = -1;
       FH_SYNC();
