@@ -1887,22 +1887,27 @@ struct Solver {
           }
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
           { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED); FH_T1(10); }  // the children inherit this node's factorisation
-          if (lane == 0) {
-            signed char* ord = &stk_order[depth * FH_MAX_POLY];
-            const unsigned am = allowed_mask(bseg);
-            int cnt = 0;
-            for (int p = 0; p < P; p++)
-              if ((am >> p) & 1u) ord[cnt++] = (signed char)p;
-            stk_cnt[depth] = cnt;
-            for (int a = 1; a < cnt; a++)
-              for (int b = a; b > 0 && viol[bseg * FH_MAX_POLY + ord[b]] < viol[bseg * FH_MAX_POLY + ord[b - 1]]; b--) {
-                const signed char tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp;
-              }
-            stk_seg[depth] = bseg;
-            stk_q[depth] = q;
-            stk_next[depth] = 1;
-            stk_mask[depth] = 0;
-            assign[bseg] = ord[0];
+          {  // child order: candidates sorted by how far the segment is outside each (ascending, ties by polytope index — the order
+             // a stable insertion sort gives), by counting: lane p ranks polytope p among the candidates, no serial loop over LDS
+            const unsigned am = allowed_mask(bseg) & (P ? ((1u << P) - 1u) : 0u);
+            const bool cand = lane < FH_MAX_POLY && ((am >> lane) & 1u);
+            const double key = viol[bseg * FH_MAX_POLY + (lane < FH_MAX_POLY ? lane : 0)];
+            int rank = 0;
+            for (int p2 = 0; p2 < P; p2++) {
+              const double k2 = readlane_f64(key, p2);
+              rank += (((am >> p2) & 1u) && (k2 < key || (k2 == key && p2 < lane))) ? 1 : 0;
+            }
+            if (cand) {
+              stk_order[depth * FH_MAX_POLY + rank] = (signed char)lane;
+              if (rank == 0) assign[bseg] = lane;
+            }
+            if (lane == 0) {
+              stk_cnt[depth] = __builtin_popcount(am);
+              stk_seg[depth] = bseg;
+              stk_q[depth] = q;
+              stk_next[depth] = 1;
+              stk_mask[depth] = 0;
+            }
           }
           allinf |= 1u << depth;
           depth++;
