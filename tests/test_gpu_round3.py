@@ -1,0 +1,148 @@
+"""GPU tests added in round 3 (all through the C ABI): the kernel instantiations and batch sizes that the bench measures but the
+earlier tests did not compare with the oracle — fused whole+safe pairs at N = 15 (`solve_kernel<15, true>`, the C5 kernel),
+N = 16 and N = 6, on synthetic AND forest corridors from the device front-end; BASELINE config C3 at its full 4096; a 4096-pair
+subsample of the full 65536-pair C5 batch; and the independent models (SciPy on the reference's unreduced 12N-coefficient
+model) applied to 64 GPU results at N = 10."""
+import numpy as np
+import pytest
+
+from faster_amd import abi, capi, corridor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch  # noqa: F401  (torch first: one HIP runtime in the process)
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def compare(got, ref, cost_rtol=1e-7, coeff_atol=1e-6):
+    assert np.array_equal(got["solved"], ref["solved"]), np.nonzero(got["solved"] != ref["solved"])
+    assert np.array_equal(got["trials"], ref["trials"]), np.nonzero(got["trials"] != ref["trials"])
+    assert np.array_equal(got["factor"], ref["factor"]) and np.array_equal(got["dt"], ref["dt"])
+    assert np.array_equal(got["status"], ref["status"])
+    ok = ref["solved"] == 1
+    np.testing.assert_allclose(got["cost"][ok], ref["cost"][ok], rtol=cost_rtol, atol=1e-9)
+    np.testing.assert_allclose(got["coeff"][ok], ref["coeff"][ok], rtol=0, atol=coeff_atol)
+    return ok
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")
+
+
+def fused_pairs(ctx, whole, faces, tmpl, max_seg, margin):
+    """One fused launch (whole -> hand-off -> safe per pair); returns host views of everything the device wrote."""
+    import torch
+
+    B = len(whole)
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    ctx.set_pair_margin(margin)
+    d_whole, d_faces, d_safe = _dev(whole), _dev(faces), _dev(tmpl)
+    d_sf = torch.zeros_like(d_faces)
+    d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_sr = torch.zeros_like(d_wr)
+    ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, max_seg, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(),
+                           d_sf.data_ptr(), d_sr.data_ptr())
+    ctx.sync()
+    ctx.set_pair_margin(-1.0)
+    return (d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype),
+            d_safe.cpu().numpy().view(abi.problem_dtype), d_sf.cpu().numpy().view(abi.face_dtype))
+
+
+def check_pairs_against_oracle(ctx, oracle, whole, faces, max_seg, idx, margin=0.05, n_safe=None):
+    """The pairs `idx` of a fused launch over the whole batch: whole results, hand-off records (against oracle/pair_glue.py driven by
+    the ORACLE's whole results) and the safe results (the device-written safe problems solved by the oracle)."""
+    from oracle import pair_glue
+
+    tmpl = corridor.safe_templates(whole)
+    wres, sres, safe, sfaces = fused_pairs(ctx, whole, faces, tmpl, max_seg, margin)
+    wref = oracle.solve_batch(whole[idx], faces)
+    compare(wres[idx], wref)
+    safe_ref, _ = pair_glue.glue(whole[idx], wref, faces, tmpl[idx], 0.5, 0.2, 3, r_margin=margin)
+    assert np.array_equal(safe["n_seg"][idx], safe_ref["n_seg"]) and np.array_equal(safe["n_poly"][idx], safe_ref["n_poly"])
+    np.testing.assert_allclose(safe["x0"][idx], safe_ref["x0"], rtol=0, atol=1e-9)
+    live = np.nonzero(safe_ref["n_seg"] > 0)[0]
+    if n_safe is not None:
+        live = live[:n_safe]
+    sref = oracle.solve_batch(safe[idx][live], sfaces)
+    oks = compare(sres[idx][live], sref)
+    return wref, oks
+
+
+@pytest.mark.parametrize("n_seg,p_choices,B", [(15, (4, 5, 6, 7, 8), 768), (16, (6, 7, 8), 192), (6, (1, 2, 3), 1024), (12, (3, 5), 256)])
+def test_fused_pairs_against_oracle_synthetic(ctx, oracle, n_seg, p_choices, B):
+    """solve_kernel<15, true> (the C5 kernel), <16, true>, <6, true> and a size in between: every pair against the oracle."""
+    whole, faces, _ = corridor.whole_batch(B, seed=300 + n_seg, n_seg=n_seg, p_choices=p_choices)
+    wref, oks = check_pairs_against_oracle(ctx, oracle, whole, faces, n_seg, np.arange(B))
+    assert wref["solved"].mean() > 0.9 and oks.mean() > 0.4
+
+
+def test_fused_pairs_against_oracle_forest_corridors(ctx, oracle):
+    """Fused pairs at N = 15 on corridors produced by the DEVICE front-end (fh_map_* + fh_corridor_batch_device) in a random forest
+    (BASELINE config 5's input distribution), and at N = 10 on the same kind of corridors with at most 6 polytopes."""
+    from faster_amd import frontend
+
+    vmap = capi.Map(0)
+    try:
+        for n_seg, max_poly, seed in ((15, 8, 51), (10, 6, 52)):
+            whole, faces, info = frontend.forest_batch(640, seed=seed, n_seg=n_seg, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap)
+            assert len(whole) > 500 and info["no_path"] < 100
+            wref, oks = check_pairs_against_oracle(ctx, oracle, whole, faces, n_seg, np.arange(len(whole)))
+            assert wref["solved"].mean() > 0.8
+    finally:
+        vmap.close()
+
+
+def test_config_c3_full_size_against_oracle(ctx, oracle):
+    """BASELINE config C3 at its full size: 4096 whole-trajectory MIQPs, N = 10, <= 4 polytopes, every problem against the oracle."""
+    pr, faces, _ = corridor.whole_batch(4096, seed=2, n_seg=10, p_choices=(2, 3, 4))
+    got = ctx.solve_batch(pr, faces)
+    ok = compare(got, oracle.solve_batch(pr, faces))
+    assert ok.mean() > 0.95
+
+
+def test_config_c5_full_size_subsample_against_oracle(ctx, oracle):
+    """BASELINE config C5 at its full size: 65536 start/goal pairs in one random forest, corridors from the device front-end, N = 15,
+    <= 8 polytopes, ONE fused launch over all of them (bench.py --workload c5); a random 4096-pair subsample — whole results,
+    hand-off records, and the safe results of its first 2048 live pairs — against the oracle."""
+    from faster_amd import frontend
+
+    vmap = capi.Map(0)
+    try:
+        whole, faces, info = frontend.forest_batch(65536, seed=5, n_seg=15, max_poly=8, front="device", ctx=ctx, vmap=vmap)
+    finally:
+        vmap.close()
+    assert len(whole) > 60000
+    idx = np.sort(np.random.default_rng(7).choice(len(whole), 4096, replace=False))
+    wref, oks = check_pairs_against_oracle(ctx, oracle, whole, faces, 15, idx, n_safe=2048)
+    assert wref["solved"].mean() > 0.8
+
+
+def test_independent_model_on_64_gpu_results_at_n10(ctx):
+    """SciPy SLSQP on the reference's own unreduced 12N-coefficient model (oracle/py_model.py: rows written one by one as
+    solverGurobi.cpp adds them — no jerk space, no reduced space, no active-set code shared with the kernel) under the GPU's
+    assignment, for 64 solved C4-sized problems (N = 10, <= 6 polytopes): same cost (1e-6) and the same polynomial (1e-5)."""
+    from oracle import py_model
+
+    pr, faces, _ = corridor.whole_batch(96, seed=401, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    res = ctx.solve_batch(pr, faces)
+    done = 0
+    for i in np.nonzero(res["solved"])[0][:64]:
+        p, r = pr[i], res[i]
+        fb = int(p["face_begin"])
+        polys = [(faces["a"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy(), faces["b"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy())
+                 for q in range(int(p["n_poly"]))]
+        s = py_model.solve_fixed(10, float(r["dt"]), p["x0"], p["xf"], float(p["v_max"]), float(p["a_max"]), float(p["j_max"]), True, polys,
+                                 [int(a) for a in r["assign"][:10]])
+        assert s is not None, i
+        assert s[0] == pytest.approx(r["cost"], rel=1e-6, abs=1e-7), (i, s[0], r["cost"])
+        np.testing.assert_allclose(s[1], r["coeff"][:10], atol=1e-5)
+        done += 1
+    assert done == 64
