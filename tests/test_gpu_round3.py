@@ -146,3 +146,78 @@ def test_independent_model_on_64_gpu_results_at_n10(ctx):
         np.testing.assert_allclose(s[1], r["coeff"][:10], atol=1e-5)
         done += 1
     assert done == 64
+
+
+# ---- row N1 on the device against the reference's OWN sources (oracle/_ref/libref_frontend.so: untouched DecompUtil / jps3d behind
+# test-only shims, oracle/ref_frontend/; built in the development container, travels with the snapshot) ----
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_frontend import ref as r
+
+    if r.build() is None:
+        pytest.skip("oracle/_ref/libref_frontend.so is not available")
+    return r
+
+
+def test_device_decomposition_against_the_reference_sources(ctx, ref):
+    """fh_decompose_batch (K4) against the reference's EllipsoidDecomp3D / LineSegment / DecompBase themselves, driven as
+    JPS_Manager::cvxEllipsoidDecomp drives them: same polytopes as sets of rows (1e-9) on the reference's own test path and on
+    random scenes — 40+ polytopes."""
+    key = lambda M: M[np.lexsort(np.round(M, 6).T[::-1])]
+    total = 0
+    scenes = [(np.array([[5, 11.5, 0.5], [13, 11.5, 3.0], [14, 10.5, 1.5], [14, 5, 2.5]]), 1, 4000, 0.5)]   # decomp_test_node/data/path3d.txt
+    rng0 = np.random.default_rng(17)
+    for k in range(10):
+        path = np.cumsum(np.vstack([rng0.uniform(-3, 3, 3) * [1, 1, 0] + [0, 0, 1.2], rng0.uniform(0.8, 2.5, (4, 1)) * (rng0.normal(size=(4, 3)) * [1, 1, 0.2])]), axis=0)
+        path[:, 2] = np.clip(path[:, 2], 0.6, 2.4)
+        scenes.append((path, 100 + k, 1500, 0.4))
+    for path, seed, n_cloud, clearance in scenes:
+        rng = np.random.default_rng(seed)
+        cloud = rng.uniform(path.min(0) - 2.5, path.max(0) + 2.5, size=(n_cloud, 3))
+        keep = np.ones(len(cloud), bool)
+        for a, b in zip(path[:-1], path[1:]):
+            t = np.clip(((cloud - a) @ (b - a)) / ((b - a) @ (b - a)), 0, 1)
+            keep &= np.linalg.norm(cloud - (a + t[:, None] * (b - a)), axis=1) > clearance
+        cloud = cloud[keep]
+        segs = np.hstack([path[:-1], path[1:]])
+        faces, counts = ctx.decompose_batch(cloud, segs, drone_radius=0.05, z_ground=0.0, max_faces=96)
+        want = ref.decompose(path, cloud, 0.05, 0.0)
+        for i, (A, b) in enumerate(want):
+            assert counts[i] == len(b), (seed, i, counts[i], len(b))
+            got = np.column_stack([faces["a"][i, :counts[i]], faces["b"][i, :counts[i]]])
+            np.testing.assert_allclose(key(got), key(np.column_stack([A, b])), rtol=0, atol=1e-9)
+            total += 1
+    assert total >= 40
+
+
+def test_device_map_and_path_search_against_the_reference_sources(ctx, ref):
+    """fh_map_read against MapUtil::readMap itself (dimensions, origin, every cell), and fh_map_plan_batch against jps3d driven as
+    JPS_Manager::solveJPS3D drives it: a path exists for the same queries, it starts and ends on the same points; the share of
+    identical vertex lists is reported (jump point search and this A* return different equal-cost paths for most queries)."""
+    from faster_amd import frontend
+
+    cloud, cells, center, starts, goals = frontend.forest_queries(192, 3)
+    cloud = cloud.astype(np.float32).astype(np.float64)   # pcl::PointXYZ holds floats
+    res, zg, zmax, infl = 0.2, 0.0, 3.0, 0.3
+    rm = ref.Map(cloud, cells, res, center, zg, zmax, infl)
+    dm = capi.Map(0)
+    try:
+        dm.read(cloud, cells, res, center, zg, zmax, infl)
+        occ = dm.occupancy()
+        assert occ.shape == rm.occupancy().shape and np.array_equal(occ > 0, rm.occupancy() > 0)
+        dp, dn, _ = dm.plan_batch(starts, goals)
+    finally:
+        dm.close()
+    same = with_path = 0
+    for i in range(len(starts)):
+        p, cost, _ = rm.plan(starts[i], goals[i], True)
+        assert (p is None) == (dn[i] == 0), i
+        if p is None:
+            continue
+        with_path += 1
+        d = dp[i, :dn[i]]
+        np.testing.assert_allclose(d[0], p[0], atol=1e-12)
+        np.testing.assert_allclose(d[-1], p[-1], atol=1e-12)
+        same += int(len(d) == len(p) and np.allclose(d, p, atol=1e-9))
+    rm.close()
+    assert with_path >= 180 and same >= with_path // 10
