@@ -69,6 +69,17 @@ assert state_dtype.itemsize == 96
 assert params_dtype.itemsize == 48
 
 
+sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("backlog", "<i4"), ("waiting_workgroups", "<i4"),
+                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("reserved", "<i4", (2,))])
+assert sched_dtype.itemsize == 32
+
+
+def default_sched():
+    s = np.zeros((), dtype=sched_dtype)
+    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"] = 1, 4, 32, 16, 1
+    return s
+
+
 def default_params():
     p = np.zeros((), dtype=params_dtype)
     p["feas_tol"] = 1e-9

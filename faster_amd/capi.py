@@ -14,13 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))  # override: diagnostic builds only
 
 SYMBOLS = [
-    "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_set_stream",
+    "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
     "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
-    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_sync", "fh_map_read", "fh_map_read_device",
+    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
 ]
@@ -52,6 +52,12 @@ def lib():
         L.fh_set_params.argtypes = [vp, vp]
         L.fh_set_stream.restype = i32
         L.fh_set_stream.argtypes = [vp, vp]
+        L.fh_default_sched.restype = None
+        L.fh_default_sched.argtypes = [vp]
+        L.fh_set_sched.restype = i32
+        L.fh_set_sched.argtypes = [vp, vp]
+        L.fh_map_set_sched.restype = i32
+        L.fh_map_set_sched.argtypes = [vp, i32, i32]
         L.fh_set_pair_margin.restype = i32
         L.fh_set_pair_margin.argtypes = [vp, f64]
         L.fh_request_stop.restype = i32
@@ -301,6 +307,15 @@ class Context:
 
     def set_stream(self, stream_ptr):
         self._check(lib().fh_set_stream(self._h, ctypes.c_void_p(stream_ptr)), "fh_set_stream")
+
+    def set_sched(self, **kw):
+        """fh_set_sched: scheduling of a solve launch (launch_order, publish_factor, backlog, waiting_workgroups, min_nodes,
+        cloud_blocks); unnamed fields keep their defaults.  No result field depends on them."""
+        s = abi.default_sched()
+        for k, v in kw.items():
+            s[k] = v
+        s = np.ascontiguousarray(s).reshape(1)
+        self._check(lib().fh_set_sched(self._h, abi.ptr(s)), "fh_set_sched")
 
     def sync(self):
         self._check(lib().fh_sync(self._h), "fh_sync")

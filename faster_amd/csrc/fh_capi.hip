@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,7 @@ struct fh_ctx {
   std::vector<hipEvent_t> ev;  // pairs (start, stop), one pair per solve-kernel launch
   size_t ev_used = 0;          // events in use since the last fh_timing_reset
   fh_params par;
+  fh_sched sched;
   std::string err;
   // staging buffers of the host-pointer entry points (grown on demand, reused)
   // slot 5: snapshot workspace, 6: work-sharing control block + ring sequence numbers, 7: decomposition workspace,
@@ -98,8 +100,7 @@ template <int NSEG, bool PAIRS>
 static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, fh_result* d_results, fh::SolveArgs ka) {
   using SV = fh::Solver<NSEG>;
   const int n = ka.n;
-  size_t lds = SV::lds_bytes(ka.max_faces);
-  if (const char* pad = getenv("FH_DEBUG_LDS_PAD")) lds += (size_t)atoi(pad);  // occupancy experiments only
+  const size_t lds = SV::lds_bytes(ka.max_faces);
   auto kern = fh::solve_kernel<NSEG, PAIRS>;
   // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU)
   int per_cu = (int)std::min<size_t>(FH_WAVES_PER_SIMD * 4, (160 * 1024) / lds);
@@ -128,22 +129,17 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // Waiting workgroups.  Measured on C4 (32768 pairs per launch): 16 of them shorten a launch as much as 64 or 512 do (the tail is
   // bound by its critical path — the sequential factor trials of the hardest problem — not by hands), and every waiter holds
   // LDS that another launch of the same device could use (12 launches in flight: 7.4 M pairs/s with 16, 7.0 M with 64, 5.9 M with 256).
-  sa.max_hungry = std::max(8, ctx->n_cu / 16);
-  sa.min_nodes = 16;
+  sa.max_hungry = ctx->sched.waiting_workgroups > 0 ? ctx->sched.waiting_workgroups : std::max(8, ctx->n_cu / 16);
+  sa.min_nodes = ctx->sched.min_nodes;
   // Frames published AHEAD of the takers (served by workgroups between two problems).  What a launch ends on are problems with
   // 1200-4300 active-set iterations (C4: ~140 of 32768 pairs, mostly safe problems that are infeasible for all ten factors) that
   // started early and ran on ONE wavefront until the fresh problems were exhausted.  A problem that has used 4x the mean number of
   // iterations of the units finished so far may therefore publish up to 32 frames / trial ranges ahead: one launch alone 6.7 -> 6.1 ms,
   // 8 in flight -1 %.
   // (Publishing ahead from every problem with 64 nodes cost 13-25 % at any number of launches in flight: hop overhead in the bulk.)
-  sa.backlog = 32;
+  sa.backlog = ctx->sched.backlog;
   sa.giant_nodes = 1 << 30;
-  sa.giant_factor = 4;
-  if (const char* gi = getenv("FH_DEBUG_GIANT_FACTOR")) sa.giant_factor = atoi(gi);
-  if (const char* bl = getenv("FH_DEBUG_BACKLOG")) sa.backlog = atoi(bl);
-  if (const char* gn = getenv("FH_DEBUG_GIANT")) sa.giant_nodes = atoi(gn);
-  if (const char* mh = getenv("FH_DEBUG_MAX_HUNGRY")) sa.max_hungry = atoi(mh);  // experiments only
-  if (const char* mn = getenv("FH_DEBUG_MIN_NODES")) sa.min_nodes = atoi(mn);
+  sa.giant_factor = ctx->sched.publish_factor;
   ka.par = ctx->par;
   ka.workspace = (double*)ctx->d_buf[5];
   ka.basis = (const double*)ctx->d_buf[15];
@@ -170,7 +166,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   ctx->ctl_ready = false;  // (true again once the launch below has been issued: it resets the block when it ends)
   // big batches are started hardest corridors first (order_kernel); results do not depend on the order
   ka.order = nullptr;
-  if (n >= 2048 && !getenv("FH_DEBUG_NO_ORDER")) {
+  if (n >= 2048 && ctx->sched.launch_order) {
     const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 64) || !ctx->order_ready;
     ctx->order_ready = false;  // (true again once all three launches below have been issued: a failed launch must not leave dirty counters behind)
     if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 64))) != FH_OK) return rc;
@@ -213,6 +209,24 @@ extern "C" {
 
 const char* fh_version(void) { return "fasterhip 0.2 gfx950"; }
 
+void fh_default_sched(fh_sched* s) {
+  if (!s) return;
+  std::memset(s, 0, sizeof(*s));
+  s->launch_order = 1;
+  s->publish_factor = 4;
+  s->backlog = 32;
+  s->waiting_workgroups = 0;
+  s->min_nodes = 16;
+  s->cloud_blocks = 1;
+}
+
+int fh_set_sched(fh_ctx* ctx, const fh_sched* s) {
+  if (!ctx || !s) return FH_ERR_ARG;
+  if (s->publish_factor < 0 || s->backlog < 0 || s->backlog > 512 || s->waiting_workgroups < 0 || s->min_nodes < 0) return FH_ERR_ARG;
+  ctx->sched = *s;
+  return FH_OK;
+}
+
 void fh_default_params(fh_params* p) {
   if (!p) return;
   p->feas_tol = 1e-9;
@@ -231,6 +245,7 @@ int fh_create(fh_ctx** out, int device) {
   fh_ctx* ctx = new (std::nothrow) fh_ctx();
   if (!ctx) return FH_ERR_NOMEM;
   fh_default_params(&ctx->par);
+  fh_default_sched(&ctx->sched);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -488,7 +503,36 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
   std::vector<fh_problem> sub;
   std::vector<int> owner;
   std::vector<fh_result> sub_res;
+  // ONE wall-clock budget for the whole search (fh_params.deadline_ms), not one per window of factors
+  const double deadline_ms = ctx->par.deadline_ms;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto end_search = [&](int i, const fh_result* last, int status) {  // the search of problem i stops here, not solved
+    Search& s = search[(size_t)i];
+    fh_result& out = results[i];
+    if (last) out = *last;
+    else std::memset(&out, 0, sizeof(out));
+    out.solved = 0;
+    out.status = status;
+    out.trials = (int32_t)s.next;
+    out.nodes = (int32_t)s.nodes;
+    out.qp_iters = (int32_t)s.iters;
+    out.kflops = (int32_t)std::min<long long>(s.kflops, 0x7fffffffLL);
+    out.factor = 0.0;
+    out.cost = 0.0;
+    std::memset(out.coeff, 0, sizeof(out.coeff));
+    for (int t = 0; t < FH_MAX_SEG; t++) out.assign[t] = -1;
+    s.done = true;
+  };
   for (;;) {
+    if (deadline_ms > 0) {  // what is left of the budget goes to the next window; nothing left: the open searches end interrupted
+      const double used = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+      if (used >= deadline_ms) {
+        for (int i = 0; i < n; i++)
+          if (!search[(size_t)i].done) end_search(i, nullptr, FH_ST_INTERRUPTED);
+        break;
+      }
+      ctx->par.deadline_ms = deadline_ms - used;
+    }
     sub.clear();
     owner.clear();
     for (int i = 0; i < n; i++) {
@@ -506,6 +550,7 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
     if (sub.empty()) break;
     sub_res.resize(sub.size());
     const int rc = fh_solve_batch(ctx, sub.data(), faces, n_faces, (int)sub.size(), sub_res.data());
+    ctx->par.deadline_ms = deadline_ms;
     if (rc != FH_OK) return rc;
     for (size_t a = 0; a < sub.size();) {
       const int i = owner[a];
@@ -523,7 +568,9 @@ int fh_solve_batch_speculative(fh_ctx* ctx, const fh_problem* problems, const fh
           s.kflops += r.kflops;
           s.next++;
           const bool last = s.next == s.factors.size();
-          if (r.solved || r.status == FH_ST_BAD_INPUT || last) {
+          if (r.status == FH_ST_INTERRUPTED) {  // stop request or deadline: terminal, as GRB_INTERRUPTED ends genNewTraj's loop
+            end_search(i, &r, FH_ST_INTERRUPTED);   // (a later factor of the window must not be returned as "the first feasible one")
+          } else if (r.solved || r.status == FH_ST_BAD_INPUT || last) {
             results[i] = r;
             results[i].trials = r.status == FH_ST_BAD_INPUT ? 0 : (int32_t)s.next;
             results[i].nodes = (int32_t)s.nodes;
@@ -650,7 +697,7 @@ int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_clou
   // bounding boxes of the blocks of 64 cloud points: most blocks cannot touch a segment's local box and are skipped (same results)
   double* d_blocks = nullptr;
   const int n_blocks = (n_cloud + 63) / 64;
-  if (n_blocks >= 8 && !getenv("FH_DEBUG_NO_CLOUD_BLOCKS")) {
+  if (n_blocks >= 8 && ctx->sched.cloud_blocks) {
     if ((rc = ensure(ctx, 14, sizeof(double) * 6 * (size_t)n_blocks)) != FH_OK) return rc;
     d_blocks = (double*)ctx->d_buf[14];
     hipLaunchKernelGGL(fh::cloud_blocks_kernel, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, d_cloud_xyz, n_cloud, d_blocks);

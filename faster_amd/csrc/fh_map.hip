@@ -33,6 +33,7 @@ struct fh_map {
   unsigned* d_chunks = nullptr;
   unsigned* d_serials = nullptr;
   int* d_ticket = nullptr;
+  int sched_waves_per_cu = 12, sched_launch_order = 1;  // fh_map_set_sched
   int* d_order = nullptr;  // 128 counters + launch order
   size_t order_cap = 0;
   // staging of the host-pointer entry points
@@ -79,8 +80,7 @@ int stage(fh_map* m, int slot, size_t bytes) {
 int ensure_workspace(fh_map* m) {
   const size_t total = (size_t)m->nx * m->ny * m->nz;
   const size_t per_wave = total * sizeof(fhp::CellState) + (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS * 4;
-  int waves = m->n_cu * 12;  // LDS: 12.5 KB per wavefront
-  if (const char* e = getenv("FH_DEBUG_PLAN_WAVES_PER_CU")) waves = m->n_cu * std::max(1, atoi(e));
+  int waves = m->n_cu * m->sched_waves_per_cu;  // LDS: 12.5 KB per wavefront
   const size_t budget = (size_t)48 << 30;
   if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);
   if (m->d_cells && m->ws_total == total && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
@@ -147,6 +147,15 @@ int fh_map_set_stream(fh_map* m, void* stream) {
   return FH_OK;
 }
 
+int fh_map_set_sched(fh_map* m, int waves_per_cu, int launch_order) {
+  if (!m || waves_per_cu < 0 || waves_per_cu > 12) return FH_ERR_ARG;
+  const int w = waves_per_cu > 0 ? waves_per_cu : 12;
+  if (w != m->sched_waves_per_cu) m->ws_total = 0;  // the search workspace is sized by the number of wavefronts: reallocated by the next search
+  m->sched_waves_per_cu = w;
+  m->sched_launch_order = launch_order ? 1 : 0;
+  return FH_OK;
+}
+
 int fh_map_sync(fh_map* m) {
   if (!m) return FH_ERR_ARG;
   MapDeviceScope scope(m);
@@ -154,8 +163,12 @@ int fh_map_sync(fh_map* m) {
   return FH_OK;
 }
 
-// MapUtil::readMap (read_map.hpp:30-185): grid of cells[] cells (x, y widened by 5*inflation/res) centred on `center`, clipped to
-// [z_ground, z_max]; the dimension arithmetic below is the reference's (integer truncations included).
+// MapUtil::readMap (/root/reference/thirdparty/jps3d/include/jps_collision/map_util.h:30-185 — the function
+// JPS_Manager::updateJPSMap calls, jps_manager.cpp:135): grid of cells[] cells (x, y widened by 5*inflation/res) centred on
+// `center`, clipped to [z_ground, z_max]; the dimension arithmetic below is that function's (integer truncations included; the
+// "+1" variant of faster/include/read_map.hpp's MapReader is not on FASTER's path).  Pinned to the reference's own compiled
+// readMap — dimensions, origin, every cell, a z_ground-clipped map included — in tests/test_ref_frontend.py and
+// tests/test_gpu_round3.py.
 int fh_map_read_device(fh_map* m, const double* d_cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3],
                        double z_ground, double z_max, double inflation) {
   if (!m || !cells || !center || n_cloud < 0 || (n_cloud > 0 && !d_cloud_xyz) || !(res > 0.0) || !(inflation >= 0.0)) return FH_ERR_ARG;
@@ -248,7 +261,7 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
   FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
   pa.order = nullptr;
-  if (n > m->waves && !getenv("FH_DEBUG_NO_ORDER")) {  // more queries than wavefronts: far-apart pairs first
+  if (n > m->waves && m->sched_launch_order) {  // more queries than wavefronts: far-apart pairs first
     const size_t need = sizeof(int) * ((size_t)n + 128);
     if (need > m->order_cap) {
       FM_HIP(hipStreamSynchronize(m->stream));

@@ -1,7 +1,7 @@
 // fh_path.hip.hpp — voxel-grid path search on the device (gfx950): the first half of the corridor front-end.
 //
 // Reference: JPS_Manager::updateJPSMap -> MapUtil::readMap (/root/reference/faster/src/jps_manager.cpp:129-139,
-// faster/include/read_map.hpp:30-185) builds an occupancy grid from a point cloud; JPS_Manager::solveJPS3D (jps_manager.cpp:141-200)
+// thirdparty/jps3d/include/jps_collision/map_util.h:30-185) builds an occupancy grid from a point cloud; JPS_Manager::solveJPS3D (jps_manager.cpp:141-200)
 // frees the cells around start and goal, searches the 26-connected grid (jps3d graph_search.cpp: Euclidean step costs; heuristic: the
 // exact empty-grid distance, which dominates jps3d's Euclidean one and stays consistent)
 // and cleans the cell path up (jps_planner.cpp:36-105, :286-291: removeLinePts, removeCornerPts forwards and backwards).
@@ -502,7 +502,11 @@ __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
     int nv = 0;
     if (!pl.outside(pl.s[0], pl.s[1], pl.s[2]) && !pl.outside(pl.t[0], pl.t[1], pl.t[2])) {
       serial++;
-      if (serial >= 0x7fffffffu) serial = 1;  // (2^31 queries per wavefront; the workspace would have to be cleared here)
+      if (serial >= 0x7fffffffu) {  // 2^31 queries of this wavefront: its stamps start over, so its cell states are cleared first
+        for (int c = lane; c < mv.total; c += 64) cells[c].stamp = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        serial = 1;
+      }
       nv = pl.search(pa, cells, chunks, serial, expansions);
     }
     double* out = pa.paths + (size_t)q * pa.max_points * 3;

@@ -284,6 +284,7 @@ int fh_pool_solve_pairs(fh_pool* pool, const fh_problem* whole, const fh_face* f
   if (!whole || !safe_templates || (n_faces > 0 && !faces)) return FH_ERR_ARG;
   if ((!whole_results || !safe_results) && (!d_whole_results_root || !d_safe_results_root)) return FH_ERR_ARG;
   if (d_whole_results_root && (root < 0 || root >= (int)pool->dev.size())) return FH_ERR_ARG;
+  if (d_safe_results_root && !d_whole_results_root) return FH_ERR_ARG;  // (a device gather names both arrays or neither)
   Job job;
   std::memset(&job, 0, sizeof(job));
   job.problems = whole; job.faces = faces; job.n_faces = n_faces; job.n = n; job.results = whole_results;

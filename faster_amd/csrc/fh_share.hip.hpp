@@ -95,7 +95,8 @@ struct ShareRec {  // 512 B
   unsigned long long inc_key;
   double inc_f, inc_h;
   int nodes, iters;               // accumulated by finished parts
-  unsigned int last_status, pad0; // status to report if no factor is feasible: FH_ST_INTERRUPTED, or a limit hit in the LAST trial
+  unsigned int last_status;       // status to report if no factor is feasible: FH_ST_INTERRUPTED, or a limit hit in the LAST trial
+  unsigned int limit_kind;        // the limit (FH_ST_NODE_LIMIT / FH_ST_ITER_LIMIT) some wavefront ran into in a trial of this problem
   unsigned long long flops;       // accumulated flop estimate
   unsigned long long limited;     // bit min(t, 63): a wavefront hit a node / iteration limit in trial t (its leaves cannot win)
   double x[48];

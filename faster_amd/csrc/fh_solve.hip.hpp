@@ -1432,7 +1432,7 @@ struct Solver {
         ast(&R_->inc_key, best_key);
         ast(reinterpret_cast<unsigned long long*>(&R_->inc_f), tb_lane0_64(TB_F));
         ast(reinterpret_cast<unsigned long long*>(&R_->inc_h), f64_bits(h));
-        ast(&R_->nodes, 0); ast(&R_->iters, 0); ast(&R_->last_status, 0u); ast(&R_->flops, 0ull); ast(&R_->limited, 0ull);
+        ast(&R_->nodes, 0); ast(&R_->iters, 0); ast(&R_->last_status, 0u); ast(&R_->limit_kind, 0u); ast(&R_->flops, 0ull); ast(&R_->limited, 0ull);
         ast(&R_->assign_lo, alo); ast(&R_->assign_hi, ahi);
       }
       rec = r;
@@ -1573,13 +1573,16 @@ struct Solver {
     }
     state = uniform_i32(state);
     if (state == 2) return 0;
-    const unsigned long long t0 = wall_ticks();
+    unsigned long long t0 = wall_ticks();  // (lane 0) the watchdog measures LACK OF PROGRESS: restarted whenever a unit finishes or a
+    unsigned int seen = 0u;                //  frame is given away anywhere in the launch — a long tail that is still moving is not a failure
     FH_SP_T0();
     for (unsigned round = 0;; round++) {
       if (lane == 0) {
         if (q_arrived(sa, pos)) state = 1;
         else if ((round & 7u) == 7u) {
           const unsigned int done = ald(&sa.ctl->done), err = ald(&sa.ctl->error);
+          const unsigned int progress = done + ald(&sa.ctl->donated);
+          if (progress != seen) { seen = progress; t0 = wall_ticks(); }
           if (!err && !ald(&sa.ctl->interrupted) && sa.host_abort &&
               __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
             ast(&sa.ctl->interrupted, 1u);  // (an idle workgroup relays the host's stop request to the busy ones)
@@ -1729,8 +1732,11 @@ struct Solver {
     return true;
   }
   // a node / iteration limit in the current trial of a shared problem: the trial's tree is incomplete, its leaves cannot win
-  __device__ void note_limited(const ShareArgs& sa) {
-    if (lane == 0) __hip_atomic_fetch_or(&(sa.recs + rec)->limited, 1ull << (trial < 63 ? trial : 63), __ATOMIC_RELAXED, FH_AGENT);
+  __device__ void note_limited(const ShareArgs& sa, unsigned limit) {
+    if (lane == 0) {
+      __hip_atomic_fetch_or(&(sa.recs + rec)->limited, 1ull << (trial < 63 ? trial : 63), __ATOMIC_RELAXED, FH_AGENT);
+      __hip_atomic_fetch_max(&(sa.recs + rec)->limit_kind, limit, __ATOMIC_RELAXED, FH_AGENT);  // which limit (ITER_LIMIT over NODE_LIMIT)
+    }
   }
 
   // ---- MIQP for one dt: depth-first branch and bound.  entry 0: from the root; entry 1: from the frame installed as
@@ -2111,7 +2117,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     // shared problem: its leaves are in the record.  This worker goes on with the next factor if the following trials are still
     // its own and no factor up to this one has a feasible leaf (other parts of this trial may still be running elsewhere: the
     // next trial then starts speculatively, like the ones that were given away).
-    if (limit && limit != FH_ST_INTERRUPTED) sv.note_limited(sa);
+    if (limit && limit != FH_ST_INTERRUPTED) sv.note_limited(sa, limit);
     if (trials >= sv.trial_end || limit == FH_ST_INTERRUPTED || best < INFINITY) break;
     f = f + pr.f_inc;
   }
@@ -2138,7 +2144,9 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     } else {  // no factor of the window is feasible (or the search was cut short): trials_ and dt_ of the last trial of the window
       // (a limit in the winning trial disqualifies its leaves — the sequential search would have gone on to the next factor, which
       // cannot be reconstructed here: reported as not solved.  Otherwise the status of the last trial, as the sequential loop leaves it.)
-      status = (r != FH_RANK_NONE && last_status != FH_ST_INTERRUPTED) ? FH_ST_NODE_LIMIT : (last_status ? (int)last_status : FH_ST_INFEASIBLE);
+      const unsigned int limit_kind = (unsigned int)uniform_i32((int)ald(&R_->limit_kind));
+      status = (r != FH_RANK_NONE && last_status != FH_ST_INTERRUPTED) ? (int)(limit_kind ? limit_kind : (unsigned)FH_ST_NODE_LIMIT)
+                                                                       : (last_status ? (int)last_status : FH_ST_INFEASIBLE);
       trials = 0;
       for (double fk = pr.f_init; fk <= pr.f_final; fk = fk + pr.f_inc) {
         trials++;

@@ -109,7 +109,12 @@ typedef struct fh_params {
                          trees still being explored (Gurobi explores one tree with all its threads, Threads = 0,
                          faster/param/faster.yaml:41); results are identical to share = 0 (one wavefront per problem);
                          nodes / qp_iters / kflops then count the work actually done by all wavefronts.  max_nodes and
-                         max_iters apply per wavefront in a shared tree.                                              */
+                         max_iters apply per wavefront in a shared tree.  ONE documented difference: when a wavefront runs
+                         into max_nodes / max_iters in the trial that holds the best leaf of a SHARED problem, the problem
+                         is reported unsolved with that limit's status, where share = 0 would go on to the next factor
+                         (the trials after it may already have been given away; the sequential continuation cannot be
+                         reconstructed).  With the default limits (1e5 nodes, 2000 iterations per QP) no problem of the
+                         BASELINE configurations comes near them.                                                     */
   double mip_gap;     /* 0 (default): the exact optimum over all assignments.  > 0: a node is pruned when its lower bound is
                          within this relative gap of the incumbent (Gurobi's MIPGap, default 1e-4, which the reference
                          leaves untouched); the result may then depend on exploration order, so work sharing is off.   */
@@ -139,6 +144,23 @@ int fh_set_params(fh_ctx* ctx, const fh_params* p);
  * flight at a time.  Launches issued through one context are ordered on its stream; switching streams synchronises with
  * the previous one.  Use one context per concurrent pipeline (as bench.py does). */
 int fh_set_stream(fh_ctx* ctx, void* hip_stream);
+
+/* Scheduling of a solve launch: how the persistent workgroups order and share the work of a batch.  NO RESULT FIELD DEPENDS ON
+ * ANY OF THESE (tests/test_gpu_round2.py solves 8192 pairs with each of them switched off and compares bit for bit); only
+ * nodes / qp_iters / kflops, which count the work actually done, and the time a launch takes.  Defaults: fh_default_sched(). */
+typedef struct fh_sched {
+  int32_t launch_order;       /* 1 (default): batches of >= 2048 units start with the corridors that have most polytopes       */
+  int32_t publish_factor;     /* a problem that has used this many times the running mean of active-set iterations may publish
+                                 frames ahead of the idle workgroups (default 4; 0: never)                                      */
+  int32_t backlog;            /* frames that may be published ahead of the takers (default 32; 0: none)                        */
+  int32_t waiting_workgroups; /* workgroups that keep waiting for frames when the fresh problems run out (0 = default: CUs / 16) */
+  int32_t min_nodes;          /* a tree gives work away only after this many nodes, unless somebody is idle (default 16)        */
+  int32_t cloud_blocks;       /* 1 (default): the decomposition skips blocks of 64 cloud points whose bounding box misses the
+                                 local box of a segment                                                                         */
+  int32_t reserved[2];
+} fh_sched;
+void fh_default_sched(fh_sched* s);
+int fh_set_sched(fh_ctx* ctx, const fh_sched* s);
 
 /* Cooperative cancellation (SolverGurobi::StopExecution / ResetToNormalState, solverGurobi.cpp:30-39; the reference polls
  * its flag inside Gurobi callbacks, :15-28).  fh_request_stop() may be called from ANY thread while a launch of the context
@@ -291,7 +313,7 @@ int fh_pool_solve_pairs(fh_pool* pool, const fh_problem* whole, const fh_face* f
  *   With max_vertex_dist > 0 the vertices additionally go through Faster::createMoreVertexes (faster/src/faster.cpp:80-97) and, with
  *   max_poly > 0, deleteVertexes (faster/src/utils.cpp:1117-1124): what Faster::replan hands to the convex decomposition.
  * paths: [n][max_points][3]; n_points[i]: number of vertices, 0 = no path (start/goal outside the map or not connected),
- * -1 = more than max_points vertices, -2 = a search limit was hit (f >= 2040 cells, 131072 open entries, 1024 raw path cells).
+ * -1 = more than max_points vertices, -2 = a search limit was hit (f >= 2040 cells, 131072 open entries, 4096 raw path cells).
  * expansions (may be NULL): cells expanded per query.  The CPU restatement the kernels are checked against vertex for vertex is
  * faster_amd/host/corridor_frontend.cpp (plan_path).  One stream per map; entry points of one map are not re-entrant.
  * No CPU fallback: FH_ERR_DEVICE without a device. */
@@ -300,6 +322,9 @@ int fh_map_create(fh_map** out, int device);
 void fh_map_destroy(fh_map* map);
 const char* fh_map_last_error(const fh_map* map);
 int fh_map_set_stream(fh_map* map, void* hip_stream);
+/* Scheduling of the path search (results do not depend on it): wavefronts per CU that hold a search workspace (0 = default 12),
+ * and whether batches larger than the number of wavefronts start with the far-apart start/goal pairs (default 1). */
+int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
 int fh_map_sync(fh_map* map);
 int fh_map_read(fh_map* map, const double* cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3],
                 double z_ground, double z_max, double inflation);

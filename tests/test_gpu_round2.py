@@ -454,13 +454,13 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
 
     ref = run(ctx)
     assert (ref[1]["solved"] == 1).mean() > 0.7
-    variants = {"FH_DEBUG_NO_ORDER": "1", "FH_DEBUG_GIANT_FACTOR": "0", "FH_DEBUG_BACKLOG": "0"}
+    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0}   # (fh_set_sched: explicit scheduling fields, no environment)
     for k, v in variants.items():
-        os.environ[k] = v
+        ctx.set_sched(**{k: v})
         try:
             got = run(ctx)
         finally:
-            del os.environ[k]
+            ctx.set_sched()
         for a, b in zip(ref, got):
             for f in RESULT_FIELDS:
                 assert np.array_equal(a[f], b[f]), (k, f)
