@@ -1,0 +1,19 @@
+"""The reduced-space basis tables of the solve kernels (faster_amd/csrc/fh_basis.hip.hpp: computed on the host, read by the device)
+checked on the CPU by tests/cpp/test_basis.cpp: orthogonality, annihilation of the final-state functionals of
+setConstraintsXf (solverGurobi.cpp:332-357) at any step, the minimum-norm particular solution, the consistency rows for N < 3, the
+inverse row norms and the structurally constant rows of a whole trajectory."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_basis_tables():
+    exe = os.path.join(ROOT, "tests", "cpp", "test_basis")
+    src = exe + ".cpp"
+    hdr = os.path.join(ROOT, "faster_amd", "csrc", "fh_basis.hip.hpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:]
+    assert int(r.stdout.split()[1]) > 10000

@@ -221,3 +221,46 @@ def test_device_map_and_path_search_against_the_reference_sources(ctx, ref):
         same += int(len(d) == len(p) and np.allclose(d, p, atol=1e-9))
     rm.close()
     assert with_path >= 180 and same >= with_path // 10
+
+
+def test_speculative_search_ends_on_stop_and_deadline(ctx):
+    """fh_solve_batch_speculative (what SolverHip::genNewTraj calls) with several factors in flight: FH_ST_INTERRUPTED is terminal —
+    the search of a problem stops there, unsolved, instead of going on to later factor windows (genNewTraj's loop ends on the
+    abort flag, solverGurobi.cpp:445-446, :643-646) — and fh_params.deadline_ms is ONE budget for the whole search."""
+    import time
+
+    from test_gpu_round2 import hard_problems
+
+    pr, faces = hard_problems(n=64)
+    c = capi.Context(0)
+    try:
+        easy, efaces, _ = corridor.whole_batch(64, seed=6)
+        c.solve_batch_speculative(easy, efaces, 4)        # (first launch: allocations)
+        par = abi.default_params()
+        par["deadline_ms"] = 10.0
+        c.set_params(par)
+        t = time.perf_counter()
+        res = c.solve_batch_speculative(pr, faces, 4)     # 19 factors per problem, 4 at a time: 5 windows
+        dur = time.perf_counter() - t
+        assert dur < 0.1, dur                             # one 10 ms budget (+ copies), not one per window
+        hit = res["status"] == abi.FH_ST_INTERRUPTED
+        assert hit.sum() >= 1 and np.all(res["solved"][hit] == 0) and np.all(res["factor"][hit] == 0)
+        assert np.all(res["trials"][hit] < 19)            # ended where it was interrupted
+        par["deadline_ms"] = 0.0
+        c.set_params(par)
+        # the stop word: raised before the call, every search ends at its first window
+        c.request_stop()
+        t = time.perf_counter()
+        res = c.solve_batch_speculative(pr, faces, 4)
+        assert time.perf_counter() - t < 0.1
+        hit = res["status"] == abi.FH_ST_INTERRUPTED
+        # (a trial that costs nothing may still complete as infeasible before its workgroup sees the word — one workgroup in 32 polls
+        # it with every draw — and the search then moves on to the next window; the first interrupted trial ends it)
+        assert hit.sum() >= 8 and np.all(res["solved"][hit] == 0) and np.all(res["factor"][hit] == 0)
+        c.clear_stop()
+        # and without either the speculative search equals the sequential one on the easy batch
+        a, b = c.solve_batch_speculative(easy, efaces, 4), c.solve_batch(easy, efaces)
+        for f in ("solved", "trials", "factor", "dt", "cost", "status", "assign"):
+            assert np.array_equal(a[f], b[f]), f
+    finally:
+        c.close()
