@@ -1040,7 +1040,7 @@ struct Solver {
     int it = 0;
     bind_assignment();
     const int q0 = q;
-    const int st = qp_loop(fmin(ub, box_ub), tie, max_iters, it, cost);
+    const int st = qp_loop(ub, tie, max_iters, it, cost);
     iters += it;
     // FP64 flop estimate of this active-set run (useful lanes only; reported as fh_result.kflops), once per node so that the
     // iteration loop carries no bookkeeping (counting per iteration cost 3 % of the throughput).  Per outer iteration (at most
@@ -1067,7 +1067,18 @@ struct Solver {
            // mistaken for an independent one and answered with a step of 1e24.  (NaN-safe: !(cost <= ub).)
           const double xl = (lane < n) ? x[lane] : 0.0;
           cost = c0 + wave_sum(xl * xl);
-          if (!(cost <= ub) || (tie && cost == ub)) return 2;
+          if (!(cost <= box_ub)) {
+            // Infeasible, with a certificate: the current point is the cheapest one that satisfies the ACTIVE rows (the invariant of
+            // the dual method), so the active rows and the jerk box exclude each other — the conflict is the segments whose corridor
+            // rows are active (box rows do not depend on any decision).
+            const int al = lane < NVP ? act[lane] : 0;
+            conflict = wave_or((lane < q && (al >> 24) == K_POLY) ? (1u << ((al >> 16) & 31)) : 0u);
+#ifdef FH_TRACE
+            trace_src = 3; trace_id = 0; trace_v = cost;
+#endif
+            return 1;
+          }
+          if (cost > ub || (tie && cost == ub)) return 2;
         }
         bool cbad;
         scan(id, vp, cbad);
