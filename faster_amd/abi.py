@@ -74,6 +74,11 @@ sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("ba
 assert sched_dtype.itemsize == 32
 
 
+pair_rule_dtype = np.dtype([("mode", "<i4"), ("reserved", "<i4"), ("r_known", "<f8"), ("drone_radius", "<f8"), ("delta_h", "<f8"),
+                            ("delta_a", "<f8")])
+assert pair_rule_dtype.itemsize == 40
+
+
 def default_sched():
     s = np.zeros((), dtype=sched_dtype)
     s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"] = 1, 4, 32, 16, 1

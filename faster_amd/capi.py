@@ -15,10 +15,10 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
-    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin",
+    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
-    "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin",
+    "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
     "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
@@ -60,6 +60,8 @@ def lib():
         L.fh_map_set_sched.argtypes = [vp, i32, i32]
         L.fh_set_pair_margin.restype = i32
         L.fh_set_pair_margin.argtypes = [vp, f64]
+        L.fh_set_pair_rule.restype = i32
+        L.fh_set_pair_rule.argtypes = [vp, vp]
         L.fh_request_stop.restype = i32
         L.fh_request_stop.argtypes = [vp]
         L.fh_clear_stop.restype = i32
@@ -104,6 +106,8 @@ def lib():
         L.fh_pool_set_params.argtypes = [vp, vp]
         L.fh_pool_set_pair_margin.restype = i32
         L.fh_pool_set_pair_margin.argtypes = [vp, f64]
+        L.fh_pool_set_pair_rule.restype = i32
+        L.fh_pool_set_pair_rule.argtypes = [vp, vp]
         L.fh_pool_solve_batch.restype = i32
         L.fh_pool_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp]
         L.fh_pool_solve_pairs.restype = i32
@@ -323,6 +327,12 @@ class Context:
     def set_pair_margin(self, r_margin):
         """r_margin >= 0: the synthetic hand-off keeps R strictly inside its safe corridor (see fasterhip.h); < 0: SURVEY 8(d) literal."""
         self._check(lib().fh_set_pair_margin(self._h, float(r_margin)), "fh_set_pair_margin")
+
+    def set_pair_rule(self, mode=0, r_known=0.0, drone_radius=0.0, delta_h=1.0, delta_a=0.5):
+        """fh_set_pair_rule: mode 0 = R at the fraction r_frac of the whole trajectory; 1 = FASTER's findIndexH / findIndexR."""
+        r = np.zeros(1, dtype=abi.pair_rule_dtype)
+        r["mode"], r["r_known"], r["drone_radius"], r["delta_h"], r["delta_a"] = mode, r_known, drone_radius, delta_h, delta_a
+        self._check(lib().fh_set_pair_rule(self._h, abi.ptr(r)), "fh_set_pair_rule")
 
     def request_stop(self):
         """StopExecution(): callable from any thread while a launch is running."""

@@ -42,6 +42,7 @@ struct fh_ctx {
   unsigned int* d_abort = nullptr;          // its device address
   unsigned int* h_report = nullptr;         // pinned: the control block's report words of the last launch (copied with the results)
   double pair_margin = -1.0;                // fh_set_pair_margin
+  fh_pair_rule pair_rule = {0, 0, 0.0, 0.0, 1.0, 0.5};  // fh_set_pair_rule
   bool ctl_ready = false;                   // the device-side control block is in its initial state (left so by the previous launch)
   bool launched = false;                    // a solve launch has been issued since the control block was last checked
   int last_grid = 0;
@@ -324,6 +325,14 @@ int fh_set_stream(fh_ctx* ctx, void* hip_stream) {
 int fh_set_pair_margin(fh_ctx* ctx, double r_margin) {
   if (!ctx || !(r_margin == r_margin)) return FH_ERR_ARG;
   ctx->pair_margin = r_margin < 0 ? -1.0 : r_margin;
+  return FH_OK;
+}
+
+int fh_set_pair_rule(fh_ctx* ctx, const fh_pair_rule* rule) {
+  if (!ctx || !rule) return FH_ERR_ARG;
+  if (rule->mode != 0 && rule->mode != 1) return FH_ERR_ARG;
+  if (rule->mode == 1 && (!(rule->r_known > 0) || !(rule->drone_radius >= 0) || !(rule->delta_h > 0) || !(rule->delta_a > 0))) return FH_ERR_ARG;
+  ctx->pair_rule = *rule;
   return FH_OK;
 }
 
@@ -633,7 +642,7 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
   if (!d_whole || !d_whole_results || !d_safe) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
   hipLaunchKernelGGL(fh::pair_glue_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole,
-                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, ctx->pair_margin, d_safe, d_safe_faces);
+                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, ctx->pair_margin, ctx->pair_rule, d_safe, d_safe_faces);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
@@ -654,7 +663,7 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   std::memset(&ka, 0, sizeof(ka));
   ka.n = n; ka.max_faces = max_faces;
   ka.safe = d_safe; ka.sfaces = d_safe_faces; ka.sres = d_safe_results;
-  ka.r_frac = r_frac; ka.shrink = shrink; ka.max_safe_poly = max_safe_poly; ka.r_margin = ctx->pair_margin;
+  ka.r_frac = r_frac; ka.shrink = shrink; ka.max_safe_poly = max_safe_poly; ka.r_margin = ctx->pair_margin; ka.rule = ctx->pair_rule;
   if (max_seg <= 6) return launch_solve<6, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   if (max_seg <= 10) return launch_solve<10, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   if (max_seg <= 15) return launch_solve<15, true>(ctx, d_whole, d_faces, d_whole_results, ka);

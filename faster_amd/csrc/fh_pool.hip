@@ -261,6 +261,15 @@ int fh_pool_set_pair_margin(fh_pool* pool, double r_margin) {
   return FH_OK;
 }
 
+int fh_pool_set_pair_rule(fh_pool* pool, const fh_pair_rule* rule) {
+  if (!pool || !rule) return FH_ERR_ARG;
+  for (PoolDev& d : pool->dev) {
+    const int rc = fh_set_pair_rule(d.ctx, rule);
+    if (rc != FH_OK) return rc;
+  }
+  return FH_OK;
+}
+
 int fh_pool_solve_batch(fh_pool* pool, const fh_problem* problems, const fh_face* faces, int64_t n_faces, int n, fh_result* results,
                         int root, fh_result* d_results_root) {
   if (!pool || n < 0 || n_faces < 0) return FH_ERR_ARG;

@@ -111,9 +111,24 @@ __device__ __forceinline__ void glue_store(int32_t* p, int32_t v) {
   if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
 }
+// sample i of fillX (solverGurobi.cpp:122-168) without running the clock: t = (i + 1) DC, segment = boundaries crossed (the
+// reference's `if (t > dt (interval + 1)) interval++` once per sample, DC <= dt / 2).  Used by the search for R only — where two
+// pieces meet they agree to rounding; the state that becomes x0 of the safe problem is evaluated with the reference's own clock.
+__device__ __forceinline__ void state_at(const fh_result& rw, int N, double DC, int i, int size, fh_state& s) {
+  const double t = (double)(i + 1) * DC;
+  int interval = (int)ceil(t / rw.dt) - 1;
+  interval = interval < 0 ? 0 : (interval > N - 1 ? N - 1 : interval);
+  eval_state(rw.coeff[interval], t - interval * rw.dt, i == size - 1, s);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+
 template <bool WT = false>
 __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, const fh_face* wfaces, double r_frac, double shrink,
-                                     int max_safe_poly, double r_margin, fh_problem& ps, fh_face* sfaces, int lane) {
+                                     int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane) {
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
     if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
     return;
@@ -122,6 +137,51 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
   const double dt = rw.dt, DC = pw.dc;
   const int size = sample_count(pw, rw);
   int k = (int)(r_frac * (double)size);
+  if (rule.mode == 1) {
+    // findIndexH (faster.cpp:218-251): samples 0, 10, 20, ... against unknown space (modelled: farther than r_known from x0)
+    const double lim = rule.r_known - rule.drone_radius;
+    int iH = 0x7fffffff;
+    for (int base = 0; 10 * base < size && iH == 0x7fffffff; base += 64) {
+      const int i = 10 * (base + lane);
+      int mine = 0x7fffffff;
+      if (i < size) {
+        fh_state s;
+        state_at(rw, N, DC, i, size, s);
+        const double dx = s.pos[0] - pw.x0[0], dy = s.pos[1] - pw.x0[1], dz = s.pos[2] - pw.x0[2];
+        if (sqrt(dx * dx + dy * dy + dz * dz) > lim) mine = i;
+      }
+      iH = wave_min_i32(mine);
+    }
+    if (iH == 0x7fffffff) {  // needToComputeSafePath == false (:462-466): the pair ends with its whole trajectory
+      if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
+      return;
+    }
+    int indexH = (int)(rule.delta_h * (double)iH);
+    indexH = indexH > size - 1 ? size - 1 : (indexH < 0 ? 0 : indexH);
+    fh_state sH;
+    state_at(rw, N, DC, indexH, size, sH);
+    // findIndexR (faster.cpp:173-216): first sample from which braking before H is no longer possible (x and y only)
+    const double den = 2.0 * rule.delta_a * pw.a_max;
+    int iR = indexH;
+    for (int base = 0; base <= indexH && iR == indexH; base += 64) {
+      const int i = base + lane;
+      int mine = indexH;
+      if (i <= indexH) {
+        fh_state s;
+        state_at(rw, N, DC, i, size, s);
+        bool collision = false;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          const double diff = sH.pos[a] - s.pos[a], w = s.vel[a] * diff;
+          const double sg = w > 0.0 ? 1.0 : (w < 0.0 ? -1.0 : 0.0);
+          collision |= sg * s.vel[a] * s.vel[a] / den > fabs(diff);
+        }
+        if (collision) mine = i;
+      }
+      iR = wave_min_i32(mine);
+    }
+    k = iR;
+  }
   if (k > size - 1) k = size - 1;
   if (k < 0) k = 0;
   double t = 0;
@@ -204,11 +264,11 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
 
 __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
                                                        const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink,
-                                                       int max_safe_poly, double r_margin, fh_problem* __restrict__ safe,
+                                                       int max_safe_poly, double r_margin, fh_pair_rule rule, fh_problem* __restrict__ safe,
                                                        fh_face* __restrict__ sfaces) {
   const int b = blockIdx.x;
   if (b >= n) return;
-  pair_glue_one<false>(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, r_margin, safe[b], sfaces, threadIdx.x);
+  pair_glue_one<false>(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, r_margin, rule, safe[b], sfaces, threadIdx.x);
 }
 
 }  // namespace fh

@@ -2247,6 +2247,7 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
   fh_result* sres;
   double r_frac, shrink, r_margin;
   int max_safe_poly, pad;
+  fh_pair_rule rule;  // which sample of the whole trajectory becomes R (fh_set_pair_rule)
   // launch order: ticket t works on unit order[t] (null: t).  Results do not depend on it; the hardest corridors go first so that
   // their trees are not what the launch ends on (order_kernel)
   const int* order;
@@ -2353,7 +2354,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
         if (phase == 0) {
           // the whole result was written by this wavefront (plain stores): drained, then read back by the hand-off
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          pair_glue_one<true>(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.safe[unit],
+          pair_glue_one<true>(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit],
                               ka.sfaces, opaque((int)threadIdx.x));
           // the safe problem went out write-through and is drained: this wavefront reads its own stores back (a CU's L1 follows
           // that CU's stores; no agent-scope acquire here — it made every pair drop the CU's L1 and, measured, 0.5 GB of dirty

@@ -236,6 +236,26 @@ int fh_sample_batch_device(fh_ctx* ctx, const fh_problem* d_problems, const fh_r
  * safe corridor is decomposed around R (faster.cpp:475-499), the corridor starts at the first polytope of the whole corridor that
  * contains R, and no face of that polytope is pulled closer to R than r_margin metres; the following polytopes are shrunk as before. */
 int fh_set_pair_margin(fh_ctx* ctx, double r_margin);
+/* WHICH sample of the whole trajectory becomes R (applies to fh_pair_glue_device, fh_solve_pairs_device and fh_pool_solve_pairs).
+ * mode 0 (default): sample (int)(r_frac * count) — the synthetic pairing of SURVEY.md 8(d).
+ * mode 1: FASTER's own rule, on the device, per pair:
+ *   findIndexH (faster/src/faster.cpp:218-251): every 10th sample of the whole trajectory is tested against unknown space; the first
+ *     one closer than drone_radius to it gives indexH = (int)(delta_h * i).  The reference asks a kd-tree of the mapper's unknown
+ *     voxels; a batch of independent problems has no mapper, so unknown space is MODELLED here: everything farther than r_known from
+ *     the start x0 of the whole problem is unknown (a vehicle that has seen what its sensor reaches and nothing else), i.e. the
+ *     distance to unknown space is r_known - |pos - x0|.  No sample near unknown space: no safe trajectory is needed
+ *     (needToComputeSafePath == false, faster.cpp:462-466) and the pair ends with its whole trajectory (safe n_seg = 0).
+ *   findIndexR (faster.cpp:173-216): the first sample i <= indexH from which the vehicle can no longer brake before H — per axis
+ *     x, y: sign(v (pH - p)) v^2 / (2 delta_a a_max) > |pH - p| — is R; if there is none, R = H.
+ * r_frac of the calls is ignored in mode 1.  The safe corridor is built from R as described above in both modes. */
+typedef struct fh_pair_rule {
+  int32_t mode, reserved;
+  double r_known;       /* [m] radius of known space around x0 (mode 1)                                   */
+  double drone_radius;  /* [m] par_.drone_radius (faster.yaml: 0.42)                                       */
+  double delta_h;       /* par_.delta_H (faster.yaml: 1.0)                                                 */
+  double delta_a;       /* par_.delta_a (faster.yaml: 0.5)                                                 */
+} fh_pair_rule;
+int fh_set_pair_rule(fh_ctx* ctx, const fh_pair_rule* rule);
 int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results,
                         const fh_face* d_faces, int n, double r_frac, double shrink, int max_safe_poly,
                         fh_problem* d_safe, fh_face* d_safe_faces);
@@ -290,6 +310,7 @@ int fh_pool_size(const fh_pool* pool);
 const char* fh_pool_last_error(const fh_pool* pool);
 int fh_pool_set_params(fh_pool* pool, const fh_params* p);
 int fh_pool_set_pair_margin(fh_pool* pool, double r_margin);
+int fh_pool_set_pair_rule(fh_pool* pool, const fh_pair_rule* rule);
 /* fh_solve_batch over the pool (host pointers, synchronous).  The result blocks are gathered into `results` (host, may be NULL)
  * and/or into `d_results_root`, n records in the memory of pool device number `root`, with peer copies over xGMI
  * (hipMemcpyPeerAsync) — for a consumer that lives on that GPU.  At least one destination must be given. */

@@ -8,7 +8,28 @@ from faster_amd import abi
 from . import oracle
 
 
-def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_poly=3, r_margin=-1.0):
+def find_index_h(X, x0_pos, r_known, drone_radius, delta_h):
+    """Faster::findIndexH (faster/src/faster.cpp:218-251) with the unknown space of fh_set_pair_rule: every 10th sample; the first one
+    whose nearest unknown point (modelled: anything farther than r_known from x0) is closer than drone_radius.  -> (indexH, needed)"""
+    for i in range(0, X.shape[0], 10):
+        if r_known - np.linalg.norm(X[i]["pos"] - x0_pos) < drone_radius:
+            return int(delta_h * i), True
+    return X.shape[0] - 1, False
+
+
+def find_index_r(X, index_h, delta_a, a_max):
+    """Faster::findIndexR (faster.cpp:173-216), literally: x and y only."""
+    pos_h = X[index_h]["pos"][:2]
+    for i in range(0, index_h + 1):
+        vel, pos = X[i]["vel"][:2], X[i]["pos"][:2]
+        braking = np.sign(vel * (pos_h - pos)) * vel ** 2 / (2 * delta_a * a_max)
+        if np.any(braking > np.abs(pos_h - pos)):
+            return i
+    return index_h
+
+
+def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_poly=3, r_margin=-1.0, rule=None):
+    """rule: None (R at the fraction r_frac of the samples) or dict(r_known, drone_radius, delta_h, delta_a): FASTER's own choice of R."""
     keep_r = r_margin >= 0
     safe = safe_templates.copy()
     sfaces = np.zeros_like(faces)
@@ -20,6 +41,12 @@ def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_po
         X = oracle.sample(pw, rw)
         size = X.shape[0]
         k = min(max(int(r_frac * size), 0), size - 1)
+        if rule is not None:
+            index_h, needed = find_index_h(X, pw["x0"][:3], rule["r_known"], rule["drone_radius"], rule.get("delta_h", 1.0))
+            if not needed:          # needToComputeSafePath == false (faster.cpp:462-466): no safe trajectory
+                safe["n_seg"][i] = 0
+                continue
+            k = find_index_r(X, min(index_h, size - 1), rule.get("delta_a", 0.5), float(pw["a_max"]))
         R = X[k]
         safe["x0"][i, 0:3], safe["x0"][i, 3:6], safe["x0"][i, 6:9] = R["pos"], R["vel"], R["accel"]
         P = int(pw["n_poly"])

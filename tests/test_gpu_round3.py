@@ -264,3 +264,34 @@ def test_speculative_search_ends_on_stop_and_deadline(ctx):
             assert np.array_equal(a[f], b[f]), f
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("n_seg,p_choices,r_known", [(10, (2, 3, 4, 5, 6), 3.0), (15, (4, 5, 6, 7, 8), 4.0)])
+def test_reference_rule_for_r_on_the_device(ctx, oracle, n_seg, p_choices, r_known):
+    """fh_set_pair_rule mode 1: R chosen per pair as Faster::findIndexH / findIndexR choose it (faster.cpp:173-251; unknown space
+    modelled as everything farther than r_known from the start) inside the fused pair kernel, against the literal numpy restatement
+    of the two functions on the oracle's samples (oracle/pair_glue.py): the same pairs skip the safe trajectory, the same sample
+    becomes R (state equal to 1e-9), and the safe results match the oracle's on the device-written problems."""
+    from oracle import pair_glue
+
+    B = 768
+    whole, faces, _ = corridor.whole_batch(B, seed=500 + n_seg, n_seg=n_seg, p_choices=p_choices)
+    tmpl = corridor.safe_templates(whole)
+    rule = dict(r_known=r_known, drone_radius=0.3, delta_h=1.0, delta_a=0.5)
+    ctx.set_pair_rule(mode=1, **rule)
+    try:
+        wres, sres, safe, sfaces = fused_pairs(ctx, whole, faces, tmpl, n_seg, 0.05)
+    finally:
+        ctx.set_pair_rule(mode=0)
+    wref = oracle.solve_batch(whole, faces)
+    compare(wres, wref)
+    safe_ref, _ = pair_glue.glue(whole, wref, faces, tmpl, 0.5, 0.2, 3, r_margin=0.05, rule=rule)
+    assert np.array_equal(safe["n_seg"], safe_ref["n_seg"])
+    live = np.nonzero(safe_ref["n_seg"] > 0)[0]
+    assert 0.3 * B < len(live) <= B and (safe_ref["n_seg"] == 0).sum() >= 0
+    np.testing.assert_allclose(safe["x0"][live], safe_ref["x0"][live], rtol=0, atol=1e-9)
+    assert np.array_equal(safe["n_poly"][live], safe_ref["n_poly"][live])
+    sref = oracle.solve_batch(safe[live], sfaces)
+    oks = compare(sres[live], sref)
+    # R was chosen so that the vehicle can still brake: far more safe problems have a solution than with R at half of the trajectory
+    assert oks.mean() > 0.85, oks.mean()
