@@ -490,23 +490,23 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
     fctx.set_params(par)
     fctx.set_pair_margin(r_margin)
 
-    def run(mode):
+    def run(mode, shrink, max_safe_poly):
         fctx.set_pair_rule(mode=mode, r_known=4.0, drone_radius=0.3, delta_h=1.0, delta_a=0.5)   # Ra, delta_H, delta_a: faster.yaml
         d_safe.copy_(to_dev(tmpl))
         ms = []
         for k in range(reps + 1):
             torch.cuda.synchronize()
             t = time.perf_counter()
-            fctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(), d_sf.data_ptr(),
-                                    d_sr.data_ptr())
+            fctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, shrink, max_safe_poly, d_wr.data_ptr(), d_safe.data_ptr(),
+                                    d_sf.data_ptr(), d_sr.data_ptr())
             fctx.sync()
             ms.append(1e3 * (time.perf_counter() - t))
         w, s_ = d_wr.cpu().numpy().view(abi.result_dtype).copy(), d_sr.cpu().numpy().view(abi.result_dtype).copy()
         sp = d_safe.cpu().numpy().view(abi.problem_dtype)
         return float(np.median(ms[1:])), w, s_, int((sp["n_seg"] > 0).sum())
 
-    med_half, wres_half, sres_half, live_half = run(0)   # R at half of the whole trajectory
-    med, wres, sres, live = run(1)                       # FASTER's own rule for R (findIndexH / findIndexR, fh_set_pair_rule)
+    med_half, wres_half, sres_half, live_half = run(0, 0.2, 3)   # C4's synthetic pairing applied to the forest corridors
+    med, wres, sres, live = run(1, 0.0, 5)                       # FASTER's own rule for R; safe corridor long enough to reach from R to H
     fctx.close()
     ft = finfo["front_timing"]
     front_s = ft["map_s"] + ft["path_search_s"] + ft["decomposition_s"]
@@ -520,17 +520,18 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
             "safe_problems": live, "safe_solved_frac": float(sres["solved"].sum() / max(live, 1)),
             "mean_qp_iters_per_pair": float(wres["qp_iters"].mean() + sres["qp_iters"].mean()),
             "max_faces": mf,
-            "r_rule": "FASTER's findIndexH / findIndexR on the device (fh_set_pair_rule mode 1: unknown space = farther than Ra = 4 m from the "
-                      "start, drone_radius 0.3 m, delta_H 1.0, delta_a 0.5); pairs whose whole trajectory stays in known space need no safe "
-                      "trajectory (faster.cpp:462-466)",
+            "hand_off": "R by FASTER's findIndexH / findIndexR on the device (fh_set_pair_rule mode 1: unknown space = farther than Ra = 4 m from "
+                        "the start, drone_radius 0.3 m, delta_H 1.0, delta_a 0.5; pairs whose whole trajectory stays in known space need no safe "
+                        "trajectory, faster.cpp:462-466); safe corridor = the polytopes of the whole corridor from the one that holds R, up to 5 "
+                        "of them, not pulled in (they are <= 1.5 m long each, dist_max_vertexes: five reach from R to the unknown boundary, "
+                        "which the reference covers with <= 3 longer polytopes decomposed anew around R..M, faster.cpp:475-499)",
             "r_at_half_of_the_trajectory": {"step_ms_median": med_half, "pairs_per_s": B / (med_half * 1e-3), "safe_problems": live_half,
                                             "safe_solved_frac": float(sres_half["solved"].sum() / max(live_half, 1)),
                                             "mean_qp_iters_per_pair": float(wres_half["qp_iters"].mean() + sres_half["qp_iters"].mean()),
-                                            "note": "SURVEY.md 8(d)'s synthetic pairing: R is where the speed peaks, so about half of these safe "
-                                                    "problems cannot brake inside their corridor and are infeasible for every factor — problems "
-                                                    "FASTER never poses"},
-            "note": "the safe corridor is the run of polytopes of the whole corridor from the one that holds R (pulled in by 0.2 m, not closer "
-                    "than r_margin to R), not a decomposition around R in unknown+occupied space (faster.cpp:495-499: host stub only)"}
+                                            "note": "C4's synthetic pairing (SURVEY.md 8(d): R = the sample at half of the whole trajectory, the "
+                                                    "first 3 polytopes pulled in by 0.2 m) on the forest corridors: R is where the speed peaks and "
+                                                    "three 1.5 m polytopes are too short to stop in, so about half of these safe problems are "
+                                                    "infeasible for every factor — problems FASTER never poses"}}
 
 
 def literal_leg(make_pipe, run_step, fused, abi, B):
