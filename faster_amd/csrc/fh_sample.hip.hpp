@@ -192,10 +192,10 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
   }
   fh_state R;
   eval_state(rw.coeff[interval], t - interval * dt, k == size - 1, R);
-  if (lane < 3) {
-    glue_store<WT>(&ps.x0[lane], R.pos[lane]);
-    glue_store<WT>(&ps.x0[3 + lane], R.vel[lane]);
-    glue_store<WT>(&ps.x0[6 + lane], R.accel[lane]);
+  if (lane < 3) {  // (selected, not indexed: an array indexed by the lane would live in scratch memory)
+    glue_store<WT>(&ps.x0[lane], lane == 0 ? R.pos[0] : (lane == 1 ? R.pos[1] : R.pos[2]));
+    glue_store<WT>(&ps.x0[3 + lane], lane == 0 ? R.vel[0] : (lane == 1 ? R.vel[1] : R.vel[2]));
+    glue_store<WT>(&ps.x0[6 + lane], lane == 0 ? R.accel[0] : (lane == 1 ? R.accel[1] : R.accel[2]));
   }
   const bool keep_r = r_margin >= 0.0;
   const double test_shrink = keep_r ? 0.0 : shrink;  // which polytope holds R: the original one / the shrunk one
