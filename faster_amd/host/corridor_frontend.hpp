@@ -326,8 +326,10 @@ struct VoxelGrid {
     }
   }
 
-  void set_free_around(const int c[3], double inflation) {  // setFreeVoxelAndSurroundings (map_util.h:255-273)
-    const int m = (int)std::floor(inflation / res);
+  // setFreeVoxelAndSurroundings(center, const float d) (jps3d map_util.h:248-263): n_voxels = round(d / res + 0.5) with d a FLOAT
+  // (inflation 0.3, res 0.2: 2 cells — not the floor(inflation / res) = 1 of readMap's inflation)
+  void set_free_around(const int c[3], double inflation) {
+    const int m = (int)std::round((double)(float)inflation / res + 0.5);
     for (int ix = c[0] - m; ix <= c[0] + m; ix++)
       for (int iy = c[1] - m; iy <= c[1] + m; iy++)
         for (int iz = c[2] - m; iz <= c[2] + m; iz++)

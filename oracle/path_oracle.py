@@ -42,6 +42,10 @@ class Grid:
         self.occ = bytearray(total)
         m = int(math.floor(inflation / res))
         self.m = m
+        # setFreeVoxelAndSurroundings(center, const float d) (jps3d map_util.h:248-263): round(d / res + 0.5) cells, d a FLOAT
+        import struct
+        d32 = struct.unpack("f", struct.pack("f", inflation))[0]
+        self.m_free = _round_half_away(d32 / res + 0.5)
         for p in cloud:
             c = [max(v, 0) for v in self.to_cell(p)]
             for ix in range(c[0] - m, c[0] + m + 1):
@@ -76,9 +80,9 @@ def plan(grid, start, goal):
     s, t = grid.to_cell(start), grid.to_cell(goal)
     freed = set()
     for c in (s, t):
-        for ix in range(c[0] - grid.m, c[0] + grid.m + 1):
-            for iy in range(c[1] - grid.m, c[1] + grid.m + 1):
-                for iz in range(c[2] - grid.m, c[2] + grid.m + 1):
+        for ix in range(c[0] - grid.m_free, c[0] + grid.m_free + 1):
+            for iy in range(c[1] - grid.m_free, c[1] + grid.m_free + 1):
+                for iz in range(c[2] - grid.m_free, c[2] + grid.m_free + 1):
                     if not grid.outside(ix, iy, iz):
                         freed.add(grid.index(ix, iy, iz))
 

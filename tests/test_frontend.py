@@ -115,8 +115,9 @@ def test_path_search_properties(seed, start, goal):
     def cell(p):
         return np.round((p - origin) / res - 0.5).astype(int)
 
+    mf = int(round(float(np.float32(infl)) / res + 0.5))   # setFreeVoxelAndSurroundings: round(d / res + 0.5), d a float (map_util.h:248-263)
     for c in (cell(start), cell(goal)):
-        occ[max(c[0] - m, 0):c[0] + m + 1, max(c[1] - m, 0):c[1] + m + 1, max(c[2] - m, 0):c[2] + m + 1] = False
+        occ[max(c[0] - mf, 0):c[0] + mf + 1, max(c[1] - mf, 0):c[1] + mf + 1, max(c[2] - mf, 0):c[2] + mf + 1] = False
     for v in path:
         assert not occ[tuple(cell(v))], "path vertex in an occupied cell"
     def ray_clear(a, b):

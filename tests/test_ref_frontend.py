@@ -193,3 +193,36 @@ def test_jps3d_raw_cost_is_the_dijkstra_optimum(ref, seed, start, goal):
     dist = dijkstra(g, indices=ids[tuple(cell(start))])[ids[tuple(cell(goal))]]
     assert cost == pytest.approx(dist * res, rel=1e-9)
     m.close()
+
+
+def test_start_and_goal_inside_the_inflated_obstacles(ref):
+    """setFreeVoxelAndSurroundings(center, const float d) frees round(d / res + 0.5) cells around start and goal (map_util.h:248-263;
+    inflation 0.3 m at 0.2 m cells: TWO cells, not the one cell of readMap's own inflation): queries that start or end inside the
+    inflated hull of a tree — where that number decides whether a path exists at all — exist for jps3d iff they exist here and cost
+    the same.  (Rounds 1-2 freed floor(inflation / res) cells; found when the reference's own map code could be run.)"""
+    cloud, centres = frontend.forest_cloud(3)
+    cloud = cloud.astype(np.float32).astype(np.float64)
+    res, zg, zmax, infl = 0.2, 0.0, 3.0, 0.3
+    cells, center = (110, 110, 15), np.array([10.0, 10.0, 1.5])
+    rng = np.random.default_rng(11)
+    n = 96
+    ang = rng.uniform(0, 2 * np.pi, n)
+    near = centres[rng.integers(0, len(centres), n)] + np.column_stack([np.cos(ang), np.sin(ang)]) * rng.uniform(0.40, 0.75, (n, 1))
+    starts = np.column_stack([near, rng.uniform(0.8, 2.2, n)])
+    goals = np.column_stack([rng.uniform(2, 18, n), rng.uniform(2, 18, n), rng.uniform(0.8, 2.2, n)])
+    starts[n // 2:], goals[n // 2:] = goals[n // 2:].copy(), starts[n // 2:].copy()    # half of them END inside the hull
+    hp, hn, _ = frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals, max_points=256)
+    m = ref.Map(cloud, cells, res, center, zg, zmax, infl)
+    occ = m.occupancy()
+    inside = found = 0
+    for i in range(n):
+        p, cost, _ = m.plan(starts[i], goals[i], True)
+        c = np.round((np.minimum(starts[i], goals[i]) * 0 + (starts[i] if i < n // 2 else goals[i]) - m.origin) / res - 0.5).astype(int)
+        inside += int(occ[c[2], c[1], c[0]] > 0)
+        assert (p is None) == (hn[i] == 0), (i, p is None, hn[i])
+        if p is not None:
+            found += 1
+            np.testing.assert_allclose(hp[i, 0], p[0], atol=1e-12)
+            np.testing.assert_allclose(hp[i, hn[i] - 1], p[-1], atol=1e-12)
+    m.close()
+    assert inside >= 20 and found >= 40, (inside, found)
