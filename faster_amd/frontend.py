@@ -23,6 +23,12 @@ def lib():
         L.ff_decompose.argtypes = [vp, i32, vp, i32, vp, f64, f64, vp, i32, vp, vp]
         L.ff_plan.restype = i32
         L.ff_plan.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, vp, i32]
+        L.ff_set_search_mode.restype = i32
+        L.ff_set_search_mode.argtypes = [i32]
+        L.ff_plan_jps.restype = i32
+        L.ff_plan_jps.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, vp, i32, vp, vp]
+        L.ff_jps_tables.restype = None
+        L.ff_jps_tables.argtypes = [vp, vp, vp]
         L.ff_plan_batch.restype = i32
         L.ff_plan_batch.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp]
         L.ff_corridor_batch.restype = i32
@@ -58,6 +64,34 @@ def plan(cloud, cells, res, center, z_ground, z_max, inflation, start, goal, max
     if k < 0:
         raise RuntimeError("max_points too small")
     return out[:k].copy() if k > 0 else None
+
+
+def plan_jps(cloud, cells, res, center, z_ground, z_max, inflation, start, goal, max_points=4096):
+    """JPS_Manager::solveJPS3D with jps3d's own jump point search order (plan_path_jps). -> (path [k, 3] or None, raw cost [m], expansions)"""
+    import ctypes
+
+    cloud = _c(cloud).reshape(-1, 3)
+    out = np.zeros((max_points, 3))
+    cost, ex = ctypes.c_double(0.0), ctypes.c_longlong(0)
+    k = lib().ff_plan_jps(abi.ptr(cloud) if len(cloud) else None, len(cloud), int(cells[0]), int(cells[1]), int(cells[2]), res, abi.ptr(_c(center)),
+                          z_ground, z_max, inflation, abi.ptr(_c(start)), abi.ptr(_c(goal)), abi.ptr(out), max_points, ctypes.byref(cost), ctypes.byref(ex))
+    if k < 0:
+        raise RuntimeError("max_points too small")
+    return (out[:k].copy() if k > 0 else None), cost.value, ex.value
+
+
+def set_search(mode):
+    """Which search plan_batch / forest_batch(front="host") run: "astar" (default: the total-order A* the device search reproduces bit for
+    bit) or "jps" (jump point search in jps3d's own order: the path FASTER itself gets)."""
+    if lib().ff_set_search_mode({"astar": 0, "jps": 1}[mode]) != 0:
+        raise ValueError(mode)
+
+
+def jps_tables():
+    """The neighbour tables plan_path_jps generates, in the layout of jps3d's JPS3DNeib."""
+    ns, f1, f2 = np.zeros((27, 3, 26), dtype=np.int32), np.zeros((27, 3, 12), dtype=np.int32), np.zeros((27, 3, 12), dtype=np.int32)
+    lib().ff_jps_tables(abi.ptr(ns), abi.ptr(f1), abi.ptr(f2))
+    return ns, f1, f2
 
 
 def plan_batch(cloud, cells, res, center, z_ground, z_max, inflation, starts, goals, max_points=64, max_vertex_dist=0.0, max_poly=0,

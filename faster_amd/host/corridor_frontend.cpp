@@ -155,10 +155,303 @@ bool plan_path(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double in
   return true;
 }
 
+// =====================================================================================================================
+// Jump point search with jps3d's own expansion order (what FASTER runs: planner_ptr_->plan(start, goal, 1, true),
+// faster/src/jps_manager.cpp:166 -> thirdparty/jps3d/src/jps_planner/graph_search.cpp:123-470).
+//
+// plan_path() above finds AN optimal path with a total order of its own; jps3d finds the optimal path that its pruning rules, the
+// order in which it generates successors, its tolerance comparator (graph_search.h:19-29: f within 1e-6 => smaller g first) and
+// the sift discipline of its binary heap select — FASTER's corridors are built around THAT path.  plan_path_jps() reproduces all
+// four, so that the cleaned vertex list is jps3d's (checked vertex for vertex against the reference's own compiled sources in
+// tests/test_ref_frontend.py).  The neighbour tables are generated from the geometric rules below, not tabulated; the test compares
+// them entry by entry with the reference's JPS3DNeib.
+namespace {
+
+struct JpsTables {
+  // per direction id = (dx+1) + 3 (dy+1) + 9 (dz+1): natural neighbours ns, cells to test f1, directions to add when forced f2
+  int ns[27][26][3], f1[27][12][3], f2[27][12][3];
+};
+const int kJpsCount[4][2] = {{26, 0}, {1, 8}, {3, 12}, {7, 12}};  // by |d|_1: natural neighbours, forced-neighbour entries
+
+JpsTables make_jps_tables() {
+  JpsTables T;
+  std::memset(&T, 0, sizeof(T));
+  const int seq[3] = {0, 1, -1};
+  for (int dz = -1; dz <= 1; dz++)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int id = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+        const int d[3] = {dx, dy, dz};
+        const int norm1 = std::abs(dx) + std::abs(dy) + std::abs(dz);
+        auto put = [](int (*arr)[3], int k, int x, int y, int z) { arr[k][0] = x; arr[k][1] = y; arr[k][2] = z; };
+        if (norm1 == 0) {  // the start node: all 26 neighbours, z = 0 plane first; inside a plane y then x in the order 0, +1, -1
+          int k = 0;
+          for (int zi = 0; zi < 3; zi++)
+            for (int yi = 0; yi < 3; yi++)
+              for (int xi = 0; xi < 3; xi++)
+                if (seq[xi] || seq[yi] || seq[zi]) put(T.ns[id], k++, seq[xi], seq[yi], seq[zi]);
+        } else if (norm1 == 1) {  // straight: the move itself; forced: the 8 cells around the axis, (u, v) in a fixed order
+          put(T.ns[id], 0, dx, dy, dz);
+          const int uv[8][2] = {{0, 1}, {0, -1}, {1, 0}, {1, 1}, {1, -1}, {-1, 0}, {-1, 1}, {-1, -1}};
+          for (int k = 0; k < 8; k++) {
+            int f[3];
+            if (dz) { f[0] = uv[k][0]; f[1] = uv[k][1]; f[2] = 0; }        // move along z: (u, v) = (x, y)
+            else if (dx) { f[0] = 0; f[1] = uv[k][1]; f[2] = uv[k][0]; }   // along x: u -> z, v -> y
+            else { f[0] = uv[k][0]; f[1] = 0; f[2] = uv[k][1]; }           // along y: u -> x, v -> z
+            put(T.f1[id], k, f[0], f[1], f[2]);
+            put(T.f2[id], k, f[0] + dx, f[1] + dy, f[2] + dz);
+          }
+        } else if (norm1 == 2) {  // diagonal in a plane: in-plane axes p < q (x before y before z), c the axis across the plane
+          const int c = dx == 0 ? 0 : (dy == 0 ? 1 : 2);
+          const int p_ = c == 0 ? 1 : 0, q_ = c == 2 ? 1 : 2;
+          auto vec = [&](int ap, int aq, int ac, int out[3]) { out[0] = out[1] = out[2] = 0; out[p_] = ap; out[q_] = aq; out[c] = ac; };
+          int v[3];
+          vec(0, d[q_], 0, v); put(T.ns[id], 0, v[0], v[1], v[2]);
+          vec(d[p_], 0, 0, v); put(T.ns[id], 1, v[0], v[1], v[2]);
+          put(T.ns[id], 2, dx, dy, dz);
+          // entries 0-1: in the plane; 2-3: across; 4-7: across and behind one component; 8-11: across, one component ahead
+          const int F[12][3] = {{0, -1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}, {0, -1, 1}, {-1, 0, 1}, {0, -1, -1}, {-1, 0, -1},
+                                {0, 0, 1}, {0, 0, 1}, {0, 0, -1}, {0, 0, -1}};   // (p, q, c) in units of (d_p, d_q, 1)
+          const int G[12][3] = {{1, -1, 0}, {-1, 1, 0}, {1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {-1, 1, 1}, {1, -1, -1}, {-1, 1, -1},
+                                {1, 0, 1}, {0, 1, 1}, {1, 0, -1}, {0, 1, -1}};
+          for (int k = 0; k < 12; k++) {
+            vec(F[k][0] * d[p_], F[k][1] * d[q_], F[k][2], v); put(T.f1[id], k, v[0], v[1], v[2]);
+            vec(G[k][0] * d[p_], G[k][1] * d[q_], G[k][2], v); put(T.f2[id], k, v[0], v[1], v[2]);
+          }
+        } else {  // diagonal in space: the three axis moves, the three plane diagonals, the move itself
+          const int M[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+          for (int k = 0; k < 7; k++) put(T.ns[id], k, M[k][0] * dx, M[k][1] * dy, M[k][2] * dz);
+          // forced: cells behind one component (0-2), behind two (3-5), and the "extras" (6-11); in units of (dx, dy, dz)
+          const int F[12][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, -1, -1}, {-1, 0, -1}, {-1, -1, 0},
+                                {-1, 0, 0}, {-1, 0, 0}, {0, -1, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, -1}};
+          const int G[12][3] = {{-1, 1, 1}, {1, -1, 1}, {1, 1, -1}, {1, -1, -1}, {-1, 1, -1}, {-1, -1, 1},
+                                {-1, 0, 1}, {-1, 1, 0}, {0, -1, 1}, {1, -1, 0}, {0, 1, -1}, {1, 0, -1}};
+          for (int k = 0; k < 12; k++) {
+            put(T.f1[id], k, F[k][0] * dx, F[k][1] * dy, F[k][2] * dz);
+            put(T.f2[id], k, G[k][0] * dx, G[k][1] * dy, G[k][2] * dz);
+          }
+        }
+      }
+  return T;
+}
+const JpsTables& jps_tables() {
+  static const JpsTables T = make_jps_tables();
+  return T;
+}
+
+struct JpsSearch {
+  const VoxelGrid& grid;
+  const JpsTables& T;
+  int gx, gy, gz;  // goal cell
+  std::vector<double> g, h;
+  std::vector<int> parent, heap_pos;
+  std::vector<signed char> dir;  // [3 * id]
+  std::vector<char> seen, opened, closed;
+  std::vector<int> heap;
+
+  JpsSearch(const VoxelGrid& gr) : grid(gr), T(jps_tables()) {
+    const size_t n = (size_t)gr.nx * gr.ny * gr.nz;
+    g.assign(n, std::numeric_limits<double>::infinity());
+    h.assign(n, 0.0);
+    parent.assign(n, -1);
+    heap_pos.assign(n, -1);
+    dir.assign(3 * n, 0);
+    seen.assign(n, 0); opened.assign(n, 0); closed.assign(n, 0);
+  }
+  bool is_free(int x, int y, int z) const { return grid.is_free(x, y, z); }
+  bool is_occupied(int x, int y, int z) const {  // inside the map AND not free (graph_search.cpp:63-66): outside is neither
+    return !grid.outside(x, y, z) && grid.occ[grid.index(x, y, z)] > 0;
+  }
+  double heur(int x, int y, int z) const {  // graph_search.cpp:72-74 (eps = 1)
+    return std::sqrt((double)((x - gx) * (x - gx) + (y - gy) * (y - gy) + (z - gz) * (z - gz)));
+  }
+  // ---- the binary heap of boost::heap::d_ary_heap<arity 2, mutable> with jps3d's comparator ----
+  bool lower(int a, int b) const {  // compare_state: true = a has LOWER priority than b
+    const double fa = g[a] + h[a], fb = g[b] + h[b];
+    if (fa >= fb - 0.000001 && fa <= fb + 0.000001) return g[a] < g[b];
+    return fa > fb;
+  }
+  void swap_nodes(int i, int j) {
+    std::swap(heap[i], heap[j]);
+    heap_pos[heap[i]] = i;
+    heap_pos[heap[j]] = j;
+  }
+  void sift_up(int i) {
+    while (i != 0) {
+      const int p = (i - 1) / 2;
+      if (!lower(heap[p], heap[i])) return;
+      swap_nodes(p, i);
+      i = p;
+    }
+  }
+  void sift_down(int i) {
+    for (;;) {
+      const int first = 2 * i + 1;
+      if (first >= (int)heap.size()) return;
+      int best = first;
+      if (first + 1 < (int)heap.size() && lower(heap[best], heap[first + 1])) best = first + 1;
+      if (lower(heap[best], heap[i])) return;
+      swap_nodes(best, i);
+      i = best;
+    }
+  }
+  void push(int id) {
+    heap.push_back(id);
+    heap_pos[id] = (int)heap.size() - 1;
+    sift_up((int)heap.size() - 1);
+  }
+  int pop() {
+    const int top = heap.front();
+    swap_nodes(0, (int)heap.size() - 1);
+    heap.pop_back();
+    heap_pos[top] = -1;
+    if (!heap.empty()) sift_down(0);
+    return top;
+  }
+  bool has_forced(int x, int y, int z, int dx, int dy, int dz) const {  // graph_search.cpp:417-470: 8 / 8 / 6 cells by |d|_1
+    const int norm1 = std::abs(dx) + std::abs(dy) + std::abs(dz), id = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
+    const int count = norm1 == 3 ? 6 : (norm1 >= 1 ? 8 : 0);
+    for (int fn = 0; fn < count; fn++)
+      if (is_occupied(x + T.f1[id][fn][0], y + T.f1[id][fn][1], z + T.f1[id][fn][2])) return true;
+    return false;
+  }
+  // graph_search.cpp:374-400.  (Iterative along the move itself — the reference's tail call — recursive into the lower-dimensional moves.)
+  bool jump(int x, int y, int z, int dx, int dy, int dz, int& nx, int& ny, int& nz) const {
+    const int id = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1), norm1 = std::abs(dx) + std::abs(dy) + std::abs(dz);
+    const int num = kJpsCount[norm1][0];
+    nx = x; ny = y; nz = z;
+    for (;;) {
+      nx += dx; ny += dy; nz += dz;
+      if (!is_free(nx, ny, nz)) return false;
+      if (nx == gx && ny == gy && nz == gz) return true;
+      if (has_forced(nx, ny, nz, dx, dy, dz)) return true;
+      for (int k = 0; k < num - 1; k++) {
+        int ax, ay, az;
+        if (jump(nx, ny, nz, T.ns[id][k][0], T.ns[id][k][1], T.ns[id][k][2], ax, ay, az)) return true;
+      }
+    }
+  }
+};
+
+}  // namespace
+
+bool plan_path_jps(VoxelGrid& grid, const V3& start_in, const V3& goal_in, double inflation, std::vector<V3>& path, long long* expansions,
+                   double* raw_cost) {
+  path.clear();
+  const V3 start(start_in.x, start_in.y, std::max(start_in.z, 0.0)), goal(goal_in.x, goal_in.y, std::max(goal_in.z, 0.0));
+  int s[3], t[3];
+  grid.to_cell(start, s);
+  grid.to_cell(goal, t);
+  grid.set_free_around(s, inflation);  // jps_manager.cpp:161-162
+  grid.set_free_around(t, inflation);
+  if (!grid.is_free(s[0], s[1], s[2]) || !grid.is_free(t[0], t[1], t[2])) return false;  // jps_planner.cpp:214-239
+  JpsSearch js(grid);
+  js.gx = t[0]; js.gy = t[1]; js.gz = t[2];
+  const JpsTables& T = js.T;
+  const int sid = grid.index(s[0], s[1], s[2]), tid = grid.index(t[0], t[1], t[2]);
+  const int nxy = grid.nx * grid.ny;
+  js.g[sid] = 0.0;
+  js.h[sid] = js.heur(s[0], s[1], s[2]);
+  js.seen[sid] = 1;
+  js.push(sid);
+  js.opened[sid] = 1;
+  int cur;
+  for (;;) {  // graph_search.cpp:123-217
+    if (expansions) ++*expansions;
+    cur = js.pop();
+    js.closed[cur] = 1;
+    if (cur == tid) break;
+    const int cz = cur / nxy, rem = cur - cz * nxy, cy = rem / grid.nx, cx = rem - cy * grid.nx;
+    const int dx0 = js.dir[3 * cur], dy0 = js.dir[3 * cur + 1], dz0 = js.dir[3 * cur + 2];
+    const int norm1 = std::abs(dx0) + std::abs(dy0) + std::abs(dz0), id = (dx0 + 1) + 3 * (dy0 + 1) + 9 * (dz0 + 1);
+    const int num_neib = kJpsCount[norm1][0], num_fneib = kJpsCount[norm1][1];
+    for (int dev = 0; dev < num_neib + num_fneib; dev++) {  // getJpsSucc, :318-368, successor by successor
+      int nx, ny, nz, dx, dy, dz;
+      if (dev < num_neib) {
+        dx = T.ns[id][dev][0]; dy = T.ns[id][dev][1]; dz = T.ns[id][dev][2];
+        if (!js.jump(cx, cy, cz, dx, dy, dz, nx, ny, nz)) continue;
+      } else {
+        const int k = dev - num_neib;
+        if (!js.is_occupied(cx + T.f1[id][k][0], cy + T.f1[id][k][1], cz + T.f1[id][k][2])) continue;
+        dx = T.f2[id][k][0]; dy = T.f2[id][k][1]; dz = T.f2[id][k][2];
+        if (!js.jump(cx, cy, cz, dx, dy, dz, nx, ny, nz)) continue;
+      }
+      const int nid = grid.index(nx, ny, nz);
+      if (!js.seen[nid]) {
+        js.seen[nid] = 1;
+        js.dir[3 * nid] = (signed char)dx; js.dir[3 * nid + 1] = (signed char)dy; js.dir[3 * nid + 2] = (signed char)dz;
+        js.h[nid] = js.heur(nx, ny, nz);
+      }
+      const double cost = std::sqrt((double)((nx - cx) * (nx - cx) + (ny - cy) * (ny - cy) + (nz - cz) * (nz - cz)));
+      const double tentative = js.g[cur] + cost;  // :150-191
+      if (tentative < js.g[nid]) {
+        js.parent[nid] = cur;
+        js.g[nid] = tentative;
+        if (js.opened[nid] && !js.closed[nid]) {
+          js.sift_up(js.heap_pos[nid]);  // pq_.increase
+          auto sgn = [](int v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); };
+          js.dir[3 * nid] = (signed char)sgn(nx - cx); js.dir[3 * nid + 1] = (signed char)sgn(ny - cy); js.dir[3 * nid + 2] = (signed char)sgn(nz - cz);
+        } else if (!js.opened[nid]) {
+          js.push(nid);
+          js.opened[nid] = 1;
+        }  // (opened and closed: the reference prints "ASTAR ERROR!" and goes on)
+      }
+    }
+    if (js.heap.empty()) return false;
+  }
+  std::vector<V3> raw;
+  double cost = 0.0;
+  for (int id = tid;; id = js.parent[id]) {
+    const int cz = id / nxy, rem = id - cz * nxy, cy = rem / grid.nx, cx = rem - cy * grid.nx;
+    raw.push_back(grid.cell_center(cx, cy, cz));
+    if (id == sid || js.parent[id] < 0) break;
+  }
+  std::reverse(raw.begin(), raw.end());
+  for (size_t i = 1; i < raw.size(); i++) cost += (raw[i] - raw[i - 1]).norm();
+  if (raw_cost) *raw_cost = cost;
+  std::vector<V3> p = remove_corner_points(grid, remove_line_points(raw));  // jps_planner.cpp:283-291
+  std::reverse(p.begin(), p.end());
+  p = remove_corner_points(grid, p);
+  std::reverse(p.begin(), p.end());
+  if (p.size() > 1) {  // jps_manager.cpp:175-186: ends forced onto the requested points
+    p.front() = start;
+    p.back() = goal;
+  } else {
+    p.clear();
+    p.push_back(start);
+    p.push_back(goal);
+  }
+  path = p;
+  return true;
+}
+
+void jps_neighbour_tables(int* ns, int* f1, int* f2) {  // [27][3][26], [27][3][12], [27][3][12]: the layout of jps3d's JPS3DNeib
+  const JpsTables& T = jps_tables();
+  for (int id = 0; id < 27; id++)
+    for (int a = 0; a < 3; a++) {
+      for (int k = 0; k < 26; k++) ns[(id * 3 + a) * 26 + k] = T.ns[id][k][a];
+      for (int k = 0; k < 12; k++) { f1[(id * 3 + a) * 12 + k] = T.f1[id][k][a]; f2[(id * 3 + a) * 12 + k] = T.f2[id][k][a]; }
+    }
+}
+
 }  // namespace fhfront
 
 // ---- C wrapper (plain pointers) for tests and the Python workload generator -------------------------------------------
+// Which search the batch entry points below run: 0 (default) plan_path — A* with a total order, what the device search
+// (csrc/fh_path.hip.hpp) reproduces bit for bit; 1 plan_path_jps — jump point search in jps3d's own order, FASTER's exact path.
+static int g_search_mode = 0;
+static bool run_search(fhfront::VoxelGrid& g, const fhfront::V3& s, const fhfront::V3& t, double inflation, std::vector<fhfront::V3>& path,
+                       long long* expansions = nullptr) {
+  return g_search_mode == 1 ? fhfront::plan_path_jps(g, s, t, inflation, path, expansions) : fhfront::plan_path(g, s, t, inflation, path, expansions);
+}
+
 extern "C" {
+
+int ff_set_search_mode(int mode) {
+  if (mode != 0 && mode != 1) return -1;
+  g_search_mode = mode;
+  return 0;
+}
 
 // Decomposition of one path: writes the rows [a_x a_y a_z b] of polytope i to faces[face_off[i] .. face_off[i+1]).
 // Returns the total number of faces, or -1 if max_faces is too small.  ellipsoids (optional): per segment 15 doubles
@@ -215,6 +508,27 @@ int ff_plan(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y, int 
 }
 
 
+// jump point search with jps3d's expansion order (plan_path_jps): same arguments as ff_plan; raw_cost (optional): length of the raw
+// cell path in metres
+int ff_plan_jps(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y, int cells_z, double res, const double* center,
+                double z_ground, double z_max, double inflation, const double* start, const double* goal, double* path_xyz,
+                int max_points, double* raw_cost, long long* expansions) {
+  using namespace fhfront;
+  std::vector<V3> cloud;
+  for (int i = 0; i < n_cloud; i++) cloud.push_back(V3(cloud_xyz[3 * i], cloud_xyz[3 * i + 1], cloud_xyz[3 * i + 2]));
+  VoxelGrid g;
+  g.build(cloud, cells_x, cells_y, cells_z, res, V3(center[0], center[1], center[2]), z_ground, z_max, inflation);
+  std::vector<V3> path;
+  if (expansions) *expansions = 0;
+  if (!plan_path_jps(g, V3(start[0], start[1], start[2]), V3(goal[0], goal[1], goal[2]), inflation, path, expansions, raw_cost)) return 0;
+  if ((int)path.size() > max_points) return -1;
+  for (size_t i = 0; i < path.size(); i++) {
+    path_xyz[3 * i] = path[i].x; path_xyz[3 * i + 1] = path[i].y; path_xyz[3 * i + 2] = path[i].z;
+  }
+  return (int)path.size();
+}
+void ff_jps_tables(int* ns, int* f1, int* f2) { fhfront::jps_neighbour_tables(ns, f1, f2); }
+
 // Faster::createMoreVertexes (faster/src/faster.cpp:80-97: legs longer than `max_vertex_dist` are cut, each new vertex one
 // spacing beyond the previous one) and deleteVertexes (faster/src/utils.cpp:1117-1124: at most max_poly legs kept).
 // createMoreVertexes repeats the end point when a leg is an exact multiple of the spacing; the reference would then decompose a
@@ -260,8 +574,8 @@ int ff_plan_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y
     VoxelGrid g = base;  // the search frees the cells around start and goal
     std::vector<V3> path;
     long long ex = 0;
-    const bool ok = plan_path(g, V3(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), V3(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]),
-                              inflation, path, &ex);
+    const bool ok = run_search(g, V3(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), V3(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]),
+                               inflation, path, &ex);
     if (expansions) expansions[i] = ex;
     n_points[i] = 0;
     if (!ok) continue;
@@ -300,7 +614,7 @@ int ff_corridor_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cel
     std::vector<V3> path;
     const V3 s(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), t(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]);
     goal_out[3 * i] = t.x; goal_out[3 * i + 1] = t.y; goal_out[3 * i + 2] = t.z;
-    if (!plan_path(g, s, t, inflation, path)) continue;
+    if (!run_search(g, s, t, inflation, path)) continue;
     refine_vertices(path, max_vertex_dist, max_poly);
     const std::vector<LinearConstraint> cs = decompose_path(path, cloud, drone_radius, z_ground);
     int total = 0;

@@ -363,4 +363,10 @@ struct VoxelGrid {
 bool plan_path(VoxelGrid& grid, const V3& start, const V3& goal, double inflation, std::vector<V3>& path,
                long long* expansions = nullptr);
 
+// Jump point search with jps3d's own expansion order (successor order, tolerance comparator, binary-heap discipline): the path
+// FASTER itself would get from planner_ptr_->plan(start, goal, 1, true) (jps_manager.cpp:166).  corridor_frontend.cpp.
+bool plan_path_jps(VoxelGrid& grid, const V3& start, const V3& goal, double inflation, std::vector<V3>& path, long long* expansions = nullptr,
+                   double* raw_cost = nullptr);
+void jps_neighbour_tables(int* ns, int* f1, int* f2);
+
 }  // namespace fhfront

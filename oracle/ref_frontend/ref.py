@@ -41,6 +41,8 @@ def lib():
         L.ref_map_plan.restype = i32
         L.ref_map_plan.argtypes = [vp, vp, vp, i32, vp, i32, vp, vp]
         L.ref_frontend_sources.restype = ctypes.c_char_p
+        L.ref_jps3d_tables.restype = None
+        L.ref_jps3d_tables.argtypes = [vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -60,6 +62,13 @@ def decompose(path, cloud, drone_radius=0.05, z_ground=0.0, max_rows=256):
     if rc != 0:
         raise RuntimeError("max_rows too small")
     return [(rows[i, :counts[i], :3].copy(), rows[i, :counts[i], 3].copy()) for i in range(nseg)]
+
+
+def jps3d_tables():
+    """jps3d's JPS3DNeib tables (ns [27][3][26], f1 [27][3][12], f2 [27][3][12]) as the reference's constructor builds them."""
+    ns, f1, f2 = np.zeros((27, 3, 26), dtype=np.int32), np.zeros((27, 3, 12), dtype=np.int32), np.zeros((27, 3, 12), dtype=np.int32)
+    lib().ref_jps3d_tables(_p(ns), _p(f1), _p(f2))
+    return ns, f1, f2
 
 
 class Map:

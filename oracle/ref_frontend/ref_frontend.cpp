@@ -114,6 +114,14 @@ int ref_map_plan(RefMap* m, const double* start_sent, const double* goal_sent, i
   return (int)path.size();
 }
 
+// jps3d's neighbour tables as its constructor builds them (graph_search.cpp:573-937): ns [27][3][26], f1 / f2 [27][3][12]
+void ref_jps3d_tables(int* ns, int* f1, int* f2) {
+  JPS::JPS3DNeib jn;
+  std::memcpy(ns, jn.ns, sizeof(jn.ns));
+  std::memcpy(f1, jn.f1, sizeof(jn.f1));
+  std::memcpy(f2, jn.f2, sizeof(jn.f2));
+}
+
 const char* ref_frontend_sources(void) {
   return "DecompUtil decomp_util/{ellipsoid_decomp,line_segment,decomp_base}.h decomp_geometry/{ellipsoid,polyhedron,geometric_utils}.h; "
          "jps3d src/jps_planner/{graph_search,jps_planner}.cpp include/jps_collision/map_util.h — untouched, from /root/reference/thirdparty";

@@ -226,3 +226,67 @@ def test_start_and_goal_inside_the_inflated_obstacles(ref):
             np.testing.assert_allclose(hp[i, hn[i] - 1], p[-1], atol=1e-12)
     m.close()
     assert inside >= 20 and found >= 40, (inside, found)
+
+
+# ---- jump point search in jps3d's own order (fhfront::plan_path_jps): FASTER's exact path ------------------------------------------
+def test_jps_neighbour_tables_equal_jps3d(ref):
+    """The tables plan_path_jps GENERATES from geometric rules (natural neighbours, cells to test, directions to add per move) equal
+    the ones jps3d's JPS3DNeib constructor writes down case by case (graph_search.cpp:573-937), entry by entry in the same order —
+    the order decides in which sequence successors reach the open list, hence which of several equal-cost paths is found."""
+    a, b = ref.jps3d_tables(), frontend.jps_tables()
+    count = {0: (26, 0), 1: (1, 8), 2: (3, 12), 3: (7, 12)}
+    for idx in range(27):
+        d = (idx % 3 - 1, (idx // 3) % 3 - 1, idx // 9 - 1)
+        nn, nf = count[abs(d[0]) + abs(d[1]) + abs(d[2])]
+        assert np.array_equal(a[0][idx, :, :nn], b[0][idx, :, :nn]), ("ns", d)
+        assert np.array_equal(a[1][idx, :, :nf], b[1][idx, :, :nf]), ("f1", d)
+        assert np.array_equal(a[2][idx, :, :nf], b[2][idx, :, :nf]), ("f2", d)
+
+
+@pytest.mark.parametrize("seed,res,inflation,n", [(3, 0.2, 0.3, 400), (4, 0.25, 0.25, 200), (5, 0.15, 0.3, 120)])
+def test_jps_vertex_lists_equal_jps3d(ref, seed, res, inflation, n):
+    """plan_path_jps against the reference's compiled graph_search.cpp / jps_planner.cpp driven as solveJPS3D drives them: the same
+    raw cost and the same cleaned vertex list, vertex for vertex and bit for bit, for every query (jump point pruning, the
+    successor order, the tolerance comparator f within 1e-6 => smaller g first, the sift discipline of the binary heap, the path
+    clean-up).  This is the path FASTER feeds its decomposition."""
+    cloud, cells, center, starts, goals = forest(seed, n, res=res, inflation=inflation)
+    zg, zmax = 0.0, 3.0
+    m = ref.Map(cloud, cells, res, center, zg, zmax, inflation)
+    found = 0
+    for i in range(n):
+        p, cost, _ = m.plan(starts[i], goals[i], True)
+        hp, hcost, hex_ = frontend.plan_jps(cloud, cells, res, center, zg, zmax, inflation, starts[i], goals[i])
+        assert (p is None) == (hp is None), i
+        if p is None:
+            continue
+        found += 1
+        assert len(p) == len(hp) and np.array_equal(p, hp), (i, len(p), len(hp))
+        assert hcost == pytest.approx(cost, abs=1e-9)
+    m.close()
+    assert found >= 0.95 * n
+
+
+def test_jps_vertex_lists_equal_jps3d_inside_the_inflated_obstacles(ref):
+    """The same for queries that start or end inside the inflated hull of a tree (the cells freed around start and goal matter)."""
+    cloud, centres = frontend.forest_cloud(3)
+    cloud = cloud.astype(np.float32).astype(np.float64)
+    res, zg, zmax, infl = 0.2, 0.0, 3.0, 0.3
+    cells, center = (110, 110, 15), np.array([10.0, 10.0, 1.5])
+    rng = np.random.default_rng(12)
+    n = 96
+    ang = rng.uniform(0, 2 * np.pi, n)
+    near = centres[rng.integers(0, len(centres), n)] + np.column_stack([np.cos(ang), np.sin(ang)]) * rng.uniform(0.40, 0.75, (n, 1))
+    starts = np.column_stack([near, rng.uniform(0.8, 2.2, n)])
+    goals = np.column_stack([rng.uniform(2, 18, n), rng.uniform(2, 18, n), rng.uniform(0.8, 2.2, n)])
+    starts[n // 2:], goals[n // 2:] = goals[n // 2:].copy(), starts[n // 2:].copy()
+    m = ref.Map(cloud, cells, res, center, zg, zmax, infl)
+    found = 0
+    for i in range(n):
+        p, cost, _ = m.plan(starts[i], goals[i], True)
+        hp, hcost, _ = frontend.plan_jps(cloud, cells, res, center, zg, zmax, infl, starts[i], goals[i])
+        assert (p is None) == (hp is None), i
+        if p is not None:
+            found += 1
+            assert len(p) == len(hp) and np.array_equal(p, hp), i
+    m.close()
+    assert found >= 40
