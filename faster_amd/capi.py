@@ -23,6 +23,7 @@ SYMBOLS = [
     "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
+    "fh_packed_result_size", "fh_pack_results_device", "fh_pack_results", "fh_unpack_results",
 ]
 
 _LIB = None
@@ -30,6 +31,30 @@ _LIB = None
 
 class FasterHipError(RuntimeError):
     pass
+
+
+def packed_result_size(n_seg):
+    return int(lib().fh_packed_result_size(int(n_seg)))
+
+
+def pack_results(results, n_seg):
+    """numpy array of fh_result records -> uint8 array of packed records (host side)."""
+    results = np.ascontiguousarray(results)
+    out = np.zeros(len(results) * packed_result_size(n_seg), dtype=np.uint8)
+    rc = lib().fh_pack_results(abi.ptr(results), len(results), int(n_seg), abi.ptr(out))
+    if rc != 0:
+        raise FasterHipError("fh_pack_results: rc=%d" % rc)
+    return out
+
+
+def unpack_results(packed, n, n_seg):
+    """Packed records (bytes-like / uint8 array) -> numpy array of fh_result records (host side, no device needed)."""
+    buf = np.ascontiguousarray(np.frombuffer(packed, dtype=np.uint8) if not isinstance(packed, np.ndarray) else packed.view(np.uint8).reshape(-1))
+    out = np.zeros(n, dtype=abi.result_dtype)
+    rc = lib().fh_unpack_results(abi.ptr(buf), n, int(n_seg), abi.ptr(out))
+    if rc != 0:
+        raise FasterHipError("fh_unpack_results: rc=%d" % rc)
+    return out
 
 
 def lib():
@@ -62,6 +87,14 @@ def lib():
         L.fh_set_pair_margin.argtypes = [vp, f64]
         L.fh_set_pair_rule.restype = i32
         L.fh_set_pair_rule.argtypes = [vp, vp]
+        L.fh_packed_result_size.restype = ctypes.c_size_t
+        L.fh_packed_result_size.argtypes = [i32]
+        L.fh_pack_results_device.restype = i32
+        L.fh_pack_results_device.argtypes = [vp, vp, i32, i32, vp]
+        L.fh_unpack_results.restype = i32
+        L.fh_unpack_results.argtypes = [vp, i32, i32, vp]
+        L.fh_pack_results.restype = i32
+        L.fh_pack_results.argtypes = [vp, i32, i32, vp]
         L.fh_request_stop.restype = i32
         L.fh_request_stop.argtypes = [vp]
         L.fh_clear_stop.restype = i32
@@ -333,6 +366,10 @@ class Context:
         r = np.zeros(1, dtype=abi.pair_rule_dtype)
         r["mode"], r["r_known"], r["drone_radius"], r["delta_h"], r["delta_a"] = mode, r_known, drone_radius, delta_h, delta_a
         self._check(lib().fh_set_pair_rule(self._h, abi.ptr(r)), "fh_set_pair_rule")
+
+    def pack_results_device(self, d_results, n, n_seg, d_packed):
+        """fh_pack_results_device: n fh_result records -> n packed records of packed_result_size(n_seg) bytes (device pointers)."""
+        self._check(lib().fh_pack_results_device(self._h, d_results, n, n_seg, d_packed), "fh_pack_results_device")
 
     def request_stop(self):
         """StopExecution(): callable from any thread while a launch is running."""

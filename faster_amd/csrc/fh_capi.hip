@@ -206,7 +206,62 @@ static int check_share_error(fh_ctx* ctx) {
   return FH_OK;
 }
 
+// packed results: the words of an fh_result without the coefficient rows beyond n_seg (one thread per 8-byte word of the output)
+__global__ void __launch_bounds__(256) pack_results_kernel(const double* __restrict__ in, double* __restrict__ out, long long total_words,
+                                                           int words_out, int coeff_words) {
+  const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= total_words) return;
+  const long long r = w / words_out;
+  const int k = (int)(w - r * words_out);
+  constexpr int WORDS_IN = (int)(sizeof(fh_result) / 8), HEAD = 6, TAIL0 = WORDS_IN - 2;
+  const int src = k < HEAD + coeff_words ? k : TAIL0 + (k - HEAD - coeff_words);
+  out[w] = in[r * WORDS_IN + src];
+}
+
 extern "C" {
+
+size_t fh_packed_result_size(int n_seg) { return (n_seg < 1 || n_seg > FH_MAX_SEG) ? 0 : (size_t)(64 + 96 * n_seg); }
+
+int fh_pack_results_device(fh_ctx* ctx, const fh_result* d_results, int n, int n_seg, void* d_packed) {
+  if (!ctx || n < 0 || n_seg < 1 || n_seg > FH_MAX_SEG) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_results || !d_packed) return FH_ERR_ARG;
+  const int words_out = (int)(fh_packed_result_size(n_seg) / 8);
+  const long long total = (long long)n * words_out;
+  hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const double*>(d_results), reinterpret_cast<double*>(d_packed), total, words_out, 12 * n_seg);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_pack_results(const fh_result* results, int n, int n_seg, void* packed) {
+  if (n < 0 || n_seg < 1 || n_seg > FH_MAX_SEG || (n > 0 && (!packed || !results))) return FH_ERR_ARG;
+  const size_t rec = fh_packed_result_size(n_seg);
+  unsigned char* p = static_cast<unsigned char*>(packed);
+  for (int i = 0; i < n; i++, p += rec) {
+    const fh_result& r = results[i];
+    std::memcpy(p, &r, 48);
+    std::memcpy(p + 48, &r.coeff[0][0], (size_t)96 * n_seg);
+    std::memcpy(p + 48 + (size_t)96 * n_seg, &r.assign[0], 16);
+  }
+  return FH_OK;
+}
+
+int fh_unpack_results(const void* packed, int n, int n_seg, fh_result* results) {
+  if (n < 0 || n_seg < 1 || n_seg > FH_MAX_SEG || (n > 0 && (!packed || !results))) return FH_ERR_ARG;
+  const size_t rec = fh_packed_result_size(n_seg);
+  const unsigned char* p = static_cast<const unsigned char*>(packed);
+  for (int i = 0; i < n; i++, p += rec) {
+    fh_result& r = results[i];
+    std::memset(&r, 0, sizeof(r));
+    std::memcpy(&r, p, 48);
+    std::memcpy(&r.coeff[0][0], p + 48, (size_t)96 * n_seg);
+    std::memcpy(&r.assign[0], p + 48 + (size_t)96 * n_seg, 16);
+  }
+  return FH_OK;
+}
 
 const char* fh_version(void) { return "fasterhip 0.2 gfx950"; }
 

@@ -145,6 +145,18 @@ int fh_set_params(fh_ctx* ctx, const fh_params* p);
  * the previous one.  Use one context per concurrent pipeline (as bench.py does). */
 int fh_set_stream(fh_ctx* ctx, void* hip_stream);
 
+/* Packed results: what crosses PCIe / xGMI.  An fh_result holds FH_MAX_SEG = 16 coefficient rows whatever n_seg is (1600 B; at
+ * N = 10, 576 B of it are dead rows).  A packed record is the same words without the rows beyond n_seg:
+ *   [ the 48-byte head: solved .. cost | coeff[0 .. n_seg-1][12] | assign[16] ]  =  64 + 96 n_seg bytes  (N = 10: 1024 B).
+ * Lossless: fh_unpack_results() restores the fh_result records exactly (dead rows zero, as the kernels write them). */
+size_t fh_packed_result_size(int n_seg);
+/* d_results [n] fh_result -> d_packed [n] packed records; device pointers, asynchronous on the context stream */
+int fh_pack_results_device(fh_ctx* ctx, const fh_result* d_results, int n, int n_seg, void* d_packed);
+/* host side (no device needed): full records -> packed records, and back */
+int fh_pack_results(const fh_result* results, int n, int n_seg, void* packed);
+int fh_unpack_results(const void* packed, int n, int n_seg, fh_result* results);
+
+
 /* Scheduling of a solve launch: how the persistent workgroups order and share the work of a batch.  NO RESULT FIELD DEPENDS ON
  * ANY OF THESE (tests/test_gpu_round2.py solves 8192 pairs with each of them switched off and compares bit for bit); only
  * nodes / qp_iters / kflops, which count the work actually done, and the time a launch takes.  Defaults: fh_default_sched(). */

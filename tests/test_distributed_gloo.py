@@ -57,6 +57,23 @@ if rank == 0:
     weak = shard.unpad_gathered(torch.cat(g_weak[1]).numpy(), len(pr), world, abi.result_dtype)
     for f in abi.result_dtype.names:
         assert np.array_equal(weak[f], full[f]), ("gather", f)
+# the PACKED layout bench.py gathers (fh_pack_results: no dead coefficient rows, 64 + 96 N bytes per record): lossless
+from faster_amd import capi
+PK = capi.packed_result_size(6)
+assert PK == 64 + 96 * 6
+pblk = torch.from_numpy(capi.pack_results(pad, 6))
+gp = [torch.zeros(world * per * PK, dtype=torch.uint8) for _ in range(2)]
+shard.gather_result_blocks(dist, pblk, pblk, gp, True, rank)
+unpacked = capi.unpack_results(gp[0].numpy(), world * per, 6)
+everything_p = shard.unpad_gathered(unpacked.view(np.uint8), len(pr), world, abi.result_dtype)
+for f in abi.result_dtype.names:
+    assert np.array_equal(everything_p[f], full[f]), ("packed all_gather", f)
+gpw = [[torch.zeros(per * PK, dtype=torch.uint8) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+shard.gather_result_blocks(dist, pblk, pblk, gpw, False, rank)
+if rank == 0:
+    weak_p = shard.unpad_gathered(capi.unpack_results(torch.cat(gpw[0]).numpy(), world * per, 6).view(np.uint8), len(pr), world, abi.result_dtype)
+    for f in abi.result_dtype.names:
+        assert np.array_equal(weak_p[f], full[f]), ("packed gather", f)
 if rank == 0:
     got = np.concatenate([g[r * per: r * per + (shard.shard_range(len(pr), r, world)[1] - shard.shard_range(len(pr), r, world)[0])].numpy() for r in range(world)])
     assert got.shape[0] == len(pr)

@@ -295,3 +295,27 @@ def test_reference_rule_for_r_on_the_device(ctx, oracle, n_seg, p_choices, r_kno
     oks = compare(sres[live], sref)
     # R was chosen so that the vehicle can still brake: far more safe problems have a solution than with R at half of the trajectory
     assert oks.mean() > 0.85, oks.mean()
+
+
+def test_packed_results_are_lossless(ctx):
+    """fh_pack_results_device: the records that cross PCIe / xGMI (no dead coefficient rows: 64 + 96 N bytes instead of 1600) unpack
+    to exactly the fh_result records of the launch, for every kernel size; the host-side packer agrees byte for byte."""
+    import torch
+
+    for n_seg in (6, 10, 15, 16):
+        pr, faces, _ = corridor.whole_batch(257, seed=600 + n_seg, n_seg=n_seg, p_choices=(2, 3))
+        d_pr, d_fc = _dev(pr), _dev(faces)
+        d_res = torch.zeros(len(pr) * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+        mf = int(pr["face_off"][np.arange(len(pr)), pr["n_poly"]].max())
+        ctx.solve_batch_device(d_pr.data_ptr(), d_fc.data_ptr(), len(pr), n_seg, mf, d_res.data_ptr())
+        pk = capi.packed_result_size(n_seg)
+        assert pk == 64 + 96 * n_seg
+        d_pack = torch.zeros(len(pr) * pk, dtype=torch.uint8, device="cuda:0")
+        ctx.pack_results_device(d_res.data_ptr(), len(pr), n_seg, d_pack.data_ptr())
+        ctx.sync()
+        full = d_res.cpu().numpy().view(abi.result_dtype)
+        packed = d_pack.cpu().numpy()
+        back = capi.unpack_results(packed, len(pr), n_seg)
+        assert full["solved"].sum() > 100
+        assert np.array_equal(back.view(np.uint8), np.ascontiguousarray(full).view(np.uint8))
+        assert np.array_equal(capi.pack_results(full, n_seg), packed)
