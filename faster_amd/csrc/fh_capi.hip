@@ -104,7 +104,9 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   const size_t lds = SV::lds_bytes(ka.max_faces);
   auto kern = fh::solve_kernel<NSEG, PAIRS>;
   // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU)
-  int per_cu = (int)std::min<size_t>(FH_WAVES_PER_SIMD * 4, (160 * 1024) / lds);
+  // LDS is handed out in granules of 1280 B (residency census on MI355X: 14 080 B admit 11 workgroups per CU, 14 336 B only 10)
+  const size_t lds_alloc = (lds + 1279) / 1280 * 1280;
+  int per_cu = (int)std::min<size_t>(FH_WAVES_PER_SIMD * 4, (160 * 1024) / lds_alloc);
   if (per_cu < 1) per_cu = 1;
   const int resident = ctx->n_cu * per_cu;
   const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;

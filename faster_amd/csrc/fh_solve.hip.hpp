@@ -318,7 +318,8 @@ struct Solver {
   double *Pc, *Vc, *Ac;                               // [NT*3] current states at segment starts
   double* viol;                                       // [NSEG][FH_MAX_POLY]
   double* xfl;                                        // [9] goal state (+3 pad)
-  double* tolf;                                       // [n_faces] feas_tol / |a_f|
+  float* tolf;                                        // [n_faces] feas_tol / |a_f| (added to the scaled violation of the row that is selected:
+                                                      //           ~1e-9, so a float's relative 6e-8 is 1e-16 absolute)
   fh_face* faces;                                     // [n_faces] NORMALISED rows: a/|a| and bt = -(b + feas_tol)/|a|, so that
                                                       //           a.cp + bt > 0  <=>  the original row is violated by more than feas_tol
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *face_off;
@@ -329,9 +330,11 @@ struct Solver {
   signed char* stk_order;                             // [NSEG][FH_MAX_POLY] child order per tree level
 
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
-    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 3 * NVP + NXP + NSEG * ZS + 3 * NT * 3 + 12) +
-           sizeof(int) * (9 * NSEG + FH_MAX_POLY + 1 + 3 + TB_WORDS) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
-           (sizeof(fh_face) + sizeof(double)) * max_faces + 32;
+    // (the hardware hands out LDS in granules of 1280 B — measured with a residency census: 14 080 B admit 11 workgroups per CU,
+    // 14 336 B only 10 — so every few hundred bytes of this carve decide a wavefront per CU)
+    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 2 * NVP + NXP + NSEG * ZS + 3 * NT * 3 + 12) +
+           sizeof(int) * (8 * NSEG + FH_MAX_POLY + 1 + TB_WORDS) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
+           (sizeof(fh_face) + sizeof(float)) * max_faces + 16;
   }
 
   // ---- per-lane state kept in registers (LDS is what limits the number of resident solves) ----
@@ -376,12 +379,15 @@ struct Solver {
     x = p; p += NVP;  u = p; p += NVP;  rinv = p; p += NVP;
     act = reinterpret_cast<int*>(p); p += NVP / 2;
     // ---- end of the snapshot block ----
-    z = p; p += NVP;  g = p; p += NVP;  d = p; p += NVP;  r = d;
+    g = p; p += NVP;  d = p; p += NVP;  r = d;
     xs = p; p += NXP;
+    z = xs;  // the remainder kept for the re-orthogonalisation pass lives where the x-space scratch does: xs is dead between the
+             // reduction of a row normal (build_g) and the next compute_states
+    static_assert(NXP >= NVP, "z aliases xs");
     Zm = p; p += NSEG * ZS;
     Pc = p; p += NT * 3;  Vc = p; p += NT * 3;  Ac = p; p += NT * 3;
-    viol = z;  // [NSEG][FH_MAX_POLY] aliases z,g,d,xs: only live between two active-set runs (analyze)
-    static_assert(NSEG * FH_MAX_POLY <= 3 * NVP + NXP && 9 <= NVP, "scratch must fit in z,g,d,xs");
+    viol = g;  // [NSEG][FH_MAX_POLY] aliases g,d,xs: only live between two active-set runs (analyze)
+    static_assert(NSEG * FH_MAX_POLY <= 2 * NVP + NXP && 9 <= NVP, "scratch must fit in g,d,xs");
     xfl = p; p += 12;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
@@ -391,7 +397,7 @@ struct Solver {
     stk_order = reinterpret_cast<signed char*>(ip);
     const size_t off = (size_t)(reinterpret_cast<unsigned char*>(ip) - base) + NSEG * FH_MAX_POLY;
     faces = reinterpret_cast<fh_face*>(base + ((off + 15) & ~(size_t)15));  // [max_faces] 32-B rows, read 16 B at a time
-    tolf = reinterpret_cast<double*>(faces + max_faces);
+    tolf = reinterpret_cast<float*>(faces + max_faces);
   }
 
   // ---- node state snapshots (HBM workspace, one slot per tree level; L2-resident in practice) ----
@@ -472,7 +478,7 @@ struct Solver {
     const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     for (int i = lane; i < NVP * S; i += 64) Q[i] = 0.0;
     for (int i = lane; i < RPSZ; i += 64) R[i] = 0.0;
-    if (lane < NVP) { x[lane] = 0; z[lane] = 0; g[lane] = 0; d[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
+    if (lane < NVP) { x[lane] = 0; g[lane] = 0; d[lane] = 0; u[lane] = 0; rinv[lane] = 0; act[lane] = 0; }
     if (lane < NXP) xs[lane] = 0;
     q = 0;
     FH_SYNC();
@@ -566,7 +572,7 @@ struct Solver {
 #pragma unroll
       for (int l = 0; l < 3; l++) {
         const double cl = E[l * 3 + 0] * rho[0] + E[l * 3 + 1] * rho[1] + E[l * 3 + 2] * rho[2];
-        if (lane < 3) z[l * 3 + lane] = cl;  // (scratch: z is rewritten before it is read by the solver)
+        if (lane < 3) d[l * 3 + lane] = cl;  // (scratch: d is rewritten before it is read by the solver)
         if ((mask >> l) & 1) {
           const int kind = (l + koff) < 3 ? l + koff : 2;
           const double res = (kind == 0 ? hp[0] : (kind == 1 ? hp[1] : hp[2])) * (E[9 + l * 3 + 0] * rho[0] + E[9 + l * 3 + 1] * rho[1] + E[9 + l * 3 + 2] * rho[2]);
@@ -581,7 +587,7 @@ struct Solver {
       double xp = 0.0;
       if (lane < nx) {
         const int nl = N < 3 ? N : 3;
-        for (int l = 0; l < nl; l++) xp += Zm[s * ZS + l] * z[l * 3 + i];
+        for (int l = 0; l < nl; l++) xp += Zm[s * ZS + l] * d[l * 3 + i];
       }
       xpr = xp;
       if (lane < NXP) xs[lane] = xp;
@@ -732,7 +738,7 @@ struct Solver {
         if (wi == 0.0) bad = true;  // a row that does not depend on y (segment 0: control points 0..2; whole trajectory: 1..3 of the last segment) violated
         else {
           const double sc = bvt * wi;
-          if (sc > bs) { bs = sc; bv = bvt + tolf[f0 + bf]; bid = mk_id(K_POLY, t, k, bf); }
+          if (sc > bs) { bs = sc; bv = bvt + (double)tolf[f0 + bf]; bid = mk_id(K_POLY, t, k, bf); }
         }
       }
     }
@@ -2041,11 +2047,11 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
         const double inv = 1.0 / nr;
         fc.a[0] *= inv; fc.a[1] *= inv; fc.a[2] *= inv;
         fc.b = -(fc.b + par.feas_tol) * inv;
-        sv.tolf[f] = par.feas_tol * inv;
+        sv.tolf[f] = (float)(par.feas_tol * inv);
       } else {  // 0 <= b: never binding if b >= -tol, else no point satisfies it
         degenerate_violated = -fc.b > par.feas_tol;
         fc.b = -1.0;
-        sv.tolf[f] = 0.0;
+        sv.tolf[f] = 0.0f;
         for (int p = 0; p < pr.n_poly; p++) pf = (f >= pr.face_off[p]) ? p : pf;
       }
       sv.faces[f] = fc;
