@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/fasterhip.h"
+#include "../host/jps_tables.hpp"
 #include "fh_path.hip.hpp"
 
 struct fh_map {
@@ -36,6 +37,8 @@ struct fh_map {
   int sched_waves_per_cu = 12, sched_launch_order = 1;  // fh_map_set_sched
   int* d_order = nullptr;  // 128 counters + launch order
   size_t order_cap = 0;
+  int search_mode = 0;                    // fh_map_set_search: 0 A* with a total order, 1 jump point search in jps3d's order
+  unsigned char* d_jps_tables = nullptr;  // neighbour tables of the jump point search (uploaded by the first fh_map_set_search(1))
   // staging of the host-pointer entry points
   void* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_cap[5] = {0, 0, 0, 0, 0};
@@ -129,7 +132,7 @@ void fh_map_destroy(fh_map* m) {
   if (!m) return;
   MapDeviceScope scope(m);
   (void)hipStreamSynchronize(m->stream);
-  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order})
+  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables})
     if (p) (void)hipFree(p);
   for (void* p : m->d_stage)
     if (p) (void)hipFree(p);
@@ -153,6 +156,32 @@ int fh_map_set_sched(fh_map* m, int waves_per_cu, int launch_order) {
   if (w != m->sched_waves_per_cu) m->ws_total = 0;  // the search workspace is sized by the number of wavefronts: reallocated by the next search
   m->sched_waves_per_cu = w;
   m->sched_launch_order = launch_order ? 1 : 0;
+  return FH_OK;
+}
+
+// Which search fh_map_plan_batch* runs.  0 (default): A* with a total order of its own (an optimal path; equals the host restatement
+// plan_path bit for bit).  1: jump point search with jps3d's pruning rules, successor order, comparator and heap (the optimal path
+// FASTER itself gets from planner_ptr_->plan(start, goal, 1, true), jps_manager.cpp:166; equals plan_path_jps bit for bit).
+int fh_map_set_search(fh_map* m, int mode) {
+  if (!m || (mode != 0 && mode != 1)) return FH_ERR_ARG;
+  MapDeviceScope scope(m);
+  if (mode == 1 && !m->d_jps_tables) {
+    // [27][28] natural neighbours, [27][12] cells to test, [27][12] directions to add; one byte per vector: (dx+1) | (dy+1) << 2 | (dz+1) << 4
+    const fhfront::JpsTables& T = fhfront::jps_tables();
+    std::vector<unsigned char> tab(27 * 28 + 2 * 27 * 12, 0);
+    auto pk = [](const int v[3]) { return (unsigned char)((v[0] + 1) | ((v[1] + 1) << 2) | ((v[2] + 1) << 4)); };
+    for (int id = 0; id < 27; id++) {
+      for (int k = 0; k < 26; k++) tab[id * 28 + k] = pk(T.ns[id][k]);
+      for (int k = 0; k < 12; k++) {
+        tab[27 * 28 + id * 12 + k] = pk(T.f1[id][k]);
+        tab[27 * 28 + 27 * 12 + id * 12 + k] = pk(T.f2[id][k]);
+      }
+    }
+    FM_HIP(hipMalloc(&m->d_jps_tables, tab.size()));
+    FM_HIP(hipMemcpy(m->d_jps_tables, tab.data(), tab.size(), hipMemcpyHostToDevice));
+  }
+  if (mode != m->search_mode) m->ws_total = 0;  // the two searches stamp the cell states differently: the workspace starts over
+  m->search_mode = mode;
   return FH_OK;
 }
 
@@ -259,6 +288,7 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.paths = d_paths; pa.n_points = d_n_points; pa.expansions = (long long*)d_expansions;
   pa.cells = m->d_cells; pa.chunks = m->d_chunks; pa.serials = m->d_serials; pa.ticket = m->d_ticket;
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
+  pa.jps_tables = m->d_jps_tables;
   FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
   pa.order = nullptr;
   if (n > m->waves && m->sched_launch_order) {  // more queries than wavefronts: far-apart pairs first
@@ -280,7 +310,8 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
     pa.order = m->d_order + 128;
   }
   const int grid = std::min(m->waves, n);
-  hipLaunchKernelGGL(fhp::plan_kernel, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
+  if (m->search_mode == 1) hipLaunchKernelGGL(fhp::plan_kernel<true>, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
+  else hipLaunchKernelGGL(fhp::plan_kernel<false>, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
   FM_HIP(hipGetLastError());
   return FH_OK;
 }

@@ -63,6 +63,7 @@ struct PlanArgs {
   // corridor post-processing (Faster::createMoreVertexes, faster.cpp:80-97; deleteVertexes, utils.cpp:1117-1124); 0 = off
   double max_vertex_dist;
   int max_poly;
+  const unsigned char* jps_tables;  // jump point search only: the neighbour tables, see Planner::init_jps
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -179,9 +180,8 @@ struct Planner {
       const int n = n0 + lane;
       bool out = false, occ = false;
       if (n < steps) {
-        const double f = sc * n;
-        int c[3];
-        to_cell(a[0] + dx * f, a[1] + dy * f, a[2] + dz * f, c);
+        int c[3];  // rayTrace: pt = pt1 + (diff * s) * n, in this order (the rounding decides the cell when a sample sits on a corner)
+        to_cell(a[0] + (dx * sc) * (double)n, a[1] + (dy * sc) * (double)n, a[2] + (dz * sc) * (double)n, c);
         out = outside(c[0], c[1], c[2]);
         if (!out) occ = occupied_in(c[0], c[1], c[2]);
       }
@@ -417,7 +417,11 @@ struct Planner {
       if (__ballot(limit != 0)) return -2;
     }
     if (!found) return 0;
+    return finish_path(cells, chunks, sid, tid);
+  }
 
+  // The parent chain goal -> start, then the clean-up of jps_planner.cpp:283-291.  Returns the number of cells in va[] (start -> goal).
+  __device__ int finish_path(const CellState* cells, unsigned* chunks, int sid, int tid) {
     // ---- raw cell path, goal -> start
     raw = (int*)chunks;
     va = raw + MAXRAW;
@@ -471,15 +475,337 @@ struct Planner {
     settle();
     return nc;
   }
+
+  // =================================================================================================================
+  // Jump point search in jps3d's own order (thirdparty/jps3d/src/jps_planner/graph_search.cpp:123-470 — what
+  // JPS_Manager::solveJPS3D runs, jps_manager.cpp:166): the pruning rules, the order in which successors are generated, the
+  // tolerance comparator (graph_search.h:19-29) and the sift discipline of the binary heap select ONE of the optimal paths, and
+  // FASTER's corridor is built around that one.  The CPU restatement is plan_path_jps (host/corridor_frontend.cpp), itself pinned
+  // to the reference's compiled sources vertex for vertex; this search is checked against it bit for bit.
+  //
+  // The control flow of jps3d is serial (one heap, successors relaxed one after the other); what the 64 lanes share out is the
+  // inside of a jump:
+  //   * a straight jump tests 64 consecutive cells at once (free? goal? forced neighbour?): ballots give the first blocked cell
+  //     and the first cell that ends the jump;
+  //   * a plane-diagonal jump tests 32 diagonal cells at once, then the two straight jumps that leave every diagonal cell before
+  //     the first stop run one per lane in lock step (a lane whose diagonal cell lies beyond one that has already succeeded
+  //     retires);
+  //   * a space-diagonal jump does the same for 8 diagonal cells x (3 straight + 3 plane-diagonal jumps), one jump per lane.
+  // A jump only returns "some cell of this ray ends it" and the diagonal cell it happened at, so the order in which the lanes
+  // find that out does not matter: the successor list and its order are jps3d's.
+  // The heap is jps3d's binary heap, top 512 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
+  // program that all lanes execute; the position of an entry whose key decreases is found by a lane-parallel scan.
+  // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
+  static constexpr int CAP_L = 512, CAP_G = 60000;
+  double* hf;            // LDS [CAP_L]
+  double* hg;
+  int* hid;
+  const unsigned* jns;   // LDS: natural neighbours [27][28] bytes (26 used; 7 words per direction)
+  const unsigned* jf1;   // cells to test [27][12] bytes (3 words per direction)
+  const unsigned* jf2;   // directions to add [27][12] bytes
+  double* gf;            // HBM overflow of the heap
+  double* gg;
+  int* gi;
+
+  struct HE { int id; double f, g; };
+
+  __device__ void init_jps(char* lds, const unsigned char* tab) {
+    hf = (double*)lds;
+    hg = hf + CAP_L;
+    hid = (int*)(hg + CAP_L);
+    unsigned* w = (unsigned*)(hid + CAP_L);
+    const unsigned* tw = (const unsigned*)tab;
+    for (int i = lane; i < JTAB_WORDS; i += 64) w[i] = tw[i];
+    jns = w;
+    jf1 = w + 27 * 7;
+    jf2 = jf1 + 27 * 3;
+  }
+  static constexpr int JTAB_WORDS = 27 * 7 + 27 * 3 + 27 * 3;
+
+  __device__ __forceinline__ static int ux(unsigned pk) { return (int)(pk & 3u) - 1; }
+  __device__ __forceinline__ static int uy(unsigned pk) { return (int)((pk >> 2) & 3u) - 1; }
+  __device__ __forceinline__ static int uz(unsigned pk) { return (int)((pk >> 4) & 3u) - 1; }
+  __device__ __forceinline__ static int code_of(unsigned pk) { return (int)((pk & 3u) + 3u * ((pk >> 2) & 3u) + 9u * ((pk >> 4) & 3u)); }
+  __device__ __forceinline__ static unsigned byte_of(const unsigned* w, int i) { return (w[i >> 2] >> (8 * (i & 3))) & 255u; }
+  __device__ __forceinline__ unsigned nat(int code, int k) const { return byte_of(jns + code * 7, k); }
+
+  // occupied = inside the grid, not freed, bit set (graph_search.cpp:63-66); the load is issued whatever the cell (clamped)
+  __device__ __forceinline__ bool occ_any(int x, int y, int z) const {
+    const bool in = !outside(x, y, z);
+    const int id = in ? index(x, y, z) : 0;
+    const unsigned w = mv.bits[id >> 5];
+    return in && !freed(x, y, z) && ((w >> (id & 31)) & 1u);
+  }
+  __device__ __forceinline__ bool free_any(int x, int y, int z) const {
+    const bool in = !outside(x, y, z);
+    const int id = in ? index(x, y, z) : 0;
+    const unsigned w = mv.bits[id >> 5];
+    return in && (freed(x, y, z) || !((w >> (id & 31)) & 1u));
+  }
+  // does a jump in direction `code` end at this (free) cell: the goal, or a forced neighbour (graph_search.cpp:382-386, :417-470)
+  __device__ __forceinline__ bool ends_at(int x, int y, int z, int code, int norm1) const {
+    const unsigned w0 = jf1[code * 3], w1 = jf1[code * 3 + 1];
+    bool any = x == t[0] && y == t[1] && z == t[2];
+#pragma unroll
+    for (int fn = 0; fn < 8; fn++) {
+      const unsigned pk = ((fn < 4 ? w0 : w1) >> (8 * (fn & 3))) & 255u;
+      const bool o = occ_any(x + ux(pk), y + uy(pk), z + uz(pk));
+      any = any || (o && (fn < 6 || norm1 != 3));
+    }
+    return any;
+  }
+  __device__ __forceinline__ static int norm1_of(unsigned pk) { return abs(ux(pk)) + abs(uy(pk)) + abs(uz(pk)); }
+
+  // ---- the heap: entry i in LDS below CAP_L, in HBM above
+  __device__ __forceinline__ HE hget(int i) const {
+    HE e;
+    if (i < CAP_L) { e.id = hid[i]; e.f = hf[i]; e.g = hg[i]; }
+    else { const int j = i - CAP_L; e.id = gi[j]; e.f = gf[j]; e.g = gg[j]; }
+    return e;
+  }
+  __device__ __forceinline__ void hset(int i, const HE& e) {
+    if (i < CAP_L) {
+      if (lane == 0) { hid[i] = e.id; hf[i] = e.f; hg[i] = e.g; }
+    } else {
+      const int j = i - CAP_L;
+      if (lane == 0) { gi[j] = e.id; gf[j] = e.f; gg[j] = e.g; }
+      settle();
+    }
+  }
+  __device__ __forceinline__ static bool lower(const HE& a, const HE& b) {  // compare_state: a has LOWER priority than b
+    if (a.f >= b.f - 0.000001 && a.f <= b.f + 0.000001) return a.g < b.g;
+    return a.f > b.f;
+  }
+  __device__ void sift_up(int i, const HE& m) {
+    while (i != 0) {
+      const int p = (i - 1) / 2;
+      const HE pe = hget(p);
+      if (!lower(pe, m)) break;
+      hset(i, pe);
+      i = p;
+    }
+    hset(i, m);
+  }
+  __device__ void sift_down(int i, const HE& m, int n) {
+    for (;;) {
+      const int first = 2 * i + 1;
+      if (first >= n) break;
+      HE b = hget(first);
+      int best = first;
+      if (first + 1 < n) {
+        const HE c = hget(first + 1);
+        if (lower(b, c)) { b = c; best = first + 1; }
+      }
+      if (lower(b, m)) break;
+      hset(i, b);
+      i = best;
+    }
+    hset(i, m);
+  }
+  __device__ int heap_find(int id, int n) const {
+    for (int b = 0; b < n; b += 64) {
+      const int i = b + lane;
+      int v = -1;
+      if (i < n) v = i < CAP_L ? hid[i] : gi[i - CAP_L];
+      const unsigned long long m = __ballot(v == id);
+      if (m) return b + (int)__builtin_ctzll(m);
+    }
+    return -1;
+  }
+
+  // ---- jumps one per lane, in lock step.  phase 3: a straight jump along `a` from P; phase 0: a plane-diagonal jump along d2 from P
+  // (0: next diagonal cell; 1 / 2: the straight jumps along a / b that leave it).  `grp` orders the lanes: when a lane has
+  // succeeded, the lanes of later groups retire.
+  __device__ bool run_jumps(bool active, int phase, int px, int py, int pz, unsigned d2, unsigned a, unsigned b, int grp) const {
+    bool res = false;
+    int qx = px, qy = py, qz = pz;
+    while (__ballot(active)) {
+      if (active) {
+        const unsigned pk = phase == 0 ? d2 : (phase == 2 ? b : a);
+        const int x = (phase == 0 ? px : qx) + ux(pk), y = (phase == 0 ? py : qy) + uy(pk), z = (phase == 0 ? pz : qz) + uz(pk);
+        const bool fr = free_any(x, y, z);
+        const bool ev = ends_at(x, y, z, code_of(pk), phase == 0 ? 2 : 1);
+        if (fr && ev) { res = true; active = false; }
+        else if (phase == 3) {
+          if (!fr) active = false;
+          else { qx = x; qy = y; qz = z; }
+        } else if (phase == 0) {
+          px = x; py = y; pz = z;
+          if (!fr) active = false;
+          else { phase = 1; qx = x; qy = y; qz = z; }
+        } else if (phase == 1) {
+          if (!fr) { phase = 2; qx = px; qy = py; qz = pz; }
+          else { qx = x; qy = y; qz = z; }
+        } else {
+          if (!fr) phase = 0;
+          else { qx = x; qy = y; qz = z; }
+        }
+      }
+      const unsigned long long tm = __ballot(res);
+      if (tm) {
+        const int g0 = __builtin_amdgcn_readlane(grp, (int)__builtin_ctzll(tm));
+        if (grp > g0) active = false;
+      }
+    }
+    return res;
+  }
+
+  // graph_search.cpp:374-400 for one successor direction; (ox, oy, oz): the jump point
+  __device__ bool jump(int cx, int cy, int cz, unsigned pk, int& ox, int& oy, int& oz) const {
+    const int dx = ux(pk), dy = uy(pk), dz = uz(pk), code = code_of(pk), n1 = abs(dx) + abs(dy) + abs(dz);
+    int bx = cx, by = cy, bz = cz;
+    if (n1 == 1) {
+      for (;;) {
+        const int k = lane + 1;
+        const int x = bx + k * dx, y = by + k * dy, z = bz + k * dz;
+        const bool fr = free_any(x, y, z);
+        const bool ev = ends_at(x, y, z, code, 1);
+        const unsigned long long bm = __ballot(!fr), em = __ballot(fr && ev);
+        const int fb = bm ? (int)__builtin_ctzll(bm) : 64, fe = em ? (int)__builtin_ctzll(em) : 64;
+        if (fe < fb) { ox = bx + (fe + 1) * dx; oy = by + (fe + 1) * dy; oz = bz + (fe + 1) * dz; return true; }
+        if (fb < 64) return false;
+        bx += 64 * dx; by += 64 * dy; bz += 64 * dz;
+      }
+    }
+    const int per = n1 == 2 ? 2 : 8, shift = n1 == 2 ? 1 : 3, steps = 64 / per;
+    const int sub = lane & (per - 1);
+    // this lane's jump out of a diagonal cell
+    int phase = 3;
+    unsigned d2 = 0, a = 0, b = 0;
+    bool takes = true;
+    if (n1 == 2) a = nat(code, sub);
+    else if (sub < 3) a = nat(code, sub);
+    else if (sub < 6) {
+      phase = 0;
+      d2 = nat(code, sub);
+      const int c2 = code_of(d2);
+      a = nat(c2, 0);
+      b = nat(c2, 1);
+    } else takes = false;
+    for (;;) {
+      const int k = (lane >> shift) + 1;
+      const int x = bx + k * dx, y = by + k * dy, z = bz + k * dz;
+      const bool fr = free_any(x, y, z);
+      const bool ev = ends_at(x, y, z, code, n1);
+      const unsigned long long sm = __ballot(!fr || ev);
+      const int kstop = sm ? ((int)__builtin_ctzll(sm) >> shift) + 1 : steps + 1;
+      const bool res = run_jumps(takes && k < kstop, phase, x, y, z, d2, a, b, k);
+      const unsigned long long tm = __ballot(res);
+      if (tm) {
+        const int kt = ((int)__builtin_ctzll(tm) >> shift) + 1;
+        ox = bx + kt * dx; oy = by + kt * dy; oz = bz + kt * dz;
+        return true;
+      }
+      if (kstop <= steps) {
+        ox = bx + kstop * dx; oy = by + kstop * dy; oz = bz + kstop * dz;
+        return ((__ballot(fr) >> ((kstop - 1) << shift)) & 1ull) != 0ull;
+      }
+      bx += steps * dx; by += steps * dy; bz += steps * dz;
+    }
+  }
+
+  __device__ __forceinline__ double heur_jps(int x, int y, int z) const {  // graph_search.cpp:72-74, eps = 1
+    return sqrt((double)dist2(x, y, z));
+  }
+
+  __device__ int search_jps(CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
+    gf = (double*)chunks;
+    gg = gf + CAP_G;
+    gi = (int*)(gg + CAP_G);
+    const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
+    const int nxy = mv.nx * mv.ny;
+    {
+      HE e;
+      e.id = sid; e.g = 0.0; e.f = 0.0 + heur_jps(s[0], s[1], s[2]);
+      hset(0, e);
+      if (lane == 0) {
+        CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = (serial << 6) | (13u << 1);
+        cells[sid] = cs;
+      }
+    }
+    int n = 1;
+    long long pops = 0;
+    for (;;) {  // graph_search.cpp:123-217
+      expansions++;
+      if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
+      const HE top = hget(0);
+      n--;
+      if (n > 0) {
+        const HE last = hget(n);
+        sift_down(0, last, n);
+      }
+      const int cur = rfl(top.id);
+      settle();
+      const unsigned cstamp = (unsigned)rfl((int)cells[cur].stamp);
+      if (lane == 0) cells[cur].stamp = cstamp | 1u;
+      if (cur == tid) break;
+      const int cz = cur / nxy, rem = cur - cz * nxy, cy = rem / mv.nx, cx = rem - cy * mv.nx;
+      const int code = (int)((cstamp >> 1) & 31u);
+      const int n1 = abs(code % 3 - 1) + abs((code / 3) % 3 - 1) + abs(code / 9 - 1);
+      const int num_neib = n1 == 0 ? 26 : (n1 == 1 ? 1 : (n1 == 2 ? 3 : 7)), num_fneib = n1 == 0 ? 0 : (n1 == 1 ? 8 : 12);
+      // which of the forced-neighbour entries apply (getJpsSucc, :346-366): one per lane
+      unsigned long long fm;
+      {
+        const unsigned pk = byte_of(jf1 + code * 3, lane < 12 ? lane : 0);
+        fm = __ballot(lane < num_fneib && occ_any(cx + ux(pk), cy + uy(pk), cz + uz(pk)));
+      }
+      for (int dev = 0; dev < num_neib + num_fneib; dev++) {  // successor by successor, in getJpsSucc's order
+        unsigned pk;
+        if (dev < num_neib) pk = nat(code, dev);
+        else {
+          const int k = dev - num_neib;
+          if (!((fm >> k) & 1ull)) continue;
+          pk = byte_of(jf2 + code * 3, k);
+        }
+        int jx, jy, jz;
+        if (!jump(cx, cy, cz, pk, jx, jy, jz)) continue;
+        jx = rfl(jx); jy = rfl(jy); jz = rfl(jz);
+        const int nid = index(jx, jy, jz);
+        settle();
+        const CellState ns = cells[nid];
+        const bool visited = (ns.stamp >> 6) == serial;
+        const bool closed = visited && (ns.stamp & 1u);
+        const int ex = jx - cx, ey = jy - cy, ez = jz - cz;
+        const double cost = sqrt((double)(ex * ex + ey * ey + ez * ez));
+        const double tentative = top.g + cost;  // :150-191
+        if (!visited || tentative < ns.g) {
+          unsigned ncode = visited ? ((ns.stamp >> 1) & 31u) : (unsigned)code_of(pk);
+          HE me;
+          me.id = nid; me.g = tentative; me.f = tentative + heur_jps(jx, jy, jz);
+          if (visited && !closed) {  // pq_.increase, and the direction becomes the sign of the move (:176-181)
+            const int pos = heap_find(nid, n);
+            if (pos < 0) return -2;  // (cannot happen)
+            sift_up(pos, me);
+            ncode = (unsigned)((ex > 0 ? 2 : (ex < 0 ? 0 : 1)) + 3 * (ey > 0 ? 2 : (ey < 0 ? 0 : 1)) + 9 * (ez > 0 ? 2 : (ez < 0 ? 0 : 1)));
+          } else if (!visited) {
+            if (n >= CAP_L + CAP_G) return -2;
+            sift_up(n, me);
+            n++;
+          }  // (closed: jps3d updates g and the parent and goes on)
+          if (lane == 0) {
+            CellState w; w.g = tentative; w.parent = cur; w.stamp = (serial << 6) | (ncode << 1) | (closed ? 1u : 0u);
+            cells[nid] = w;
+          }
+        }
+      }
+      if (n == 0) return 0;
+    }
+    settle();
+    return finish_path(cells, chunks, sid, tid);
+  }
 };
 
 constexpr int PLAN_LDS_BYTES = NCHUNK * 2 * 2 + NS * 4 * 4 + NS * 2;
+constexpr int JPS_LDS_BYTES = Planner::CAP_L * 20 + Planner::JTAB_WORDS * 4;
+constexpr unsigned JPS_SERIAL_LIMIT = (1u << 26) - 1u;
 
 // One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
 // (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
+template <bool JPS>
 __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
-  __shared__ __attribute__((aligned(16))) char lds[PLAN_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds[JPS ? JPS_LDS_BYTES : PLAN_LDS_BYTES];
   Planner pl(mv, lds);
+  if (JPS) pl.init_jps(lds, pa.jps_tables);
   const int lane = pl.lane;
   const int wave = (int)blockIdx.x;
   CellState* cells = pa.cells + (size_t)wave * mv.total;
@@ -502,12 +828,12 @@ __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
     int nv = 0;
     if (!pl.outside(pl.s[0], pl.s[1], pl.s[2]) && !pl.outside(pl.t[0], pl.t[1], pl.t[2])) {
       serial++;
-      if (serial >= 0x7fffffffu) {  // 2^31 queries of this wavefront: its stamps start over, so its cell states are cleared first
+      if (serial >= (JPS ? JPS_SERIAL_LIMIT : 0x7fffffffu)) {  // 2^31 (2^26) queries of this wavefront: its stamps start over, so its cell states are cleared first
         for (int c = lane; c < mv.total; c += 64) cells[c].stamp = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         serial = 1;
       }
-      nv = pl.search(pa, cells, chunks, serial, expansions);
+      nv = JPS ? pl.search_jps(cells, chunks, serial, expansions) : pl.search(pa, cells, chunks, serial, expansions);
     }
     double* out = pa.paths + (size_t)q * pa.max_points * 3;
     int np = nv;

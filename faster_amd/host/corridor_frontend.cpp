@@ -2,6 +2,8 @@
 #include "corridor_frontend.hpp"
 #include "jps_tables.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <limits>

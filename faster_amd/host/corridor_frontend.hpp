@@ -344,8 +344,10 @@ struct VoxelGrid {
     if (steps <= 0) return false;
     const double s = 1.0 / steps;
     int prev[3] = {-1, -1, -1};
+    const V3 step = diff * s;  // rayTrace: step = diff * s, pt = pt1 + step * n — in THIS order: samples of a diagonal ray sit on cell
+                               // corners, and the rounding of the product decides the cell
     for (int n = 1; n < steps; n++) {
-      const V3 p = a + diff * (s * n);
+      const V3 p = a + step * (double)n;
       int c[3];
       to_cell(p, c);
       if (outside(c[0], c[1], c[2])) break;

@@ -159,8 +159,7 @@ def plan(grid, start, goal):
             return False
         sc = 1.0 / steps
         for n in range(1, steps):
-            fr = sc * n
-            c = grid.to_cell([a[k] + d[k] * fr for k in range(3)])
+            c = grid.to_cell([a[k] + (d[k] * sc) * n for k in range(3)])   # rayTrace: pt1 + (diff * s) * n, in this order
             if grid.outside(*c):
                 break
             if occupied(grid.index(*c)):

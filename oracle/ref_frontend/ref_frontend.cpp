@@ -114,6 +114,23 @@ int ref_map_plan(RefMap* m, const double* start_sent, const double* goal_sent, i
   return (int)path.size();
 }
 
+// The raw path of the same call (jump points, start -> goal), for diagnosing a differing vertex list.  Returns the number of points.
+int ref_map_raw_path(RefMap* m, const double* start_sent, const double* goal_sent, int use_jps, double* out_raw, int max_pts) {
+  auto map_util_ = std::make_shared<JPS::MapUtil<3>>(*m->map);
+  Vec3f start(start_sent[0], start_sent[1], std::max(start_sent[2], 0.0));
+  Vec3f goal(goal_sent[0], goal_sent[1], std::max(goal_sent[2], 0.0));
+  map_util_->setFreeVoxelAndSurroundings(map_util_->floatToInt(start), m->inflation);
+  map_util_->setFreeVoxelAndSurroundings(map_util_->floatToInt(goal), m->inflation);
+  JPSPlanner3D planner(false);
+  planner.setMapUtil(map_util_);
+  if (!planner.plan(start, goal, 1, use_jps != 0)) return 0;
+  const vec_Vecf<3> raw = planner.getRawPath();
+  if ((int)raw.size() > max_pts) return -1;
+  for (size_t i = 0; i < raw.size(); i++)
+    for (int k = 0; k < 3; k++) out_raw[3 * i + k] = raw[i](k);
+  return (int)raw.size();
+}
+
 // jps3d's neighbour tables as its constructor builds them (graph_search.cpp:573-937): ns [27][3][26], f1 / f2 [27][3][12]
 void ref_jps3d_tables(int* ns, int* f1, int* f2) {
   JPS::JPS3DNeib jn;

@@ -319,3 +319,115 @@ def test_packed_results_are_lossless(ctx):
         assert full["solved"].sum() > 100
         assert np.array_equal(back.view(np.uint8), np.ascontiguousarray(full).view(np.uint8))
         assert np.array_equal(capi.pack_results(full, n_seg), packed)
+
+
+def _plans_equal(host, dev, what):
+    hp, hn, hex_ = host
+    dp, dn, dex = dev
+    assert np.array_equal(hn, dn), (what, np.nonzero(hn != dn)[0][:8])
+    assert np.array_equal(hex_, dex), (what, "jump point search on the device popped other nodes than the host")
+    for i in np.nonzero(hn > 0)[0]:
+        assert np.array_equal(dp[i, :hn[i]], hp[i, :hn[i]]), (what, i)
+
+
+@pytest.fixture()
+def host_jps():
+    from faster_amd import frontend
+
+    frontend.set_search("jps")
+    yield frontend
+    frontend.set_search("astar")
+
+
+def test_device_jump_point_search_equals_host_restatement(host_jps):
+    """fh_map_set_search(1): jump point search in jps3d's own order on the device == plan_path_jps (which is pinned to the reference's
+    compiled jps3d vertex for vertex, tests/test_ref_frontend.py): the same number of popped nodes and the same vertices BIT FOR BIT,
+    on the forest of config C5 (4096 queries), with the vertices Faster::replan would decompose, after switching the map object
+    between the two searches, and on the edge cases of the A* test (wall, empty map, coarse cells, z clipping, 0.1 m cells)."""
+    frontend = host_jps
+    res, infl, zmax = 0.2, 0.3, 3.0
+    cloud, cells, center, starts, goals = frontend.forest_queries(4096, 23)
+    m = capi.Map(0)
+    try:
+        m.read(cloud, cells, res, center, 0.0, zmax, infl)
+        astar = m.plan_batch(starts[:512], goals[:512])
+        m.set_search("jps")
+        host = frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals)
+        assert (host[1] > 0).mean() > 0.95 and host[2].mean() > 100
+        _plans_equal(host, m.plan_batch(starts, goals), "forest")
+        _plans_equal(host, m.plan_batch(starts, goals), "forest, second call (serial numbers)")
+        _plans_equal(frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, max_points=16, max_vertex_dist=1.5, max_poly=8),
+                     m.plan_batch(starts, goals, max_points=16, max_vertex_dist=1.5, max_poly=8), "refined")
+        m.set_search("astar")
+        again = m.plan_batch(starts[:512], goals[:512])
+        assert np.array_equal(astar[1], again[1]) and np.array_equal(astar[2], again[2])
+        m.set_search("jps")
+        rng = np.random.default_rng(5)
+        for case in ["wall", "empty", "coarse", "tall", "large"]:
+            res, infl, zg, zmax = 0.25, 0.25, 0.0, 2.0
+            cells, center = (40, 40, 8), np.array([5.0, 5.0, 1.0])
+            if case == "wall":
+                yy, zz = np.meshgrid(np.arange(-3, 13, 0.1), np.arange(-1, 3, 0.1))
+                cloud = np.column_stack([np.full(yy.size, 5.0), yy.ravel(), zz.ravel()])
+            elif case == "empty":
+                cloud = np.zeros((0, 3))
+            elif case == "coarse":
+                cloud, _ = frontend.forest_cloud(4, size=(10.0, 10.0, 2.0), density=0.2)
+                res, infl, cells = 0.5, 0.2, (20, 20, 4)
+            elif case == "tall":
+                cloud, _ = frontend.forest_cloud(5, size=(10.0, 10.0, 2.0), density=0.2)
+                center, cells = np.array([5.0, 5.0, 1.7]), (40, 40, 12)
+            else:
+                cloud, _ = frontend.forest_cloud(8, size=(10.0, 10.0, 2.0), density=0.25)
+                res, infl, cells = 0.1, 0.3, (100, 100, 30)
+            n = 256
+            starts = np.column_stack([rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
+            goals = np.column_stack([rng.uniform(6.0, 9.5, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
+            goals[:8] = starts[:8] + 0.01
+            goals[8] = starts[8]
+            starts[9] = [-50.0, 5.0, 1.0]
+            goals[10] = [5.0, 500.0, 1.0]
+            starts[11, 2] = -0.7
+            goals[12, 2] = -0.2
+            starts[13] = goals[13] - [0.3, 0.0, 0.0]
+            m.read(cloud, cells, res, center, zg, zmax, infl)
+            host = frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals)
+            dev = m.plan_batch(starts, goals)
+            _plans_equal(host, dev, case)
+            assert dev[1][9] == 0 and dev[1][10] == 0
+            if case == "wall":
+                assert (dev[1][16:] == 0).all()
+            if case == "empty":
+                assert (dev[1][16:] == 2).all()
+    finally:
+        m.close()
+
+
+def test_device_jump_point_search_against_the_reference_sources(ref):
+    """The device search in mode 1 against jps3d ITSELF (the reference's sources compiled untouched, driven as JPS_Manager::solveJPS3D
+    drives them): the same queries have a path and every vertex list is identical."""
+    from faster_amd import frontend
+
+    total = 0
+    for seed in (3, 4):
+        cloud, cells, center, starts, goals = frontend.forest_queries(160, seed)
+        cloud = cloud.astype(np.float32).astype(np.float64)   # pcl::PointXYZ holds floats
+        res, zg, zmax, infl = 0.2, 0.0, 3.0, 0.3
+        rm = ref.Map(cloud, cells, res, center, zg, zmax, infl)
+        dm = capi.Map(0)
+        try:
+            dm.read(cloud, cells, res, center, zg, zmax, infl)
+            dm.set_search("jps")
+            dp, dn, _ = dm.plan_batch(starts, goals, max_points=128)
+        finally:
+            dm.close()
+        for i in range(len(starts)):
+            p, _, _ = rm.plan(starts[i], goals[i], True)
+            assert (p is None) == (dn[i] == 0), (seed, i)
+            if p is None:
+                continue
+            assert dn[i] == len(p), (seed, i, dn[i], len(p))
+            np.testing.assert_allclose(dp[i, :dn[i]], p, rtol=0, atol=1e-9)
+            total += 1
+        rm.close()
+    assert total >= 300

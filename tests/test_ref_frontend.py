@@ -290,3 +290,24 @@ def test_jps_vertex_lists_equal_jps3d_inside_the_inflated_obstacles(ref):
             assert len(p) == len(hp) and np.array_equal(p, hp), i
     m.close()
     assert found >= 40
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_jps_vertex_lists_equal_jps3d_on_the_c5_queries(ref, seed):
+    """The start/goal pairs of config C5's generator.  Seed 4, query 112 is the case that pinned the ORDER of the ray test's arithmetic
+    (rayTrace, map_util.h:349-370: pt = pt1 + (diff * s) * n): the samples of a diagonal ray sit on cell corners, diff * (s * n)
+    rounds to the other cell once in a few thousand rays, removeCornerPts then keeps another vertex."""
+    cloud, cells, center, starts, goals = frontend.forest_queries(160, seed)
+    cloud = cloud.astype(np.float32).astype(np.float64)
+    res, zg, zmax, infl = 0.2, 0.0, 3.0, 0.3
+    m = ref.Map(cloud, cells, res, center, zg, zmax, infl)
+    found = 0
+    for i in range(len(starts)):
+        p, cost, _ = m.plan(starts[i], goals[i], True)
+        hp, hcost, _ = frontend.plan_jps(cloud, cells, res, center, zg, zmax, infl, starts[i], goals[i])
+        assert (p is None) == (hp is None), i
+        if p is not None:
+            found += 1
+            assert len(p) == len(hp) and np.array_equal(p, hp), i
+    m.close()
+    assert found >= 150
