@@ -270,6 +270,10 @@ class Map:
     def sync(self):
         self._check(lib().fh_map_sync(self._h), "fh_map_sync")
 
+    def set_sched(self, waves_per_cu=0, launch_order=1):
+        """fh_map_set_sched: wavefronts per CU that hold a search workspace (0 = default 12), far-apart pairs first (default 1)."""
+        self._check(lib().fh_map_set_sched(self._h, int(waves_per_cu), int(launch_order)), "fh_map_set_sched")
+
     def set_search(self, mode):
         """fh_map_set_search: "astar" (default; an optimal path, total order of its own) or "jps" (jump point search in jps3d's own
         order: the optimal path FASTER itself gets)."""

@@ -39,6 +39,9 @@ struct fh_map {
   size_t order_cap = 0;
   int search_mode = 0;                    // fh_map_set_search: 0 A* with a total order, 1 jump point search in jps3d's order
   unsigned char* d_jps_tables = nullptr;  // neighbour tables of the jump point search (uploaded by the first fh_map_set_search(1))
+  short* d_jps_entries = nullptr;         // jump tables of the current grid [27][cells] (fhp::jps_table_kernel), built by the first search in mode 1
+  size_t entries_cap = 0;
+  bool entries_valid = false;
   // staging of the host-pointer entry points
   void* d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t stage_cap[5] = {0, 0, 0, 0, 0};
@@ -132,7 +135,7 @@ void fh_map_destroy(fh_map* m) {
   if (!m) return;
   MapDeviceScope scope(m);
   (void)hipStreamSynchronize(m->stream);
-  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables})
+  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables, (void*)m->d_jps_entries})
     if (p) (void)hipFree(p);
   for (void* p : m->d_stage)
     if (p) (void)hipFree(p);
@@ -234,6 +237,7 @@ int fh_map_read_device(fh_map* m, const double* d_cloud_xyz, int n_cloud, const 
     FM_HIP(hipGetLastError());
   }
   m->have_map = true;
+  m->entries_valid = false;
   return FH_OK;
 }
 
@@ -290,6 +294,27 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
   pa.jps_tables = m->d_jps_tables;
   FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
+  pa.jps_entries = nullptr;
+  if (m->search_mode == 1) {
+    if (!m->entries_valid) {  // the jump tables of this grid: three small launches, once per map
+      const size_t need = (size_t)27 * mv.total * sizeof(short);
+      if (need > m->entries_cap) {
+        FM_HIP(hipStreamSynchronize(m->stream));
+        if (m->d_jps_entries) FM_HIP(hipFree(m->d_jps_entries));
+        m->d_jps_entries = nullptr; m->entries_cap = 0;
+        FM_HIP(hipMalloc(&m->d_jps_entries, need));
+        m->entries_cap = need;
+      }
+      for (int level = 1; level <= 3; level++) {
+        const long long threads = (long long)mv.total * (level == 1 ? 6 : (level == 2 ? 12 : 8));
+        hipLaunchKernelGGL(fhp::jps_table_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, m->stream, mv, m->d_jps_tables,
+                           m->d_jps_entries, level);
+      }
+      FM_HIP(hipGetLastError());
+      m->entries_valid = true;
+    }
+    pa.jps_entries = m->d_jps_entries;
+  }
   pa.order = nullptr;
   if (n > m->waves && m->sched_launch_order) {  // more queries than wavefronts: far-apart pairs first
     const size_t need = sizeof(int) * ((size_t)n + 128);

@@ -64,6 +64,7 @@ struct PlanArgs {
   double max_vertex_dist;
   int max_poly;
   const unsigned char* jps_tables;  // jump point search only: the neighbour tables, see Planner::init_jps
+  const short* jps_entries;         // ... and the jump tables of this map [27][total], see jps_table_kernel
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -509,13 +510,14 @@ struct Planner {
 
   struct HE { int id; double f, g; };
 
-  __device__ void init_jps(char* lds, const unsigned char* tab) {
+  __device__ void init_jps(char* lds, const unsigned char* tab, const short* entries) {
     hf = (double*)lds;
     hg = hf + CAP_L;
     hid = (int*)(hg + CAP_L);
     unsigned* w = (unsigned*)(hid + CAP_L);
     const unsigned* tw = (const unsigned*)tab;
     for (int i = lane; i < JTAB_WORDS; i += 64) w[i] = tw[i];
+    jt = entries;
     jns = w;
     jf1 = w + 27 * 7;
     jf2 = jf1 + 27 * 3;
@@ -613,32 +615,107 @@ struct Planner {
     return -1;
   }
 
+  // ---- jump tables (jps_table_kernel): jt[code * total + cell] = the outcome of the jump that leaves `cell` in direction `code` on
+  // the map as read — no goal, no cells freed around start and goal: +k the jump ends (forced neighbour, or a lower jump that ends)
+  // k cells away, -k the k-th cell is blocked, 0 not known.  A query may use an entry when nothing it depends on has changed:
+  //   * the cells that differ from the map as read are the occupied cells inside the two freed cubes: their bounding boxes are
+  //     dlo/dhi (empty box: lo > hi);
+  //   * a straight jump looks at its ray and the 8 cells around every ray cell: the first ray cell whose surroundings touch a box is
+  //     computed exactly (tube_contact); up to there the entry holds, from there on the cells are examined one by one;
+  //   * a diagonal jump looks at cells of the cone it opens (one cell of margin): if a box meets the cone, or the goal lies where a
+  //     ray of the jump could pass, the entry is not used and the jump is evaluated cell by cell with the entries one level down;
+  //   * the goal on a straight ray is arithmetic.
+  const short* jt;
+  int dlo[2][3], dhi[2][3];
+  static constexpr int BIGK = 1 << 28;
+
+  __device__ __forceinline__ int tube_contact(int bx, int by, int bz, int ax, int ay, int az, int kend) const {
+    int best = BIGK;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      int lo, hi, ba, sg;
+      bool perp;
+      if (ax) {
+        sg = ax; ba = bx; lo = dlo[q][0]; hi = dhi[q][0];
+        perp = by >= dlo[q][1] - 1 && by <= dhi[q][1] + 1 && bz >= dlo[q][2] - 1 && bz <= dhi[q][2] + 1;
+      } else if (ay) {
+        sg = ay; ba = by; lo = dlo[q][1]; hi = dhi[q][1];
+        perp = bx >= dlo[q][0] - 1 && bx <= dhi[q][0] + 1 && bz >= dlo[q][2] - 1 && bz <= dhi[q][2] + 1;
+      } else {
+        sg = az; ba = bz; lo = dlo[q][2]; hi = dhi[q][2];
+        perp = bx >= dlo[q][0] - 1 && bx <= dhi[q][0] + 1 && by >= dlo[q][1] - 1 && by <= dhi[q][1] + 1;
+      }
+      int kf = sg > 0 ? lo - ba : ba - hi, kl = sg > 0 ? hi - ba : ba - lo;
+      kf = kf > 1 ? kf : 1;
+      kl = kl < kend ? kl : kend;
+      if (perp && kf <= kl && kf < best) best = kf;
+    }
+    return best;
+  }
+  __device__ __forceinline__ int goal_on_ray(int bx, int by, int bz, int ax, int ay, int az) const {
+    const int ex = t[0] - bx, ey = t[1] - by, ez = t[2] - bz;
+    int k, off;
+    if (ax) { k = ex * ax; off = abs(ey) + abs(ez); }
+    else if (ay) { k = ey * ay; off = abs(ex) + abs(ez); }
+    else { k = ez * az; off = abs(ex) + abs(ey); }
+    return (off == 0 && k >= 1) ? k : BIGK;
+  }
+  // may the entry of a diagonal jump from (x, y, z) be used
+  __device__ __forceinline__ bool cone_clean(int x, int y, int z, int ax, int ay, int az) const {
+    bool dirty = false;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const bool mx = ax > 0 ? dhi[q][0] >= x : (ax < 0 ? dlo[q][0] <= x : (dlo[q][0] - 1 <= x && x <= dhi[q][0] + 1));
+      const bool my = ay > 0 ? dhi[q][1] >= y : (ay < 0 ? dlo[q][1] <= y : (dlo[q][1] - 1 <= y && y <= dhi[q][1] + 1));
+      const bool mz = az > 0 ? dhi[q][2] >= z : (az < 0 ? dlo[q][2] <= z : (dlo[q][2] - 1 <= z && z <= dhi[q][2] + 1));
+      dirty = dirty || (mx && my && mz);
+    }
+    const int ex = t[0] - x, ey = t[1] - y, ez = t[2] - z;
+    const bool gx = ax ? ex * ax >= 1 : ex == 0, gy = ay ? ey * ay >= 1 : ey == 0, gz = az ? ez * az >= 1 : ez == 0;
+    return !dirty && !(gx && gy && gz);
+  }
+  __device__ __forceinline__ int entry(int code, int x, int y, int z) const { return (int)jt[(size_t)code * mv.total + index(x, y, z)]; }
+
   // ---- jumps one per lane, in lock step.  phase 3: a straight jump along `a` from P; phase 0: a plane-diagonal jump along d2 from P
   // (0: next diagonal cell; 1 / 2: the straight jumps along a / b that leave it).  `grp` orders the lanes: when a lane has
-  // succeeded, the lanes of later groups retire.
+  // succeeded, the lanes of later groups retire.  One round = one table entry or one examined cell per lane.
   __device__ bool run_jumps(bool active, int phase, int px, int py, int pz, unsigned d2, unsigned a, unsigned b, int grp) const {
     bool res = false;
     int qx = px, qy = py, qz = pz;
     while (__ballot(active)) {
       if (active) {
         const unsigned pk = phase == 0 ? d2 : (phase == 2 ? b : a);
-        const int x = (phase == 0 ? px : qx) + ux(pk), y = (phase == 0 ? py : qy) + uy(pk), z = (phase == 0 ? pz : qz) + uz(pk);
-        const bool fr = free_any(x, y, z);
-        const bool ev = ends_at(x, y, z, code_of(pk), phase == 0 ? 2 : 1);
-        if (fr && ev) { res = true; active = false; }
-        else if (phase == 3) {
-          if (!fr) active = false;
-          else { qx = x; qy = y; qz = z; }
-        } else if (phase == 0) {
-          px = x; py = y; pz = z;
-          if (!fr) active = false;
-          else { phase = 1; qx = x; qy = y; qz = z; }
-        } else if (phase == 1) {
-          if (!fr) { phase = 2; qx = px; qy = py; qz = pz; }
-          else { qx = x; qy = y; qz = z; }
-        } else {
-          if (!fr) phase = 0;
-          else { qx = x; qy = y; qz = z; }
+        const int ax = ux(pk), ay = uy(pk), az = uz(pk), dcode = code_of(pk);
+        const int bx = phase == 0 ? px : qx, by = phase == 0 ? py : qy, bz = phase == 0 ? pz : qz;
+        const int J = entry(dcode, bx, by, bz);
+        int outcome = 0;  // 1 the jump along pk ends (true), 2 it is blocked, 3 examine the next cell, 0 go on (Q moved)
+        if (J == 0) outcome = 3;
+        else if (phase == 0) outcome = cone_clean(bx, by, bz, ax, ay, az) ? (J > 0 ? 1 : 2) : 3;
+        else {
+          const int kend = abs(J);
+          const int k0 = tube_contact(bx, by, bz, ax, ay, az, kend), kt = goal_on_ray(bx, by, bz, ax, ay, az);
+          if (k0 > kend) outcome = (J > 0 || kt < kend || (kt == kend && J > 0)) ? 1 : 2;
+          else if (k0 > 1) {
+            if (kt < k0) outcome = 1;
+            else { qx = bx + (k0 - 1) * ax; qy = by + (k0 - 1) * ay; qz = bz + (k0 - 1) * az; }
+          } else outcome = 3;
+        }
+        int x = 0, y = 0, z = 0;
+        if (outcome == 3) {
+          x = bx + ax; y = by + ay; z = bz + az;
+          const bool fr = free_any(x, y, z);
+          const bool ev = ends_at(x, y, z, dcode, phase == 0 ? 2 : 1);
+          outcome = (fr && ev) ? 1 : (!fr ? 2 : 4);  // 4: a free cell that ends nothing
+          if (phase == 0) { px = x; py = y; pz = z; }
+        }
+        if (outcome == 1) { res = true; active = false; }
+        else if (outcome == 2) {
+          if (phase == 3 || phase == 0) active = false;
+          else if (phase == 1) { phase = 2; qx = px; qy = py; qz = pz; }
+          else phase = 0;
+        } else if (outcome == 4) {
+          if (phase == 0) phase = 1;
+          qx = x; qy = y; qz = z;
         }
       }
       const unsigned long long tm = __ballot(res);
@@ -656,6 +733,22 @@ struct Planner {
     int bx = cx, by = cy, bz = cz;
     if (n1 == 1) {
       for (;;) {
+        const int J = rfl(entry(code, bx, by, bz));
+        if (J != 0) {
+          const int kend = abs(J);
+          const int k0 = tube_contact(bx, by, bz, dx, dy, dz, kend), kt = goal_on_ray(bx, by, bz, dx, dy, dz);
+          int k = -1;
+          if (k0 > kend) {
+            if (kt < kend || (kt == kend && J > 0)) k = kt;
+            else if (J > 0) k = J;
+            else return false;
+          } else if (k0 > 1) {
+            if (kt < k0) k = kt;
+            else { bx += (k0 - 1) * dx; by += (k0 - 1) * dy; bz += (k0 - 1) * dz; }
+          }
+          if (k > 0) { ox = bx + k * dx; oy = by + k * dy; oz = bz + k * dz; return true; }
+        }
+        // the cells ahead may differ from the map as read: 64 of them at once
         const int k = lane + 1;
         const int x = bx + k * dx, y = by + k * dy, z = bz + k * dz;
         const bool fr = free_any(x, y, z);
@@ -683,6 +776,12 @@ struct Planner {
       b = nat(c2, 1);
     } else takes = false;
     for (;;) {
+      const int J = rfl(entry(code, bx, by, bz));
+      if (J != 0 && cone_clean(bx, by, bz, dx, dy, dz)) {
+        if (J < 0) return false;
+        ox = bx + J * dx; oy = by + J * dy; oz = bz + J * dz;
+        return true;
+      }
       const int k = (lane >> shift) + 1;
       const int x = bx + k * dx, y = by + k * dy, z = bz + k * dz;
       const bool fr = free_any(x, y, z);
@@ -704,6 +803,24 @@ struct Planner {
     }
   }
 
+  // the occupied cells inside the cube freed around centre c (they are free for this query): their bounding box
+  __device__ void dirty_box(const int c[3], int q) {
+    const int m = mv.m_free, w = 2 * m + 1, count = w * w * w;
+    int lo0 = BIGK, lo1 = BIGK, lo2 = BIGK, hi0 = -BIGK, hi1 = -BIGK, hi2 = -BIGK;
+    for (int i = lane; i < count; i += 64) {
+      const int x = c[0] - m + i % w, y = c[1] - m + (i / w) % w, z = c[2] - m + i / (w * w);
+      if (!outside(x, y, z)) {
+        const int id = index(x, y, z);
+        if ((mv.bits[id >> 5] >> (id & 31)) & 1u) {
+          lo0 = min(lo0, x); lo1 = min(lo1, y); lo2 = min(lo2, z);
+          hi0 = max(hi0, x); hi1 = max(hi1, y); hi2 = max(hi2, z);
+        }
+      }
+    }
+    dlo[q][0] = wave_min_i32(lo0); dlo[q][1] = wave_min_i32(lo1); dlo[q][2] = wave_min_i32(lo2);
+    dhi[q][0] = -wave_min_i32(-hi0); dhi[q][1] = -wave_min_i32(-hi1); dhi[q][2] = -wave_min_i32(-hi2);
+  }
+
   __device__ __forceinline__ double heur_jps(int x, int y, int z) const {  // graph_search.cpp:72-74, eps = 1
     return sqrt((double)dist2(x, y, z));
   }
@@ -714,6 +831,8 @@ struct Planner {
     gi = (int*)(gg + CAP_G);
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     const int nxy = mv.nx * mv.ny;
+    dirty_box(s, 0);
+    dirty_box(t, 1);
     {
       HE e;
       e.id = sid; e.g = 0.0; e.f = 0.0 + heur_jps(s[0], s[1], s[2]);
@@ -805,7 +924,7 @@ template <bool JPS>
 __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
   __shared__ __attribute__((aligned(16))) char lds[JPS ? JPS_LDS_BYTES : PLAN_LDS_BYTES];
   Planner pl(mv, lds);
-  if (JPS) pl.init_jps(lds, pa.jps_tables);
+  if (JPS) pl.init_jps(lds, pa.jps_tables, pa.jps_entries);
   const int lane = pl.lane;
   const int wave = (int)blockIdx.x;
   CellState* cells = pa.cells + (size_t)wave * mv.total;
@@ -926,6 +1045,65 @@ __global__ void __launch_bounds__(256) plan_order_scatter_kernel(const double* s
   }
   __syncthreads();
   if (i < n) order[base[k] + mine] = i;
+}
+
+// Jump tables of a map (see Planner::jt): one launch per level (1 straight, 2 plane-diagonal, 3 space-diagonal; a level reads the
+// entries of the levels below).  A thread owns one line of cells in one direction — it starts from the cell whose successor lies
+// outside the grid and walks backwards, so every entry costs one step: entry(c) = -1 if c + d is blocked, +1 if the jump ends at
+// c + d (forced neighbour there, or a lower jump from there that ends), else entry(c + d) one further away.
+__global__ void __launch_bounds__(256) jps_table_kernel(MapView mv, const unsigned char* tb, short* jt, int level) {
+  const int ndirs = level == 1 ? 6 : (level == 2 ? 12 : 8);
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)mv.total * ndirs) return;
+  const int cell = (int)(gid % mv.total), which = (int)(gid / mv.total);
+  int code = 0;
+  for (int c = 0, seen = 0; c < 27; c++) {
+    const int n1 = abs(c % 3 - 1) + abs((c / 3) % 3 - 1) + abs(c / 9 - 1);
+    if (n1 == level) {
+      if (seen == which) { code = c; break; }
+      seen++;
+    }
+  }
+  const int dx = code % 3 - 1, dy = (code / 3) % 3 - 1, dz = code / 9 - 1;
+  const int nxy = mv.nx * mv.ny;
+  int z = cell / nxy, y = (cell - z * nxy) / mv.nx, x = cell - z * nxy - y * mv.nx;
+  auto outside = [&](int px, int py, int pz) { return px < 0 || py < 0 || pz < 0 || px >= mv.nx || py >= mv.ny || pz >= mv.nz; };
+  auto occupied = [&](int px, int py, int pz) {
+    if (outside(px, py, pz)) return false;
+    const int id = px + mv.nx * py + nxy * pz;
+    return ((mv.bits[id >> 5] >> (id & 31)) & 1u) != 0u;
+  };
+  if (!outside(x + dx, y + dy, z + dz)) return;  // not the last cell of its line
+  const int nsub = level == 1 ? 0 : (level == 2 ? 2 : 6), nforced = level == 3 ? 6 : 8;
+  short* mine = jt + (size_t)code * mv.total;
+  while (!outside(x, y, z)) {
+    const int X = x + dx, Y = y + dy, Z = z + dz;
+    short val;
+    if (outside(X, Y, Z) || occupied(X, Y, Z)) val = -1;
+    else {
+      const int xid = X + mv.nx * Y + nxy * Z;
+      bool ends = false, unknown = false;
+      for (int fn = 0; fn < nforced; fn++) {
+        const unsigned pk = tb[27 * 28 + code * 12 + fn];
+        ends = ends || occupied(X + (int)(pk & 3u) - 1, Y + (int)((pk >> 2) & 3u) - 1, Z + (int)((pk >> 4) & 3u) - 1);
+      }
+      for (int k = 0; k < nsub && !ends; k++) {
+        const unsigned pk = tb[code * 28 + k];
+        const int c2 = (int)((pk & 3u) + 3u * ((pk >> 2) & 3u) + 9u * ((pk >> 4) & 3u));
+        const short v = jt[(size_t)c2 * mv.total + xid];
+        ends = v > 0;
+        unknown = unknown || v == 0;
+      }
+      if (ends) val = 1;
+      else if (unknown) val = 0;
+      else {
+        const short nxt = mine[xid];
+        val = (nxt == 0 || nxt >= 32766 || nxt <= -32766) ? (short)0 : (short)(nxt > 0 ? nxt + 1 : nxt - 1);
+      }
+    }
+    mine[x + mv.nx * y + nxy * z] = val;
+    x -= dx; y -= dy; z -= dz;
+  }
 }
 
 // MapUtil::readMap (read_map.hpp:100-185): every point marks its cell and the cube of +-m cells around it; the flat index test is
