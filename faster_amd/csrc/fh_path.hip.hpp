@@ -494,10 +494,10 @@ struct Planner {
   //   * a space-diagonal jump does the same for 8 diagonal cells x (3 straight + 3 plane-diagonal jumps), one jump per lane.
   // A jump only returns "some cell of this ray ends it" and the diagonal cell it happened at, so the order in which the lanes
   // find that out does not matter: the successor list and its order are jps3d's.
-  // The heap is jps3d's binary heap, top 512 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
+  // The heap is jps3d's binary heap, top 432 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
   // program that all lanes execute; the position of an entry whose key decreases is found by a lane-parallel scan.
   // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
-  static constexpr int CAP_L = 512, CAP_G = 60000;
+  static constexpr int CAP_L = 432, CAP_G = 60000;  // (432: 10 044 B of LDS with the tables -> 16 workgroups per CU)
   double* hf;            // LDS [CAP_L]
   double* hg;
   int* hid;
@@ -608,7 +608,7 @@ struct Planner {
     for (int b = 0; b < n; b += 64) {
       const int i = b + lane;
       int v = -1;
-      if (i < n) v = i < CAP_L ? hid[i] : gi[i - CAP_L];
+      if (i < n) v = (i < CAP_L ? hid[i] : gi[i - CAP_L]) & IDMASK;
       const unsigned long long m = __ballot(v == id);
       if (m) return b + (int)__builtin_ctzll(m);
     }
@@ -626,8 +626,12 @@ struct Planner {
   //     ray of the jump could pass, the entry is not used and the jump is evaluated cell by cell with the entries one level down;
   //   * the goal on a straight ray is arithmetic.
   const short* jt;
+#ifdef FHP_STATS
+  mutable int stat_rounds = 0;
+#endif
   int dlo[2][3], dhi[2][3];
   static constexpr int BIGK = 1 << 28;
+  static constexpr int IDMASK = (1 << 27) - 1;  // heap entries: cell | direction id << 27 (a map has at most 2^27 cells)
 
   __device__ __forceinline__ int tube_contact(int bx, int by, int bz, int ax, int ay, int az, int kend) const {
     int best = BIGK;
@@ -683,6 +687,9 @@ struct Planner {
     bool res = false;
     int qx = px, qy = py, qz = pz;
     while (__ballot(active)) {
+#ifdef FHP_STATS
+      stat_rounds++;
+#endif
       if (active) {
         const unsigned pk = phase == 0 ? d2 : (phase == 2 ? b : a);
         const int ax = ux(pk), ay = uy(pk), az = uz(pk), dcode = code_of(pk);
@@ -835,7 +842,7 @@ struct Planner {
     dirty_box(t, 1);
     {
       HE e;
-      e.id = sid; e.g = 0.0; e.f = 0.0 + heur_jps(s[0], s[1], s[2]);
+      e.id = sid | (13 << 27); e.g = 0.0; e.f = 0.0 + heur_jps(s[0], s[1], s[2]);
       hset(0, e);
       if (lane == 0) {
         CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = (serial << 6) | (13u << 1);
@@ -853,57 +860,104 @@ struct Planner {
         const HE last = hget(n);
         sift_down(0, last, n);
       }
-      const int cur = rfl(top.id);
-      settle();
-      const unsigned cstamp = (unsigned)rfl((int)cells[cur].stamp);
-      if (lane == 0) cells[cur].stamp = cstamp | 1u;
+      const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
+      if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
+#ifdef FHP_STATS
+      expansions += (long long)stat_rounds << 40;
+      stat_rounds = 0;
+#endif
       if (cur == tid) break;
       const int cz = cur / nxy, rem = cur - cz * nxy, cy = rem / mv.nx, cx = rem - cy * mv.nx;
-      const int code = (int)((cstamp >> 1) & 31u);
       const int n1 = abs(code % 3 - 1) + abs((code / 3) % 3 - 1) + abs(code / 9 - 1);
       const int num_neib = n1 == 0 ? 26 : (n1 == 1 ? 1 : (n1 == 2 ? 3 : 7)), num_fneib = n1 == 0 ? 0 : (n1 == 1 ? 8 : 12);
-      // which of the forced-neighbour entries apply (getJpsSucc, :346-366): one per lane
-      unsigned long long fm;
-      {
-        const unsigned pk = byte_of(jf1 + code * 3, lane < 12 ? lane : 0);
-        fm = __ballot(lane < num_fneib && occ_any(cx + ux(pk), cy + uy(pk), cz + uz(pk)));
-      }
-      for (int dev = 0; dev < num_neib + num_fneib; dev++) {  // successor by successor, in getJpsSucc's order
-        unsigned pk;
-        if (dev < num_neib) pk = nat(code, dev);
-        else {
-          const int k = dev - num_neib;
-          if (!((fm >> k) & 1ull)) continue;
-          pk = byte_of(jf2 + code * 3, k);
+      // ---- the successors (getJpsSucc, :318-368), one candidate per lane in jps3d's order: lanes < num_neib the natural neighbours,
+      // then the forced-neighbour entries.  A lane settles its jump from the jump tables when it can; the others are evaluated one
+      // after the other by the whole wavefront.
+      const bool cand = lane < num_neib + num_fneib;
+      const int fk = (cand && lane >= num_neib) ? lane - num_neib : 0;
+      const unsigned fpk = byte_of(jf1 + code * 3, fk);
+      const unsigned pk = !cand ? 0x15u : (lane < num_neib ? nat(code, lane) : byte_of(jf2 + code * 3, fk));
+      const bool applies = occ_any(cx + ux(fpk), cy + uy(fpk), cz + uz(fpk)) || lane < num_neib;
+      const int ax = ux(pk), ay = uy(pk), az = uz(pk), pcode = code_of(pk);
+      const int J = cand ? entry(pcode, cx, cy, cz) : 0;
+      int status = 2, jk = 0;  // 0 no successor, 1 a successor jk cells away, 2 not settled
+      if (J != 0) {
+        if (abs(ax) + abs(ay) + abs(az) == 1) {
+          const int kend = abs(J);
+          const int k0 = tube_contact(cx, cy, cz, ax, ay, az, kend), kt = goal_on_ray(cx, cy, cz, ax, ay, az);
+          if (k0 > kend) {
+            if (kt < kend || (kt == kend && J > 0)) { status = 1; jk = kt; }
+            else if (J > 0) { status = 1; jk = J; }
+            else status = 0;
+          } else if (kt < k0) { status = 1; jk = kt; }
+        } else if (cone_clean(cx, cy, cz, ax, ay, az)) {
+          status = J > 0 ? 1 : 0;
+          jk = J;
         }
-        int jx, jy, jz;
-        if (!jump(cx, cy, cz, pk, jx, jy, jz)) continue;
-        jx = rfl(jx); jy = rfl(jy); jz = rfl(jz);
-        const int nid = index(jx, jy, jz);
-        settle();
-        const CellState ns = cells[nid];
-        const bool visited = (ns.stamp >> 6) == serial;
-        const bool closed = visited && (ns.stamp & 1u);
-        const int ex = jx - cx, ey = jy - cy, ez = jz - cz;
+      }
+      if (!cand || !applies) status = 0;
+      int jx = cx + jk * ax, jy = cy + jk * ay, jz = cz + jk * az;
+      for (unsigned long long um = __ballot(status == 2); um; um &= um - 1ull) {
+        const int j = (int)__builtin_ctzll(um);
+        int ox, oy, oz;
+#ifdef FHP_STATS
+        expansions += 1ll << 20;
+#endif
+        const bool found = jump(cx, cy, cz, (unsigned)__builtin_amdgcn_readlane((int)pk, j), ox, oy, oz);
+        if (lane == j) {
+          status = found ? 1 : 0;
+          jx = ox; jy = oy; jz = oz;
+        }
+      }
+      const bool ok = status == 1;
+      const int nid = ok ? index(jx, jy, jz) : cur;
+      settle();
+      const CellState ns = cells[nid];
+      const unsigned long long okm = __ballot(ok);
+      // a cell reached by two successors of this node: the second sees what the first wrote
+      bool dup = false;
+      if (__popcll(okm) > 1)
+        for (unsigned long long m2 = okm; m2; m2 &= m2 - 1ull) {
+          const int i = (int)__builtin_ctzll(m2);
+          if (ok && i < lane && __builtin_amdgcn_readlane(nid, i) == nid) dup = true;
+        }
+      const unsigned long long dupm = __ballot(dup);
+      for (unsigned long long m2 = okm; m2; m2 &= m2 - 1ull) {  // relaxed successor by successor, in getJpsSucc's order (:150-191)
+        const int j = (int)__builtin_ctzll(m2);
+        const int nj = __builtin_amdgcn_readlane(nid, j);
+        const int sx = __builtin_amdgcn_readlane(jx, j), sy = __builtin_amdgcn_readlane(jy, j), sz = __builtin_amdgcn_readlane(jz, j);
+        unsigned nstamp = (unsigned)__builtin_amdgcn_readlane((int)ns.stamp, j);
+        double ng = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ns.g), j), __builtin_amdgcn_readlane(__double2loint(ns.g), j));
+        if ((dupm >> j) & 1ull) {
+          settle();
+          const CellState again = cells[nj];
+          nstamp = (unsigned)rfl((int)again.stamp);
+          ng = __hiloint2double(rfl(__double2hiint(again.g)), rfl(__double2loint(again.g)));
+        }
+        const bool visited = (nstamp >> 6) == serial;
+        const bool closed = visited && (nstamp & 1u);
+        const int ex = sx - cx, ey = sy - cy, ez = sz - cz;
         const double cost = sqrt((double)(ex * ex + ey * ey + ez * ez));
-        const double tentative = top.g + cost;  // :150-191
-        if (!visited || tentative < ns.g) {
-          unsigned ncode = visited ? ((ns.stamp >> 1) & 31u) : (unsigned)code_of(pk);
+        const double tentative = top.g + cost;
+        if (!visited || tentative < ng) {
+          unsigned ncode = visited ? ((nstamp >> 1) & 31u) : (unsigned)__builtin_amdgcn_readlane(pcode, j);
           HE me;
-          me.id = nid; me.g = tentative; me.f = tentative + heur_jps(jx, jy, jz);
+          me.g = tentative; me.f = tentative + heur_jps(sx, sy, sz);
           if (visited && !closed) {  // pq_.increase, and the direction becomes the sign of the move (:176-181)
-            const int pos = heap_find(nid, n);
+            const int pos = heap_find(nj, n);
             if (pos < 0) return -2;  // (cannot happen)
-            sift_up(pos, me);
             ncode = (unsigned)((ex > 0 ? 2 : (ex < 0 ? 0 : 1)) + 3 * (ey > 0 ? 2 : (ey < 0 ? 0 : 1)) + 9 * (ez > 0 ? 2 : (ez < 0 ? 0 : 1)));
+            me.id = nj | (int)(ncode << 27);
+            sift_up(pos, me);
           } else if (!visited) {
             if (n >= CAP_L + CAP_G) return -2;
+            me.id = nj | (int)(ncode << 27);
             sift_up(n, me);
             n++;
           }  // (closed: jps3d updates g and the parent and goes on)
           if (lane == 0) {
             CellState w; w.g = tentative; w.parent = cur; w.stamp = (serial << 6) | (ncode << 1) | (closed ? 1u : 0u);
-            cells[nid] = w;
+            cells[nj] = w;
           }
         }
       }
