@@ -91,6 +91,7 @@ struct Planner {
   const MapView& mv;
   int lane;
   int s[3], t[3];  // start / goal cells (uniform)
+  bool boxes_matter = true;
   // LDS
   short* cnext;  // [NCHUNK] next chunk of a bucket
   short* fstack; // [NCHUNK] free chunks (stack)
@@ -124,6 +125,7 @@ struct Planner {
   }
   __device__ __forceinline__ int index(int x, int y, int z) const { return x + mv.nx * y + mv.nx * mv.ny * z; }
   __device__ __forceinline__ bool freed(int x, int y, int z) const {  // setFreeVoxelAndSurroundings around start and goal
+    if (!boxes_matter) return false;  // (jump point search: no occupied cell inside the two cubes, so freeing them changes nothing)
     const int m = mv.m_free;
     const bool a = x >= s[0] - m && x <= s[0] + m && y >= s[1] - m && y <= s[1] + m && z >= s[2] - m && z <= s[2] + m;
     const bool b = x >= t[0] - m && x <= t[0] + m && y >= t[1] - m && y <= t[1] + m && z >= t[2] - m && z <= t[2] + m;
@@ -578,7 +580,38 @@ struct Planner {
     if (a.f >= b.f - 0.000001 && a.f <= b.f + 0.000001) return a.g < b.g;
     return a.f > b.f;
   }
+  __device__ __forceinline__ static bool lower_fg(double af, double ag, double bf, double bg) {
+    if (af >= bf - 0.000001 && af <= bf + 0.000001) return ag < bg;
+    return af > bf;
+  }
+  // the same two walks for entries that all sit in LDS (both children of a node come from one read each)
+  __device__ void sift_up_lds(int i, const HE& m) {
+    while (i != 0) {
+      const int p = (i - 1) / 2;
+      const double pf = hf[p], pg = hg[p];
+      const int pid = hid[p];
+      if (!lower_fg(pf, pg, m.f, m.g)) break;
+      if (lane == 0) { hf[i] = pf; hg[i] = pg; hid[i] = pid; }
+      i = p;
+    }
+    if (lane == 0) { hf[i] = m.f; hg[i] = m.g; hid[i] = m.id; }
+  }
+  __device__ void sift_down_lds(int i, const HE& m, int n) {  // n <= CAP_L
+    for (;;) {
+      const int first = 2 * i + 1;
+      if (first >= n) break;
+      const double f0 = hf[first], f1 = hf[first + 1], g0 = hg[first], g1 = hg[first + 1];  // (first + 1 == n: read, not used)
+      const int i0 = hid[first], i1 = hid[first + 1];
+      const bool right = first + 1 < n && lower_fg(f0, g0, f1, g1);
+      const double bf = right ? f1 : f0, bg = right ? g1 : g0;
+      if (lower_fg(bf, bg, m.f, m.g)) break;
+      if (lane == 0) { hf[i] = bf; hg[i] = bg; hid[i] = right ? i1 : i0; }
+      i = first + (right ? 1 : 0);
+    }
+    if (lane == 0) { hf[i] = m.f; hg[i] = m.g; hid[i] = m.id; }
+  }
   __device__ void sift_up(int i, const HE& m) {
+    if (i < CAP_L) { sift_up_lds(i, m); return; }
     while (i != 0) {
       const int p = (i - 1) / 2;
       const HE pe = hget(p);
@@ -589,6 +622,7 @@ struct Planner {
     hset(i, m);
   }
   __device__ void sift_down(int i, const HE& m, int n) {
+    if (n <= CAP_L) { sift_down_lds(i, m, n); return; }
     for (;;) {
       const int first = 2 * i + 1;
       if (first >= n) break;
@@ -635,6 +669,7 @@ struct Planner {
 
   __device__ __forceinline__ int tube_contact(int bx, int by, int bz, int ax, int ay, int az, int kend) const {
     int best = BIGK;
+    if (!boxes_matter) return best;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       int lo, hi, ba, sg;
@@ -667,6 +702,7 @@ struct Planner {
   // may the entry of a diagonal jump from (x, y, z) be used
   __device__ __forceinline__ bool cone_clean(int x, int y, int z, int ax, int ay, int az) const {
     bool dirty = false;
+    if (boxes_matter)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const bool mx = ax > 0 ? dhi[q][0] >= x : (ax < 0 ? dlo[q][0] <= x : (dlo[q][0] - 1 <= x && x <= dhi[q][0] + 1));
@@ -838,8 +874,10 @@ struct Planner {
     gi = (int*)(gg + CAP_G);
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     const int nxy = mv.nx * mv.ny;
+    boxes_matter = true;
     dirty_box(s, 0);
     dirty_box(t, 1);
+    boxes_matter = dlo[0][0] <= dhi[0][0] || dlo[1][0] <= dhi[1][0];
     {
       HE e;
       e.id = sid | (13 << 27); e.g = 0.0; e.f = 0.0 + heur_jps(s[0], s[1], s[2]);
@@ -851,15 +889,26 @@ struct Planner {
     }
     int n = 1;
     long long pops = 0;
+#ifdef FHP_STATS2
+    long long tacc[5] = {0, 0, 0, 0, 0};
+#endif
     for (;;) {  // graph_search.cpp:123-217
       expansions++;
       if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
+#ifdef FHP_STATS2
+      const long long c0 = clock64();
+#endif
       const HE top = hget(0);
       n--;
       if (n > 0) {
         const HE last = hget(n);
         sift_down(0, last, n);
       }
+#ifdef FHP_STATS2
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const long long c1 = clock64();
+      tacc[0] += c1 - c0;
+#endif
       const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
       if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
 #ifdef FHP_STATS
@@ -897,6 +946,10 @@ struct Planner {
       }
       if (!cand || !applies) status = 0;
       int jx = cx + jk * ax, jy = cy + jk * ay, jz = cz + jk * az;
+#ifdef FHP_STATS2
+      const long long c2 = clock64() + (status & 0);
+      tacc[1] += c2 - c1;
+#endif
       for (unsigned long long um = __ballot(status == 2); um; um &= um - 1ull) {
         const int j = (int)__builtin_ctzll(um);
         int ox, oy, oz;
@@ -911,9 +964,21 @@ struct Planner {
       }
       const bool ok = status == 1;
       const int nid = ok ? index(jx, jy, jz) : cur;
+      // per successor, all at once: the cost of the move, h of the jump point, the direction id of the sign of the move
+      const int ex = jx - cx, ey = jy - cy, ez = jz - cz;
+      const double lcost = sqrt((double)(ex * ex + ey * ey + ez * ez)), lheur = heur_jps(jx, jy, jz);
+      const int lsign = (ex > 0 ? 2 : (ex < 0 ? 0 : 1)) + 3 * (ey > 0 ? 2 : (ey < 0 ? 0 : 1)) + 9 * (ez > 0 ? 2 : (ez < 0 ? 0 : 1));
+#ifdef FHP_STATS2
+      const long long c3 = clock64();
+      tacc[2] += c3 - c2;
+#endif
       settle();
       const CellState ns = cells[nid];
       const unsigned long long okm = __ballot(ok);
+#ifdef FHP_STATS2
+      const long long c4 = clock64() + (ns.stamp & 0);
+      tacc[3] += c4 - c3;
+#endif
       // a cell reached by two successors of this node: the second sees what the first wrote
       bool dup = false;
       if (__popcll(okm) > 1)
@@ -925,7 +990,6 @@ struct Planner {
       for (unsigned long long m2 = okm; m2; m2 &= m2 - 1ull) {  // relaxed successor by successor, in getJpsSucc's order (:150-191)
         const int j = (int)__builtin_ctzll(m2);
         const int nj = __builtin_amdgcn_readlane(nid, j);
-        const int sx = __builtin_amdgcn_readlane(jx, j), sy = __builtin_amdgcn_readlane(jy, j), sz = __builtin_amdgcn_readlane(jz, j);
         unsigned nstamp = (unsigned)__builtin_amdgcn_readlane((int)ns.stamp, j);
         double ng = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ns.g), j), __builtin_amdgcn_readlane(__double2loint(ns.g), j));
         if ((dupm >> j) & 1ull) {
@@ -936,17 +1000,17 @@ struct Planner {
         }
         const bool visited = (nstamp >> 6) == serial;
         const bool closed = visited && (nstamp & 1u);
-        const int ex = sx - cx, ey = sy - cy, ez = sz - cz;
-        const double cost = sqrt((double)(ex * ex + ey * ey + ez * ez));
+        const double cost = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lcost), j), __builtin_amdgcn_readlane(__double2loint(lcost), j));
         const double tentative = top.g + cost;
         if (!visited || tentative < ng) {
           unsigned ncode = visited ? ((nstamp >> 1) & 31u) : (unsigned)__builtin_amdgcn_readlane(pcode, j);
           HE me;
-          me.g = tentative; me.f = tentative + heur_jps(sx, sy, sz);
+          me.g = tentative;
+          me.f = tentative + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lheur), j), __builtin_amdgcn_readlane(__double2loint(lheur), j));
           if (visited && !closed) {  // pq_.increase, and the direction becomes the sign of the move (:176-181)
             const int pos = heap_find(nj, n);
             if (pos < 0) return -2;  // (cannot happen)
-            ncode = (unsigned)((ex > 0 ? 2 : (ex < 0 ? 0 : 1)) + 3 * (ey > 0 ? 2 : (ey < 0 ? 0 : 1)) + 9 * (ez > 0 ? 2 : (ez < 0 ? 0 : 1)));
+            ncode = (unsigned)__builtin_amdgcn_readlane(lsign, j);
             me.id = nj | (int)(ncode << 27);
             sift_up(pos, me);
           } else if (!visited) {
@@ -961,8 +1025,15 @@ struct Planner {
           }
         }
       }
+#ifdef FHP_STATS2
+      tacc[4] += clock64() - c4;
+#endif
       if (n == 0) return 0;
     }
+#ifdef FHP_STATS2
+    expansions = 0;
+    for (int i = 0; i < 5; i++) expansions |= (long long)((tacc[i] / pops) & 0xfff) << (12 * i);
+#endif
     settle();
     return finish_path(cells, chunks, sid, tid);
   }
