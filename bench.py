@@ -145,13 +145,13 @@ def main():
         args.max_poly = 8
         if args.front == "device":
             fctx, fmap = capi.Context(local_rank), capi.Map(local_rank)
-            frontend.forest_batch(256, seed=seed + 2, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank)  # allocations
+            frontend.forest_batch(256, seed=seed + 2, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank, search="jps")  # allocations
             whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap,
-                                                        device=local_rank)
+                                                        device=local_rank, search="jps")
             fctx.close()
             fmap.close()
         else:
-            whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8)
+            whole, faces, finfo = frontend.forest_batch(args.pairs, seed=seed + 2, n_seg=N, max_poly=8, search="jps")
     else:
         whole, faces, _ = corridor.whole_batch(args.pairs, seed=seed, n_seg=N, p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
     total_pairs = len(whole)  # (c5: pairs without a path are dropped)
@@ -540,8 +540,8 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
     N = 15
     fctx, fmap = capi.Context(local_rank), capi.Map(local_rank)
     try:
-        frontend.forest_batch(256, seed=5, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank)  # allocations
-        whole, faces, finfo = frontend.forest_batch(pairs, seed=5, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank)
+        frontend.forest_batch(256, seed=5, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank, search="jps")  # allocations
+        whole, faces, finfo = frontend.forest_batch(pairs, seed=5, n_seg=N, max_poly=8, front="device", ctx=fctx, vmap=fmap, device=local_rank, search="jps")
     finally:
         fmap.close()
     B = len(whole)
@@ -582,7 +582,9 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
                         "corridors from the device front-end; one fused launch alone on the GPU" % (B, pairs),
             "kernel": "fh::solve_kernel<15, true>", "pairs": B, "step_ms_median": med, "pairs_per_s": B / (med * 1e-3), "repetitions": reps,
             "front_end": {"map_s": ft["map_s"], "path_search_s": ft["path_search_s"], "decomposition_s": ft["decomposition_s"],
-                          "corridors_per_s": pairs / front_s, "expansions": ft["expansions"]},
+                          "corridors_per_s": pairs / front_s, "expansions": ft["expansions"],
+                          "path_search": "jump point search in jps3d's own order (fh_map_set_search 1): FASTER's exact vertex lists; the jump "
+                                         "tables of the map are built inside path_search_s"},
             "front_end_plus_solver_pairs_per_s": B / (front_s + med * 1e-3),
             "whole_solved_frac": float(wres["solved"].mean()),
             "safe_problems": live, "safe_solved_frac": float(sres["solved"].sum() / max(live, 1)),

@@ -660,9 +660,6 @@ struct Planner {
   //     ray of the jump could pass, the entry is not used and the jump is evaluated cell by cell with the entries one level down;
   //   * the goal on a straight ray is arithmetic.
   const short* jt;
-#ifdef FHP_STATS
-  mutable int stat_rounds = 0;
-#endif
   int dlo[2][3], dhi[2][3];
   static constexpr int BIGK = 1 << 28;
   static constexpr int IDMASK = (1 << 27) - 1;  // heap entries: cell | direction id << 27 (a map has at most 2^27 cells)
@@ -723,9 +720,6 @@ struct Planner {
     bool res = false;
     int qx = px, qy = py, qz = pz;
     while (__ballot(active)) {
-#ifdef FHP_STATS
-      stat_rounds++;
-#endif
       if (active) {
         const unsigned pk = phase == 0 ? d2 : (phase == 2 ? b : a);
         const int ax = ux(pk), ay = uy(pk), az = uz(pk), dcode = code_of(pk);
@@ -889,32 +883,18 @@ struct Planner {
     }
     int n = 1;
     long long pops = 0;
-#ifdef FHP_STATS2
-    long long tacc[5] = {0, 0, 0, 0, 0};
-#endif
     for (;;) {  // graph_search.cpp:123-217
       expansions++;
       if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
-#ifdef FHP_STATS2
-      const long long c0 = clock64();
-#endif
       const HE top = hget(0);
       n--;
       if (n > 0) {
         const HE last = hget(n);
         sift_down(0, last, n);
       }
-#ifdef FHP_STATS2
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const long long c1 = clock64();
-      tacc[0] += c1 - c0;
-#endif
       const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
       if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
-#ifdef FHP_STATS
-      expansions += (long long)stat_rounds << 40;
-      stat_rounds = 0;
-#endif
+
       if (cur == tid) break;
       const int cz = cur / nxy, rem = cur - cz * nxy, cy = rem / mv.nx, cx = rem - cy * mv.nx;
       const int n1 = abs(code % 3 - 1) + abs((code / 3) % 3 - 1) + abs(code / 9 - 1);
@@ -946,16 +926,9 @@ struct Planner {
       }
       if (!cand || !applies) status = 0;
       int jx = cx + jk * ax, jy = cy + jk * ay, jz = cz + jk * az;
-#ifdef FHP_STATS2
-      const long long c2 = clock64() + (status & 0);
-      tacc[1] += c2 - c1;
-#endif
       for (unsigned long long um = __ballot(status == 2); um; um &= um - 1ull) {
         const int j = (int)__builtin_ctzll(um);
         int ox, oy, oz;
-#ifdef FHP_STATS
-        expansions += 1ll << 20;
-#endif
         const bool found = jump(cx, cy, cz, (unsigned)__builtin_amdgcn_readlane((int)pk, j), ox, oy, oz);
         if (lane == j) {
           status = found ? 1 : 0;
@@ -968,17 +941,9 @@ struct Planner {
       const int ex = jx - cx, ey = jy - cy, ez = jz - cz;
       const double lcost = sqrt((double)(ex * ex + ey * ey + ez * ez)), lheur = heur_jps(jx, jy, jz);
       const int lsign = (ex > 0 ? 2 : (ex < 0 ? 0 : 1)) + 3 * (ey > 0 ? 2 : (ey < 0 ? 0 : 1)) + 9 * (ez > 0 ? 2 : (ez < 0 ? 0 : 1));
-#ifdef FHP_STATS2
-      const long long c3 = clock64();
-      tacc[2] += c3 - c2;
-#endif
       settle();
       const CellState ns = cells[nid];
       const unsigned long long okm = __ballot(ok);
-#ifdef FHP_STATS2
-      const long long c4 = clock64() + (ns.stamp & 0);
-      tacc[3] += c4 - c3;
-#endif
       // a cell reached by two successors of this node: the second sees what the first wrote
       bool dup = false;
       if (__popcll(okm) > 1)
@@ -986,54 +951,59 @@ struct Planner {
           const int i = (int)__builtin_ctzll(m2);
           if (ok && i < lane && __builtin_amdgcn_readlane(nid, i) == nid) dup = true;
         }
+      // ---- relaxation (:150-191).  What does not depend on the order is done by all successors at once: the comparison with the
+      // stored g, the new cell record (a cell reached twice waits for its turn below).  The heap operations follow one after the
+      // other in getJpsSucc's order.
+      const bool visited = (ns.stamp >> 6) == serial;
+      const bool closed = visited && (ns.stamp & 1u);
+      const double tentative = top.g + lcost;
+      const bool improves = ok && !dup && (!visited || tentative < ns.g);
+      const int lcode = !visited ? pcode : (closed ? (int)((ns.stamp >> 1) & 31u) : lsign);  // an open node takes the sign of the move (:176-181)
+      const double lf = tentative + lheur;
+      if (improves) {
+        CellState w; w.g = tentative; w.parent = cur; w.stamp = (serial << 6) | ((unsigned)lcode << 1) | (closed ? 1u : 0u);
+        cells[nid] = w;  // (closed: jps3d updates g and the parent and goes on)
+      }
       const unsigned long long dupm = __ballot(dup);
-      for (unsigned long long m2 = okm; m2; m2 &= m2 - 1ull) {  // relaxed successor by successor, in getJpsSucc's order (:150-191)
+      for (unsigned long long m2 = __ballot((improves && !closed) || dup); m2; m2 &= m2 - 1ull) {
         const int j = (int)__builtin_ctzll(m2);
         const int nj = __builtin_amdgcn_readlane(nid, j);
-        unsigned nstamp = (unsigned)__builtin_amdgcn_readlane((int)ns.stamp, j);
-        double ng = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ns.g), j), __builtin_amdgcn_readlane(__double2loint(ns.g), j));
-        if ((dupm >> j) & 1ull) {
+        HE me;
+        bool push = !(bool)__builtin_amdgcn_readlane((int)visited, j);
+        if (!((dupm >> j) & 1ull)) {
+          me.g = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tentative), j), __builtin_amdgcn_readlane(__double2loint(tentative), j));
+          me.f = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lf), j), __builtin_amdgcn_readlane(__double2loint(lf), j));
+          me.id = nj | (__builtin_amdgcn_readlane(lcode, j) << 27);
+        } else {  // the cell was reached by an earlier successor of this node: its record is read again
           settle();
           const CellState again = cells[nj];
-          nstamp = (unsigned)rfl((int)again.stamp);
-          ng = __hiloint2double(rfl(__double2hiint(again.g)), rfl(__double2loint(again.g)));
-        }
-        const bool visited = (nstamp >> 6) == serial;
-        const bool closed = visited && (nstamp & 1u);
-        const double cost = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lcost), j), __builtin_amdgcn_readlane(__double2loint(lcost), j));
-        const double tentative = top.g + cost;
-        if (!visited || tentative < ng) {
-          unsigned ncode = visited ? ((nstamp >> 1) & 31u) : (unsigned)__builtin_amdgcn_readlane(pcode, j);
-          HE me;
-          me.g = tentative;
-          me.f = tentative + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lheur), j), __builtin_amdgcn_readlane(__double2loint(lheur), j));
-          if (visited && !closed) {  // pq_.increase, and the direction becomes the sign of the move (:176-181)
-            const int pos = heap_find(nj, n);
-            if (pos < 0) return -2;  // (cannot happen)
-            ncode = (unsigned)__builtin_amdgcn_readlane(lsign, j);
-            me.id = nj | (int)(ncode << 27);
-            sift_up(pos, me);
-          } else if (!visited) {
-            if (n >= CAP_L + CAP_G) return -2;
-            me.id = nj | (int)(ncode << 27);
-            sift_up(n, me);
-            n++;
-          }  // (closed: jps3d updates g and the parent and goes on)
+          const unsigned nstamp = (unsigned)rfl((int)again.stamp);
+          const double ng = __hiloint2double(rfl(__double2hiint(again.g)), rfl(__double2loint(again.g)));
+          const bool v2 = (nstamp >> 6) == serial, c2 = v2 && (nstamp & 1u);
+          me.g = top.g + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lcost), j), __builtin_amdgcn_readlane(__double2loint(lcost), j));
+          if (v2 && !(me.g < ng)) continue;
+          me.f = me.g + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lheur), j), __builtin_amdgcn_readlane(__double2loint(lheur), j));
+          const unsigned ncode = !v2 ? (unsigned)__builtin_amdgcn_readlane(pcode, j) : (c2 ? ((nstamp >> 1) & 31u) : (unsigned)__builtin_amdgcn_readlane(lsign, j));
+          me.id = nj | (int)(ncode << 27);
           if (lane == 0) {
-            CellState w; w.g = tentative; w.parent = cur; w.stamp = (serial << 6) | (ncode << 1) | (closed ? 1u : 0u);
+            CellState w; w.g = me.g; w.parent = cur; w.stamp = (serial << 6) | (ncode << 1) | (c2 ? 1u : 0u);
             cells[nj] = w;
           }
+          if (c2) continue;
+          push = !v2;
+        }
+        if (push) {
+          if (n >= CAP_L + CAP_G) return -2;
+          sift_up(n, me);
+          n++;
+        } else {  // pq_.increase
+          const int pos = heap_find(nj, n);
+          if (pos < 0) return -2;  // (cannot happen)
+          sift_up(pos, me);
         }
       }
-#ifdef FHP_STATS2
-      tacc[4] += clock64() - c4;
-#endif
       if (n == 0) return 0;
     }
-#ifdef FHP_STATS2
-    expansions = 0;
-    for (int i = 0; i < 5; i++) expansions |= (long long)((tacc[i] / pops) & 0xfff) << (12 * i);
-#endif
     settle();
     return finish_path(cells, chunks, sid, tid);
   }

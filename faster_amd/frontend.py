@@ -163,7 +163,7 @@ def forest_cloud(seed, size=(20.0, 20.0, 3.0), density=0.1, radius=0.3, spacing=
 
 
 def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation, starts, goals, max_poly, max_vertex_dist, faces_per_problem,
-                          drone_radius, z_ground=0.0, device=0):
+                          drone_radius, z_ground=0.0, device=0, search="astar"):
     """The corridor front-end on the device: fh_map_read + fh_map_plan_batch_device (path search, createMoreVertexes,
     deleteVertexes) + fh_corridor_batch_device (decomposition, rows in fh_problem's layout).  `ctx`: capi.Context, `vmap`: capi.Map.
     Returns host copies (faces [n][fpp][4], face_off [n][9], n_poly [n], goal [n][3]) and the device times in seconds."""
@@ -182,6 +182,7 @@ def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation
     d_off = torch.zeros((n, 9), dtype=torch.int32, device=dev)
     d_npoly = torch.zeros(n, dtype=torch.int32, device=dev)
     d_goal = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    vmap.set_search(search)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     vmap.read_device(d_cloud.data_ptr(), len(d_cloud), cells, res, center, z_ground, z_max, inflation)
@@ -201,25 +202,31 @@ def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation
 
 
 def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, drone_radius=0.05,
-                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, front="host", ctx=None, vmap=None, device=0, **kw):
+                 max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, front="host", ctx=None, vmap=None, device=0,
+                 search="astar", **kw):
     """BASELINE config 5: n start/goal pairs in one random forest; corridors from the voxel path search + ellipsoid
     decomposition: front="host" this CPU front-end (OpenMP), front="device" the same steps through the C ABI on the GPU
-    (capi.Map + capi.Context; no CPU fallback).  Returns (problems, faces, info)."""
+    (capi.Map + capi.Context; no CPU fallback).  search: "astar" (an optimal path, total order of its own) or "jps" (jump point search in
+    jps3d's own order: the path FASTER itself gets); host and device produce the same corridors bit for bit in either.
+    Returns (problems, faces, info)."""
     from . import corridor
 
     cloud, cells, center, starts, goals, rng = forest_queries(n, seed, size, res, inflation, min_goal_dist, return_rng=True)
     if front == "device":
         faces, face_off, n_poly, goal_out, timing = corridor_batch_device(ctx, vmap, cloud, cells, res, center, size[2], inflation, starts, goals,
-                                                                          max_poly, max_vertex_dist, faces_per_problem, drone_radius, device=device)
+                                                                          max_poly, max_vertex_dist, faces_per_problem, drone_radius, device=device,
+                                                                          search=search)
         overflow = 0
     else:
         faces = np.zeros((n, faces_per_problem, 4))
         face_off = np.zeros((n, 9), dtype=np.int32)
         n_poly = np.zeros(n, dtype=np.int32)
         goal_out = np.zeros((n, 3))
+        set_search(search)
         overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
                                            inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
                                            faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
+        set_search("astar")
         timing = None
     ok = n_poly > 0
     counts = face_off[np.arange(n), n_poly]

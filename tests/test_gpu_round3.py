@@ -11,6 +11,11 @@ from faster_amd import abi, capi, corridor
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _torch_first():
+    import torch  # noqa: F401  (torch before the HIP library: one HIP runtime in the process)
+
+
 @pytest.fixture(scope="module")
 def ctx():
     import torch  # noqa: F401  (torch first: one HIP runtime in the process)
@@ -431,3 +436,24 @@ def test_device_jump_point_search_against_the_reference_sources(ref):
             total += 1
         rm.close()
     assert total >= 300
+
+
+def test_device_corridor_front_end_with_jump_point_search_equals_host(ctx):
+    """Config C5's whole front-end (map -> jump point search in jps3d's order -> createMoreVertexes / deleteVertexes -> decomposition)
+    on the device against the CPU front-end run with plan_path_jps: the same pairs kept, every problem field and every polytope row
+    bit for bit.  These are the corridors FASTER itself would build (its own path, its own decomposition)."""
+    from faster_amd import frontend
+
+    n = 3072
+    hp, hf, hi = frontend.forest_batch(n, 33, search="jps")
+    vmap = capi.Map(0)
+    try:
+        dp, df, di = frontend.forest_batch(n, 33, front="device", ctx=ctx, vmap=vmap, search="jps")
+    finally:
+        vmap.close()
+    assert np.array_equal(hi["kept"], di["kept"]) and len(hp) > 0.95 * n
+    for f in abi.problem_dtype.names:
+        assert np.array_equal(hp[f], dp[f]), f
+    assert hf.shape == df.shape and np.array_equal(hf["a"], df["a"]) and np.array_equal(hf["b"], df["b"])
+    ap, _, _ = frontend.forest_batch(256, 33)   # (the A* corridors differ: another of the equal-cost paths)
+    assert not np.array_equal(ap["face_off"], hp["face_off"][:len(ap)]) or len(ap) != 256
