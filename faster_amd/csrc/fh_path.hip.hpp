@@ -696,8 +696,8 @@ struct Planner {
     else { k = ez * az; off = abs(ex) + abs(ey); }
     return (off == 0 && k >= 1) ? k : BIGK;
   }
-  // may the entry of a diagonal jump from (x, y, z) be used
-  __device__ __forceinline__ bool cone_clean(int x, int y, int z, int ax, int ay, int az) const {
+  // does a box of changed cells meet the cone of a diagonal jump from (x, y, z)
+  __device__ __forceinline__ bool cone_dirty(int x, int y, int z, int ax, int ay, int az) const {
     bool dirty = false;
     if (boxes_matter)
 #pragma unroll
@@ -707,11 +707,56 @@ struct Planner {
       const bool mz = az > 0 ? dhi[q][2] >= z : (az < 0 ? dlo[q][2] <= z : (dlo[q][2] - 1 <= z && z <= dhi[q][2] + 1));
       dirty = dirty || (mx && my && mz);
     }
-    const int ex = t[0] - x, ey = t[1] - y, ez = t[2] - z;
-    const bool gx = ax ? ex * ax >= 1 : ex == 0, gy = ay ? ey * ay >= 1 : ey == 0, gz = az ? ez * az >= 1 : ez == 0;
-    return !dirty && !(gx && gy && gz);
+    return dirty;
   }
   __device__ __forceinline__ int entry(int code, int x, int y, int z) const { return (int)jt[(size_t)code * mv.total + index(x, y, z)]; }
+  // A diagonal jump from (x, y, z) along (ax, ay, az) from the entries alone, the goal included (the cone must be clean of changed
+  // cells).  -> 0 no jump point, 1 jump point k cells away, 2 not known.
+  // The goal can only end the jump at the diagonal cell P_kg where the smallest of its offsets along the jump's axes runs out
+  // (before that a ray would need a diagonal move, after that it would have to go back): there it is the cell itself, or sits on a
+  // straight ray that leaves the cell, or (space diagonal) in reach of the plane-diagonal jump that leaves it.
+  __device__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k) const {
+    const int J = entry((ax + 1) + 3 * (ay + 1) + 9 * (az + 1), x, y, z);
+    if (J == 0) return 2;
+    k = J;
+    const int plain = J > 0 ? 1 : 0;
+    const int o0 = (t[0] - x) * ax, o1 = (t[1] - y) * ay, o2 = (t[2] - z) * az;
+    if ((ax ? o0 < 1 : t[0] != x) || (ay ? o1 < 1 : t[1] != y) || (az ? o2 < 1 : t[2] != z)) return plain;  // the goal is not in the cone
+    const int kg = min(ax ? o0 : BIGK, min(ay ? o1 : BIGK, az ? o2 : BIGK));
+    if (kg > (J > 0 ? J : -J - 1)) return plain;  // the jump ends before P_kg
+    if (kg == J) return 1;
+    const int px = x + kg * ax, py = y + kg * ay, pz = z + kg * az;
+    const int r0 = ax ? o0 - kg : 0, r1 = ay ? o1 - kg : 0, r2 = az ? o2 - kg : 0;
+    const int npos = (r0 > 0) + (r1 > 0) + (r2 > 0);
+    bool hit;
+    if (npos == 0) hit = true;
+    else if (npos == 1) {
+      const int code = r0 > 0 ? 13 + ax : (r1 > 0 ? 13 + 3 * ay : 13 + 9 * az);
+      const int Js = entry(code, px, py, pz);
+      if (Js == 0) return 2;
+      hit = r0 + r1 + r2 <= (Js > 0 ? Js : -Js - 1);
+    } else {  // the plane-diagonal jump out of P_kg, in the plane of the two offsets that are left
+      const int bx = r0 > 0 ? ax : 0, by = r1 > 0 ? ay : 0, bz = r2 > 0 ? az : 0;
+      const int J2 = entry((bx + 1) + 3 * (by + 1) + 9 * (bz + 1), px, py, pz);
+      if (J2 == 0) return 2;
+      const int ra = r0 > 0 ? r0 : r1, rb = r2 > 0 ? r2 : r1;  // the two offsets
+      const int k2 = min(ra, rb);
+      hit = false;
+      if (k2 <= (J2 > 0 ? J2 : -J2 - 1)) {
+        if (ra == rb || k2 == J2) hit = true;
+        else {
+          const int qx = px + k2 * bx, qy = py + k2 * by, qz = pz + k2 * bz;
+          const int s0 = r0 > 0 ? r0 - k2 : 0, s1 = r1 > 0 ? r1 - k2 : 0, s2 = r2 > 0 ? r2 - k2 : 0;
+          const int code = s0 > 0 ? 13 + ax : (s1 > 0 ? 13 + 3 * ay : 13 + 9 * az);
+          const int Js = entry(code, qx, qy, qz);
+          if (Js == 0) return 2;
+          hit = s0 + s1 + s2 <= (Js > 0 ? Js : -Js - 1);
+        }
+      }
+    }
+    if (hit) { k = kg; return 1; }
+    return plain;
+  }
 
   // ---- jumps one per lane, in lock step.  phase 3: a straight jump along `a` from P; phase 0: a plane-diagonal jump along d2 from P
   // (0: next diagonal cell; 1 / 2: the straight jumps along a / b that leave it).  `grp` orders the lanes: when a lane has
@@ -724,10 +769,15 @@ struct Planner {
         const unsigned pk = phase == 0 ? d2 : (phase == 2 ? b : a);
         const int ax = ux(pk), ay = uy(pk), az = uz(pk), dcode = code_of(pk);
         const int bx = phase == 0 ? px : qx, by = phase == 0 ? py : qy, bz = phase == 0 ? pz : qz;
-        const int J = entry(dcode, bx, by, bz);
         int outcome = 0;  // 1 the jump along pk ends (true), 2 it is blocked, 3 examine the next cell, 0 go on (Q moved)
-        if (J == 0) outcome = 3;
-        else if (phase == 0) outcome = cone_clean(bx, by, bz, ax, ay, az) ? (J > 0 ? 1 : 2) : 3;
+        int J = 0;
+        if (phase == 0) {
+          int kk;
+          const int st = cone_dirty(bx, by, bz, ax, ay, az) ? 2 : diag_jump(bx, by, bz, ax, ay, az, kk);
+          outcome = st == 2 ? 3 : (st == 1 ? 1 : 2);
+        } else J = entry(dcode, bx, by, bz);
+        if (phase == 0) {}
+        else if (J == 0) outcome = 3;
         else {
           const int kend = abs(J);
           const int k0 = tube_contact(bx, by, bz, ax, ay, az, kend), kt = goal_on_ray(bx, by, bz, ax, ay, az);
@@ -813,11 +863,12 @@ struct Planner {
       b = nat(c2, 1);
     } else takes = false;
     for (;;) {
-      const int J = rfl(entry(code, bx, by, bz));
-      if (J != 0 && cone_clean(bx, by, bz, dx, dy, dz)) {
-        if (J < 0) return false;
-        ox = bx + J * dx; oy = by + J * dy; oz = bz + J * dz;
-        return true;
+      if (!cone_dirty(bx, by, bz, dx, dy, dz)) {
+        int kk = 0;
+        const int st = rfl(diag_jump(bx, by, bz, dx, dy, dz, kk));
+        kk = rfl(kk);
+        if (st == 0) return false;
+        if (st == 1) { ox = bx + kk * dx; oy = by + kk * dy; oz = bz + kk * dz; return true; }
       }
       const int k = (lane >> shift) + 1;
       const int x = bx + k * dx, y = by + k * dy, z = bz + k * dz;
@@ -908,10 +959,13 @@ struct Planner {
       const unsigned pk = !cand ? 0x15u : (lane < num_neib ? nat(code, lane) : byte_of(jf2 + code * 3, fk));
       const bool applies = occ_any(cx + ux(fpk), cy + uy(fpk), cz + uz(fpk)) || lane < num_neib;
       const int ax = ux(pk), ay = uy(pk), az = uz(pk), pcode = code_of(pk);
-      const int J = cand ? entry(pcode, cx, cy, cz) : 0;
+      const bool straight = abs(ax) + abs(ay) + abs(az) == 1;
+      const int J = (cand && straight) ? entry(pcode, cx, cy, cz) : 0;
       int status = 2, jk = 0;  // 0 no successor, 1 a successor jk cells away, 2 not settled
-      if (J != 0) {
-        if (abs(ax) + abs(ay) + abs(az) == 1) {
+      if (cand && !straight) {
+        if (!cone_dirty(cx, cy, cz, ax, ay, az)) status = diag_jump(cx, cy, cz, ax, ay, az, jk);
+      } else if (J != 0) {
+        {
           const int kend = abs(J);
           const int k0 = tube_contact(cx, cy, cz, ax, ay, az, kend), kt = goal_on_ray(cx, cy, cz, ax, ay, az);
           if (k0 > kend) {
@@ -919,9 +973,6 @@ struct Planner {
             else if (J > 0) { status = 1; jk = J; }
             else status = 0;
           } else if (kt < k0) { status = 1; jk = kt; }
-        } else if (cone_clean(cx, cy, cz, ax, ay, az)) {
-          status = J > 0 ? 1 : 0;
-          jk = J;
         }
       }
       if (!cand || !applies) status = 0;

@@ -457,3 +457,41 @@ def test_device_corridor_front_end_with_jump_point_search_equals_host(ctx):
     assert hf.shape == df.shape and np.array_equal(hf["a"], df["a"]) and np.array_equal(hf["b"], df["b"])
     ap, _, _ = frontend.forest_batch(256, 33)   # (the A* corridors differ: another of the equal-cost paths)
     assert not np.array_equal(ap["face_off"], hp["face_off"][:len(ap)]) or len(ap) != 256
+
+
+@pytest.mark.parametrize("kind", ["near_trees", "blobs_3d", "tight_cubes"])
+def test_device_jump_point_search_where_the_freed_cubes_and_3d_jumps_matter(host_jps, kind):
+    """The cases the jump tables have to hand over to the cell-by-cell evaluation: starts and goals INSIDE the inflated hull of a tree
+    (the cubes freed around them hold occupied cells, so entries near them do not hold), a map as high as it is wide with random
+    blobs (space-diagonal jumps, goals above and below), and a coarse inflation (big cubes) — device == plan_path_jps bit for bit."""
+    frontend = host_jps
+    rng = np.random.default_rng(11)
+    if kind == "near_trees":
+        cloud, centres = frontend.forest_cloud(3)
+        res, zg, zmax, infl = 0.2, 0.0, 3.0, 0.3
+        cells, center = (110, 110, 15), np.array([10.0, 10.0, 1.5])
+        n = 1536
+        ang = rng.uniform(0, 2 * np.pi, n)
+        near = centres[rng.integers(0, len(centres), n)] + np.column_stack([np.cos(ang), np.sin(ang)]) * rng.uniform(0.40, 0.75, (n, 1))
+        starts = np.column_stack([near, rng.uniform(0.8, 2.2, n)])
+        goals = np.column_stack([rng.uniform(2, 18, n), rng.uniform(2, 18, n), rng.uniform(0.8, 2.2, n)])
+        starts[n // 2:], goals[n // 2:] = goals[n // 2:].copy(), starts[n // 2:].copy()
+    else:
+        res, zg, zmax = 0.25, 0.0, 10.0
+        infl = 0.25 if kind == "blobs_3d" else 0.6
+        cells, center = (40, 40, 40), np.array([5.0, 5.0, 5.0])
+        blobs = rng.uniform(0.5, 9.5, (60, 3))
+        cloud = (blobs[:, None, :] + rng.normal(0, 0.25, (60, 40, 3))).reshape(-1, 3)
+        n = 1536
+        starts = rng.uniform(0.3, 9.7, (n, 3))
+        goals = rng.uniform(0.3, 9.7, (n, 3))
+    host = frontend.plan_batch(cloud, cells, res, center, zg, zmax, infl, starts, goals, max_points=128)
+    m = capi.Map(0)
+    try:
+        m.read(cloud, cells, res, center, zg, zmax, infl)
+        m.set_search("jps")
+        dev = m.plan_batch(starts, goals, max_points=128)
+    finally:
+        m.close()
+    assert (host[1] > 0).mean() > 0.8
+    _plans_equal(host, dev, kind)

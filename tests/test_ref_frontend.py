@@ -311,3 +311,27 @@ def test_jps_vertex_lists_equal_jps3d_on_the_c5_queries(ref, seed):
             assert len(p) == len(hp) and np.array_equal(p, hp), i
     m.close()
     assert found >= 150
+
+
+@pytest.mark.parametrize("inflation", [0.25, 0.6])
+def test_jps_vertex_lists_equal_jps3d_in_a_cubic_map_with_blobs(ref, inflation):
+    """A map as high as it is wide (40^3 cells) with random blobs: space-diagonal jumps, goals above and below the start, and (0.6 m
+    inflation at 0.25 m cells) large freed cubes that overlap the obstacles — plan_path_jps against the reference's compiled jps3d."""
+    rng = np.random.default_rng(11)
+    res, zg, zmax = 0.25, 0.0, 10.0
+    cells, center = (40, 40, 40), np.array([5.0, 5.0, 5.0])
+    blobs = rng.uniform(0.5, 9.5, (60, 3))
+    cloud = (blobs[:, None, :] + rng.normal(0, 0.25, (60, 40, 3))).reshape(-1, 3).astype(np.float32).astype(np.float64)
+    n = 160
+    starts, goals = rng.uniform(0.3, 9.7, (n, 3)), rng.uniform(0.3, 9.7, (n, 3))
+    m = ref.Map(cloud, cells, res, center, zg, zmax, inflation)
+    found = 0
+    for i in range(n):
+        p, cost, _ = m.plan(starts[i], goals[i], True)
+        hp, hcost, _ = frontend.plan_jps(cloud, cells, res, center, zg, zmax, inflation, starts[i], goals[i])
+        assert (p is None) == (hp is None), i
+        if p is not None:
+            found += 1
+            assert len(p) == len(hp) and np.array_equal(p, hp), i
+    m.close()
+    assert found >= 120
