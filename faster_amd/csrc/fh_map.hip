@@ -39,7 +39,7 @@ struct fh_map {
   size_t order_cap = 0;
   int search_mode = 0;                    // fh_map_set_search: 0 A* with a total order, 1 jump point search in jps3d's order
   unsigned char* d_jps_tables = nullptr;  // neighbour tables of the jump point search (uploaded by the first fh_map_set_search(1))
-  short* d_jps_entries = nullptr;         // jump tables of the current grid [27][cells] (fhp::jps_table_kernel), built by the first search in mode 1
+  short* d_jps_entries = nullptr;         // jump tables of the current grid [cells][32] (fhp::jps_table_kernel), built by the first search in mode 1
   size_t entries_cap = 0;
   bool entries_valid = false;
   // staging of the host-pointer entry points
@@ -297,7 +297,7 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.jps_entries = nullptr;
   if (m->search_mode == 1) {
     if (!m->entries_valid) {  // the jump tables of this grid: three small launches, once per map
-      const size_t need = (size_t)27 * mv.total * sizeof(short);
+      const size_t need = (size_t)32 * mv.total * sizeof(short);
       if (need > m->entries_cap) {
         FM_HIP(hipStreamSynchronize(m->stream));
         if (m->d_jps_entries) FM_HIP(hipFree(m->d_jps_entries));

@@ -64,7 +64,7 @@ struct PlanArgs {
   double max_vertex_dist;
   int max_poly;
   const unsigned char* jps_tables;  // jump point search only: the neighbour tables, see Planner::init_jps
-  const short* jps_entries;         // ... and the jump tables of this map [27][total], see jps_table_kernel
+  const short* jps_entries;         // ... and the jump tables of this map [total][32], see jps_table_kernel
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -649,7 +649,7 @@ struct Planner {
     return -1;
   }
 
-  // ---- jump tables (jps_table_kernel): jt[code * total + cell] = the outcome of the jump that leaves `cell` in direction `code` on
+  // ---- jump tables (jps_table_kernel): jt[cell * 32 + code] = the outcome of the jump that leaves `cell` in direction `code` on
   // the map as read — no goal, no cells freed around start and goal: +k the jump ends (forced neighbour, or a lower jump that ends)
   // k cells away, -k the k-th cell is blocked, 0 not known.  A query may use an entry when nothing it depends on has changed:
   //   * the cells that differ from the map as read are the occupied cells inside the two freed cubes: their bounding boxes are
@@ -709,7 +709,7 @@ struct Planner {
     }
     return dirty;
   }
-  __device__ __forceinline__ int entry(int code, int x, int y, int z) const { return (int)jt[(size_t)code * mv.total + index(x, y, z)]; }
+  __device__ __forceinline__ int entry(int code, int x, int y, int z) const { return (int)jt[(size_t)index(x, y, z) * 32 + code]; }  // the 27 entries of a cell share one 64-byte line
   // A diagonal jump from (x, y, z) along (ax, ay, az) from the entries alone, the goal included (the cone must be clean of changed
   // cells).  -> 0 no jump point, 1 jump point k cells away, 2 not known.
   // The goal can only end the jump at the diagonal cell P_kg where the smallest of its offsets along the jump's axes runs out
@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(256) jps_table_kernel(MapView mv, const unsign
   };
   if (!outside(x + dx, y + dy, z + dz)) return;  // not the last cell of its line
   const int nsub = level == 1 ? 0 : (level == 2 ? 2 : 6), nforced = level == 3 ? 6 : 8;
-  short* mine = jt + (size_t)code * mv.total;
+  short* mine = jt + code;  // [cell][32]: the entries of a cell side by side
   while (!outside(x, y, z)) {
     const int X = x + dx, Y = y + dy, Z = z + dz;
     short val;
@@ -1236,18 +1236,18 @@ __global__ void __launch_bounds__(256) jps_table_kernel(MapView mv, const unsign
       for (int k = 0; k < nsub && !ends; k++) {
         const unsigned pk = tb[code * 28 + k];
         const int c2 = (int)((pk & 3u) + 3u * ((pk >> 2) & 3u) + 9u * ((pk >> 4) & 3u));
-        const short v = jt[(size_t)c2 * mv.total + xid];
+        const short v = jt[(size_t)xid * 32 + c2];
         ends = v > 0;
         unknown = unknown || v == 0;
       }
       if (ends) val = 1;
       else if (unknown) val = 0;
       else {
-        const short nxt = mine[xid];
+        const short nxt = mine[(size_t)xid * 32];
         val = (nxt == 0 || nxt >= 32766 || nxt <= -32766) ? (short)0 : (short)(nxt > 0 ? nxt + 1 : nxt - 1);
       }
     }
-    mine[x + mv.nx * y + nxy * z] = val;
+    mine[(size_t)(x + mv.nx * y + nxy * z) * 32] = val;
     x -= dx; y -= dy; z -= dz;
   }
 }
