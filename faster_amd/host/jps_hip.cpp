@@ -17,7 +17,15 @@ bool JpsHip::ensureMap() {
     std::fprintf(stderr, "JpsHip: %s\n", err_.c_str());
     return false;
   }
-  return true;
+  rc_ = fh_map_set_search(map_, jump_point_search_ ? 1 : 0);
+  return rc_ == FH_OK;
+}
+
+bool JpsHip::setJumpPointSearch(bool on) {
+  jump_point_search_ = on;
+  if (!map_) return true;
+  rc_ = fh_map_set_search(map_, on ? 1 : 0);
+  return rc_ == FH_OK;
 }
 
 bool JpsHip::updateJPSMap(const std::vector<fhfront::V3>& cloud, const fhfront::V3& center) {

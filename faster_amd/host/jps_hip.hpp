@@ -3,7 +3,9 @@
 // Reference: JPS_Manager (/root/reference/faster/include/jps_manager.hpp:40-59, src/jps_manager.cpp): setNumCells / setFactorJPS /
 // setResolution / setInflationJPS / setZGroundAndZMax configure the map (:42-68), updateJPSMap(cloud, center) reads it (:129-139),
 // solveJPS3D(start, goal, &solved, i) searches it (:141-200).  JpsHip keeps those names and meanings over the C ABI's fh_map_*
-// (include/fasterhip.h).  The device searches one query per wavefront, so the call that pays is solveJPS3DBatch (Monte-Carlo goals,
+// (include/fasterhip.h) and searches as JPS_Manager does: jump point search in jps3d's own order (planner_ptr_->plan(start, goal, 1,
+// true), jps_manager.cpp:166; fh_map_set_search mode 1), so the vertex lists are the reference's; setJumpPointSearch(false) selects
+// the A* of mode 0 (another optimal path, no per-map jump tables).  The device searches one query per wavefront, so the call that pays is solveJPS3DBatch (Monte-Carlo goals,
 // many agents sharing a map); a single solveJPS3D is a batch of one (~0.5 ms on its one wavefront: the CPU search of
 // corridor_frontend.cpp takes ~0.1 ms and stays the better choice for one replan).  No CPU fallback: without a device every search
 // reports solved = false and lastError() says why.
@@ -26,6 +28,7 @@ public:
   void setResolution(double res) { res_ = res; }
   void setInflationJPS(double inflation_jps) { inflation_jps_ = inflation_jps; }
   void setZGroundAndZMax(double z_ground, double z_max) { z_ground_ = z_ground; z_max_ = z_max; }
+  bool setJumpPointSearch(bool on);  // default on: JPS_Manager plans with use_jps = true
 
   // MapUtil::readMap with cell size factor_jps * res (jps_manager.cpp:135-136); returns false on a device error
   bool updateJPSMap(const std::vector<fhfront::V3>& cloud, const fhfront::V3& center);
@@ -42,7 +45,7 @@ public:
 private:
   bool ensureMap();
   fh_map* map_ = nullptr;
-  bool create_failed_ = false;
+  bool create_failed_ = false, jump_point_search_ = true;
   int rc_ = FH_OK;
   std::string err_;
   int32_t cells_[3] = {200, 200, 20};

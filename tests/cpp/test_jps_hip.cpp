@@ -1,4 +1,4 @@
-// JpsHip (device) against fhfront::plan_path (host) through the JPS_Manager-shaped calls: a forest scene read from a file written by
+// JpsHip (device) against fhfront::plan_path_jps and, with setJumpPointSearch(false), fhfront::plan_path (host) through the JPS_Manager-shaped calls: a forest scene read from a file written by
 // the Python test.  usage: test_jps_hip scene.txt   -> prints JPS_OK <queries> <solved> on success
 #include <cstdio>
 #include <cstdlib>
@@ -26,22 +26,26 @@ int main(int argc, char** argv) {
   jps.setInflationJPS(infl);
   jps.setZGroundAndZMax(zg, zmax);
   if (!jps.updateJPSMap(cloud, fhfront::V3(center[0], center[1], center[2]))) { std::printf("updateJPSMap failed: %s\n", jps.lastError().c_str()); return 1; }
-  std::vector<char> solved;
-  const auto paths = jps.solveJPS3DBatch(starts, goals, &solved);
-
   fhfront::VoxelGrid base;
   base.build(cloud, cells[0], cells[1], cells[2], res, fhfront::V3(center[0], center[1], center[2]), zg, zmax, infl);
   int n_solved = 0;
-  for (int i = 0; i < n_q; i++) {
-    fhfront::VoxelGrid g = base;
-    std::vector<fhfront::V3> ref;
-    const bool ok = fhfront::plan_path(g, starts[i], goals[i], infl, ref);
-    if (ok != (bool)solved[i]) { std::printf("query %d: solved %d vs host %d\n", i, (int)solved[i], (int)ok); return 1; }
-    if (!ok) continue;
-    n_solved++;
-    if (ref.size() != paths[i].size()) { std::printf("query %d: %zu vertices vs host %zu\n", i, paths[i].size(), ref.size()); return 1; }
-    for (size_t k = 0; k < ref.size(); k++)
-      if (ref[k].x != paths[i][k].x || ref[k].y != paths[i][k].y || ref[k].z != paths[i][k].z) { std::printf("query %d vertex %zu differs\n", i, k); return 1; }
+  std::vector<char> solved;
+  std::vector<std::vector<fhfront::V3>> paths;
+  for (int mode = 1; mode >= 0; mode--) {  // 1: jump point search in jps3d's order (the default, as JPS_Manager), 0: the A* of mode 0
+    if (!jps.setJumpPointSearch(mode == 1)) { std::printf("setJumpPointSearch failed\n"); return 1; }
+    paths = jps.solveJPS3DBatch(starts, goals, &solved);
+    n_solved = 0;
+    for (int i = 0; i < n_q; i++) {
+      fhfront::VoxelGrid g = base;
+      std::vector<fhfront::V3> ref;
+      const bool ok = mode == 1 ? fhfront::plan_path_jps(g, starts[i], goals[i], infl, ref) : fhfront::plan_path(g, starts[i], goals[i], infl, ref);
+      if (ok != (bool)solved[i]) { std::printf("mode %d query %d: solved %d vs host %d\n", mode, i, (int)solved[i], (int)ok); return 1; }
+      if (!ok) continue;
+      n_solved++;
+      if (ref.size() != paths[i].size()) { std::printf("mode %d query %d: %zu vertices vs host %zu\n", mode, i, paths[i].size(), ref.size()); return 1; }
+      for (size_t k = 0; k < ref.size(); k++)
+        if (ref[k].x != paths[i][k].x || ref[k].y != paths[i][k].y || ref[k].z != paths[i][k].z) { std::printf("mode %d query %d vertex %zu differs\n", mode, i, k); return 1; }
+    }
   }
   // the single-query call of the reference
   bool one = false;

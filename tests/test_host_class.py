@@ -201,7 +201,8 @@ def test_jps_hip_mirrors_jps_manager_and_fails_loudly_without_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_jps_hip_equals_host_search(tmp_path):
-    """The JPS_Manager-shaped C++ class over fh_map_*: every path vertex for vertex as fhfront::plan_path (tests/cpp/test_jps_hip.cpp)."""
+    """The JPS_Manager-shaped C++ class over fh_map_*: every path vertex for vertex as fhfront::plan_path_jps (its default: jump point
+    search in jps3d's order, as JPS_Manager) and, switched to the A* of mode 0, as fhfront::plan_path (tests/cpp/test_jps_hip.cpp)."""
     exe = _build_jps_test()
     sc = tmp_path / "scene.txt"
     _jps_scene(sc, n_q=256)
