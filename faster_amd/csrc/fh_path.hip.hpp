@@ -696,16 +696,23 @@ struct Planner {
     else { k = ez * az; off = abs(ex) + abs(ey); }
     return (off == 0 && k >= 1) ? k : BIGK;
   }
-  // does a box of changed cells meet the cone of a diagonal jump from (x, y, z)
-  __device__ __forceinline__ bool cone_dirty(int x, int y, int z, int ax, int ay, int az) const {
+  // can a box of changed cells matter to the diagonal jump from (x, y, z) whose entry is J: the box must meet the cone the jump opens
+  // (one cell of margin), AND come within reach — every cell the jump examines sits on a ray or a plane sweep that leaves one of
+  // the first |J| diagonal cells, so along at least one axis of the jump it is at most |J| + 1 cells away.
+  __device__ __forceinline__ bool cone_dirty(int x, int y, int z, int ax, int ay, int az, int J) const {
     bool dirty = false;
-    if (boxes_matter)
+    if (boxes_matter) {
+      const int reach = abs(J) + 1;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const bool mx = ax > 0 ? dhi[q][0] >= x : (ax < 0 ? dlo[q][0] <= x : (dlo[q][0] - 1 <= x && x <= dhi[q][0] + 1));
-      const bool my = ay > 0 ? dhi[q][1] >= y : (ay < 0 ? dlo[q][1] <= y : (dlo[q][1] - 1 <= y && y <= dhi[q][1] + 1));
-      const bool mz = az > 0 ? dhi[q][2] >= z : (az < 0 ? dlo[q][2] <= z : (dlo[q][2] - 1 <= z && z <= dhi[q][2] + 1));
-      dirty = dirty || (mx && my && mz);
+      for (int q = 0; q < 2; q++) {
+        const bool mx = ax > 0 ? dhi[q][0] >= x : (ax < 0 ? dlo[q][0] <= x : (dlo[q][0] - 1 <= x && x <= dhi[q][0] + 1));
+        const bool my = ay > 0 ? dhi[q][1] >= y : (ay < 0 ? dlo[q][1] <= y : (dlo[q][1] - 1 <= y && y <= dhi[q][1] + 1));
+        const bool mz = az > 0 ? dhi[q][2] >= z : (az < 0 ? dlo[q][2] <= z : (dlo[q][2] - 1 <= z && z <= dhi[q][2] + 1));
+        const int ox = ax > 0 ? dlo[q][0] - x : (ax < 0 ? x - dhi[q][0] : BIGK);
+        const int oy = ay > 0 ? dlo[q][1] - y : (ay < 0 ? y - dhi[q][1] : BIGK);
+        const int oz = az > 0 ? dlo[q][2] - z : (az < 0 ? z - dhi[q][2] : BIGK);
+        dirty = dirty || (mx && my && mz && min(ox, min(oy, oz)) <= reach);
+      }
     }
     return dirty;
   }
@@ -716,7 +723,9 @@ struct Planner {
   // (before that a ray would need a diagonal move, after that it would have to go back): there it is the cell itself, or sits on a
   // straight ray that leaves the cell, or (space diagonal) in reach of the plane-diagonal jump that leaves it.
   __device__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k) const {
-    const int J = entry((ax + 1) + 3 * (ay + 1) + 9 * (az + 1), x, y, z);
+    return diag_jump(x, y, z, ax, ay, az, k, entry((ax + 1) + 3 * (ay + 1) + 9 * (az + 1), x, y, z));
+  }
+  __device__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k, int J) const {  // J: the entry of the jump itself
     if (J == 0) return 2;
     k = J;
     const int plain = J > 0 ? 1 : 0;
@@ -773,7 +782,8 @@ struct Planner {
         int J = 0;
         if (phase == 0) {
           int kk;
-          const int st = cone_dirty(bx, by, bz, ax, ay, az) ? 2 : diag_jump(bx, by, bz, ax, ay, az, kk);
+          const int Jd = entry(dcode, bx, by, bz);
+          const int st = cone_dirty(bx, by, bz, ax, ay, az, Jd) ? 2 : diag_jump(bx, by, bz, ax, ay, az, kk, Jd);
           outcome = st == 2 ? 3 : (st == 1 ? 1 : 2);
         } else J = entry(dcode, bx, by, bz);
         if (phase == 0) {}
@@ -863,9 +873,10 @@ struct Planner {
       b = nat(c2, 1);
     } else takes = false;
     for (;;) {
-      if (!cone_dirty(bx, by, bz, dx, dy, dz)) {
+      const int Jd = rfl(entry(code, bx, by, bz));
+      if (!cone_dirty(bx, by, bz, dx, dy, dz, Jd)) {
         int kk = 0;
-        const int st = rfl(diag_jump(bx, by, bz, dx, dy, dz, kk));
+        const int st = rfl(diag_jump(bx, by, bz, dx, dy, dz, kk, Jd));
         kk = rfl(kk);
         if (st == 0) return false;
         if (st == 1) { ox = bx + kk * dx; oy = by + kk * dy; oz = bz + kk * dz; return true; }
@@ -938,32 +949,37 @@ struct Planner {
       expansions++;
       if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
       const HE top = hget(0);
-      n--;
-      if (n > 0) {
-        const HE last = hget(n);
-        sift_down(0, last, n);
-      }
       const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
       if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
-
-      if (cur == tid) break;
       const int cz = cur / nxy, rem = cur - cz * nxy, cy = rem / mv.nx, cx = rem - cy * mv.nx;
       const int n1 = abs(code % 3 - 1) + abs((code / 3) % 3 - 1) + abs(code / 9 - 1);
       const int num_neib = n1 == 0 ? 26 : (n1 == 1 ? 1 : (n1 == 2 ? 3 : 7)), num_fneib = n1 == 0 ? 0 : (n1 == 1 ? 8 : 12);
       // ---- the successors (getJpsSucc, :318-368), one candidate per lane in jps3d's order: lanes < num_neib the natural neighbours,
       // then the forced-neighbour entries.  A lane settles its jump from the jump tables when it can; the others are evaluated one
-      // after the other by the whole wavefront.
+      // after the other by the whole wavefront.  The loads a candidate needs (its forced-neighbour cell, its table entry) depend on
+      // the popped node only: they are issued before the heap is put in order again and arrive while it is.
       const bool cand = lane < num_neib + num_fneib;
       const int fk = (cand && lane >= num_neib) ? lane - num_neib : 0;
       const unsigned fpk = byte_of(jf1 + code * 3, fk);
       const unsigned pk = !cand ? 0x15u : (lane < num_neib ? nat(code, lane) : byte_of(jf2 + code * 3, fk));
-      const bool applies = occ_any(cx + ux(fpk), cy + uy(fpk), cz + uz(fpk)) || lane < num_neib;
       const int ax = ux(pk), ay = uy(pk), az = uz(pk), pcode = code_of(pk);
       const bool straight = abs(ax) + abs(ay) + abs(az) == 1;
-      const int J = (cand && straight) ? entry(pcode, cx, cy, cz) : 0;
+      const int fx = cx + ux(fpk), fy = cy + uy(fpk), fz = cz + uz(fpk);
+      const bool fin = !outside(fx, fy, fz);
+      const int fid = fin ? index(fx, fy, fz) : 0;
+      const unsigned fword = mv.bits[fid >> 5];
+      const int J = jt[(size_t)cur * 32 + pcode];
+      n--;
+      if (n > 0) {
+        const HE last = hget(n);
+        sift_down(0, last, n);
+      }
+      if (cur == tid) break;
+      const bool applies = lane < num_neib || (fin && !freed(fx, fy, fz) && ((fword >> (fid & 31)) & 1u));
       int status = 2, jk = 0;  // 0 no successor, 1 a successor jk cells away, 2 not settled
-      if (cand && !straight) {
-        if (!cone_dirty(cx, cy, cz, ax, ay, az)) status = diag_jump(cx, cy, cz, ax, ay, az, jk);
+      if (!cand) {}
+      else if (!straight) {
+        if (!cone_dirty(cx, cy, cz, ax, ay, az, J)) status = diag_jump(cx, cy, cz, ax, ay, az, jk, J);
       } else if (J != 0) {
         {
           const int kend = abs(J);
