@@ -1,6 +1,7 @@
 """Randomized parity sweep of the device front-end (fh_map_* + fh_corridor_batch_device) against the CPU front-end: maps of different
 size, resolution, inflation and tree density; per configuration the occupancy grid, every path vertex, every expansion count and every
-polytope row are compared bit for bit.  usage (GPU box, PYTHONPATH = repo root): path_sweep.py [queries_per_config] [configs]"""
+polytope row are compared bit for bit.  usage (GPU box, PYTHONPATH = repo root): path_sweep.py [queries_per_config] [configs] [astar|jps]
+(jps: jump point search in jps3d's own order on both sides — plan_path_jps vs fh_map_set_search(1); maps as high as wide included)."""
 import sys
 import time
 
@@ -11,13 +12,16 @@ from faster_amd import abi, capi, frontend
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ncfg = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+search = sys.argv[3] if len(sys.argv) > 3 else "astar"
 rng = np.random.default_rng(2024)
 ctx, vmap = capi.Context(0), capi.Map(0)
+frontend.set_search(search)
+vmap.set_search(search)
 tot_q = tot_exp = bad = 0
 t0 = time.time()
 for c in range(ncfg):
     side = float(rng.choice([8.0, 12.0, 20.0]))
-    height = float(rng.choice([2.0, 3.0]))
+    height = float(rng.choice([2.0, 3.0])) if (search == "astar" or c % 4) else side   # (jps: every fourth map is a cube)
     res = float(rng.choice([0.15, 0.2, 0.25, 0.3]))
     infl = float(rng.choice([0.0, 0.2, 0.3, 0.45]))
     dens = float(rng.choice([0.05, 0.1, 0.2, 0.3]))
@@ -46,7 +50,8 @@ for c in range(ncfg):
     frontend.lib().ff_corridor_batch(abi.ptr(frontend._c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(frontend._c(center)), 0.0, height,
                                      infl, 0.05, abi.ptr(frontend._c(starts)), abi.ptr(frontend._c(goals)), nq, max_poly, mvd, fpp, abi.ptr(hf),
                                      abi.ptr(hoff), abi.ptr(hnp), abi.ptr(hgoal))
-    df, doff, dnp, dgoal, _ = frontend.corridor_batch_device(ctx, vmap, cloud, cells, res, center, height, infl, starts, goals, max_poly, mvd, fpp, 0.05)
+    df, doff, dnp, dgoal, _ = frontend.corridor_batch_device(ctx, vmap, cloud, cells, res, center, height, infl, starts, goals, max_poly, mvd, fpp, 0.05,
+                                                             search=search)
     same_np = np.array_equal(hnp, dnp)
     rows_ok = same_np
     if same_np:
@@ -64,4 +69,4 @@ for c in range(ncfg):
     print("cfg %2d side %4.0f res %.2f infl %.2f dens %.2f mvd %.1f P<=%d | grid %s paths %.2f | search %s corridors %s | %ds" % (
         c, side, res, infl, dens, mvd, max_poly, tuple(int(v) for v in hdims), (hn > 0).mean(), "OK" if ok else "MISMATCH",
         "OK" if rows_ok else "MISMATCH", time.time() - t0), flush=True)
-print("PATH SWEEP DONE: %d configurations, %d queries, %d expanded cells, %d configurations with a mismatch" % (ncfg, tot_q, tot_exp, bad))
+print("PATH SWEEP DONE (%s): %d configurations, %d queries, %d expanded cells, %d configurations with a mismatch" % (search, ncfg, tot_q, tot_exp, bad))
