@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=8,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     ap.add_argument("--no-share", action="store_true", help="one wavefront per problem (fh_params.share = 0)")
+    ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
     args = ap.parse_args()
 
     # more hardware queues than the HIP default (4) so that the in-flight pipelines really run concurrently
@@ -189,6 +190,8 @@ def main():
         pp.ctx.set_stream(pp.stream.cuda_stream)
         pp.ctx.set_params(par)
         pp.ctx.set_pair_margin(r_margin)
+        if args.wg_per_cu:
+            pp.ctx.set_sched(workgroups_per_cu=args.wg_per_cu)
         pp.d_safe = to_dev(safe_t)
         pp.d_sfaces = torch.zeros_like(d_faces)
         pp.d_wres = torch.zeros(per_rank * RES, dtype=torch.uint8, device=dev)  # (strong: padded to the largest shard)

@@ -70,7 +70,7 @@ assert params_dtype.itemsize == 48
 
 
 sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("backlog", "<i4"), ("waiting_workgroups", "<i4"),
-                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("reserved", "<i4", (2,))])
+                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("reserved", "<i4")])
 assert sched_dtype.itemsize == 32
 
 

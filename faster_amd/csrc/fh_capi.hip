@@ -108,6 +108,13 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   const size_t lds_alloc = (lds + 1279) / 1280 * 1280;
   int per_cu = (int)std::min<size_t>(FH_WAVES_PER_SIMD * 4, (160 * 1024) / lds_alloc);
   if (per_cu < 1) per_cu = 1;
+  // fh_sched.workgroups_per_cu: fewer resident solves per CU than would fit.  The launch then asks for so much LDS that the hardware
+  // cannot place more either, whatever else is in flight.
+  size_t lds_launch = lds;
+  if (ctx->sched.workgroups_per_cu > 0 && ctx->sched.workgroups_per_cu < per_cu) {
+    per_cu = ctx->sched.workgroups_per_cu;
+    lds_launch = std::max(lds, (size_t)(160 * 1024) / (size_t)per_cu / 1280 * 1280 - 16);
+  }
   const int resident = ctx->n_cu * per_cu;
   const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;
   // small batches get helper workgroups (one per CU) that take over subtrees of hard problems
@@ -148,9 +155,9 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   ka.basis = (const double*)ctx->d_buf[15];
   {  // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it
     size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : (NSEG <= 15 ? 2 : 3))) + (PAIRS ? 4 : 0)];
-    if (lds > have) {
-      FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      have = lds;
+    if (lds_launch > have) {
+      FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
+      have = lds_launch;
     }
   }
   if (ctx->ev_used + 2 > ctx->ev.size()) {
@@ -184,7 +191,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   }
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_problems, d_faces, d_results, ka);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_launch, ctx->stream, d_problems, d_faces, d_results, ka);
   FH_HIP(hipGetLastError());
   FH_HIP(hipEventRecord(e1, ctx->stream));
   ctx->ev_used += 2;

@@ -169,7 +169,8 @@ typedef struct fh_sched {
   int32_t min_nodes;          /* a tree gives work away only after this many nodes, unless somebody is idle (default 16)        */
   int32_t cloud_blocks;       /* 1 (default): the decomposition skips blocks of 64 cloud points whose bounding box misses the
                                  local box of a segment                                                                         */
-  int32_t reserved[2];
+  int32_t workgroups_per_cu;  /* resident solves per CU (0 = default: as many as LDS and registers admit, 11 for the C4 kernel)    */
+  int32_t reserved;
 } fh_sched;
 void fh_default_sched(fh_sched* s);
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s);

@@ -454,7 +454,7 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
 
     ref = run(ctx)
     assert (ref[1]["solved"] == 1).mean() > 0.7
-    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0}   # (fh_set_sched: explicit scheduling fields, no environment)
+    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0, "workgroups_per_cu": 5}   # (fh_set_sched: explicit fields, no environment)
     for k, v in variants.items():
         ctx.set_sched(**{k: v})
         try:
