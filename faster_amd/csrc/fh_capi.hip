@@ -711,6 +711,21 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
   return FH_OK;
 }
 
+int fh_append_plans_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const fh_problem* d_safe,
+                           const fh_result* d_safe_results, int n, double r_frac, int max_states, fh_state* d_plans, int32_t* d_counts,
+                           int32_t* d_k_safe) {
+  if (!ctx || n < 0 || max_states < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_whole || !d_whole_results || !d_safe || !d_safe_results || !d_counts || (max_states > 0 && !d_plans)) return FH_ERR_ARG;
+  if (!(r_frac >= 0) || !(r_frac <= 1)) return FH_ERR_ARG;
+  hipLaunchKernelGGL(fh::plan_append_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole, d_whole_results, d_safe, d_safe_results, n,
+                     r_frac, ctx->pair_rule, max_states, d_plans, d_counts, d_k_safe);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
 int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face* d_faces, int n, int max_seg, int max_faces,
                           double r_frac, double shrink, int max_safe_poly, fh_result* d_whole_results, fh_problem* d_safe,
                           fh_face* d_safe_faces, fh_result* d_safe_results) {

@@ -34,28 +34,14 @@ __device__ __forceinline__ void eval_state(const double* c, double tau, bool las
   }
 }
 
-__global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict__ problems, const fh_result* __restrict__ results,
-                                                    int n, int max_samples, fh_state* __restrict__ states,
-                                                    int32_t* __restrict__ counts) {
-  __shared__ __attribute__((aligned(16))) double tile[64 * 12];
-  __shared__ double coef[FH_MAX_SEG * 12];
-  const int b = blockIdx.x;
-  if (b >= n) return;
-  const int lane = threadIdx.x;
-  const fh_problem& pr = problems[b];
-  const fh_result& rs = results[b];
-  if (!rs.solved || pr.n_seg < 1 || pr.n_seg > FH_MAX_SEG) {
-    if (lane == 0) counts[b] = 0;
-    return;
-  }
+// The first `nwrite` samples of one trajectory (of `size`) to out[0 .. nwrite): the body of sample_kernel.  tile: [64 * 12], coef: [FH_MAX_SEG * 12] (LDS).
+__device__ inline void sample_into(const fh_problem& pr, const fh_result& rs, int size, int nwrite, fh_state* __restrict__ out, double* tile,
+                                   double* coef, int lane) {
   const int N = __builtin_amdgcn_readfirstlane(pr.n_seg);
   const double dt = rs.dt, DC = pr.dc;
-  const int size = __builtin_amdgcn_readfirstlane(sample_count(pr, rs));  // wave-uniform: scalar loop counters below
-  if (lane == 0) counts[b] = size;
+  __syncthreads();
   for (int i = lane; i < N * 12; i += 64) coef[i] = rs.coeff[i / 12][i % 12];
   __syncthreads();
-  const int nwrite = size < max_samples ? size : max_samples;
-  fh_state* out = states + (size_t)b * (size_t)max_samples;
   double t = 0;
   int interval = 0;
   double knot = dt * (double)(interval + 1);  // dt_ * (interval + 1) of :133, recomputed only when the interval changes
@@ -89,6 +75,25 @@ __global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict
     for (int i = lane; i < lim * 6; i += 64) __builtin_nontemporal_store(src[i], &dst[i]);  // streamed once, never re-read here
     __syncthreads();
   }
+}
+
+__global__ void __launch_bounds__(64) sample_kernel(const fh_problem* __restrict__ problems, const fh_result* __restrict__ results,
+                                                    int n, int max_samples, fh_state* __restrict__ states,
+                                                    int32_t* __restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) double tile[64 * 12];
+  __shared__ double coef[FH_MAX_SEG * 12];
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const int lane = threadIdx.x;
+  const fh_problem& pr = problems[b];
+  const fh_result& rs = results[b];
+  if (!rs.solved || pr.n_seg < 1 || pr.n_seg > FH_MAX_SEG) {
+    if (lane == 0) counts[b] = 0;
+    return;
+  }
+  const int size = __builtin_amdgcn_readfirstlane(sample_count(pr, rs));  // wave-uniform: scalar loop counters below
+  if (lane == 0) counts[b] = size;
+  sample_into(pr, rs, size, size < max_samples ? size : max_samples, states + (size_t)b * (size_t)max_samples, tile, coef, lane);
 }
 
 // One wavefront per pair: the scalar sample clock runs once (wave-uniform), the polytope tests and the face copy are
@@ -126,17 +131,14 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return v;
 }
 
-template <bool WT = false>
-__device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, const fh_face* wfaces, double r_frac, double shrink,
-                                     int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane) {
-  if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
-    if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
-    return;
-  }
+// Which sample of the whole trajectory is R (k_safe of Faster::replan): mode 0 sample (int)(r_frac * size); mode 1 FASTER's own rule —
+// findIndexH (faster.cpp:218-251) against the modelled unknown space, then findIndexR (:173-216).  Returns false when no safe
+// trajectory is needed (needToComputeSafePath == false, :462-466): k is then indexH = the last sample (:231).
+__device__ inline bool choose_r_index(const fh_problem& pw, const fh_result& rw, double r_frac, const fh_pair_rule& rule, int lane, int& k) {
   const int N = pw.n_seg;
-  const double dt = rw.dt, DC = pw.dc;
+  const double DC = pw.dc;
   const int size = sample_count(pw, rw);
-  int k = (int)(r_frac * (double)size);
+  k = (int)(r_frac * (double)size);
   if (rule.mode == 1) {
     // findIndexH (faster.cpp:218-251): samples 0, 10, 20, ... against unknown space (modelled: farther than r_known from x0)
     const double lim = rule.r_known - rule.drone_radius;
@@ -153,8 +155,8 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
       iH = wave_min_i32(mine);
     }
     if (iH == 0x7fffffff) {  // needToComputeSafePath == false (:462-466): the pair ends with its whole trajectory
-      if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
-      return;
+      k = size - 1;
+      return false;
     }
     int indexH = (int)(rule.delta_h * (double)iH);
     indexH = indexH > size - 1 ? size - 1 : (indexH < 0 ? 0 : indexH);
@@ -184,6 +186,24 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
   }
   if (k > size - 1) k = size - 1;
   if (k < 0) k = 0;
+  return true;
+}
+
+template <bool WT = false>
+__device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, const fh_face* wfaces, double r_frac, double shrink,
+                                     int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane) {
+  if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
+    if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
+    return;
+  }
+  const int N = pw.n_seg;
+  const double dt = rw.dt, DC = pw.dc;
+  const int size = sample_count(pw, rw);
+  int k;
+  if (!choose_r_index(pw, rw, r_frac, rule, lane, k)) {  // the pair ends with its whole trajectory
+    if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
+    return;
+  }
   double t = 0;
   int interval = 0;
   for (int i = 0; i <= k; i++) {  // the reference's clock (solverGurobi.cpp:131-135), wave-uniform
@@ -269,6 +289,48 @@ __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restr
   const int b = blockIdx.x;
   if (b >= n) return;
   pair_glue_one<false>(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, r_margin, rule, safe[b], sfaces, threadIdx.x);
+}
+
+// Faster::appendToPlan (faster/src/faster.cpp:606-648) for a batch of independent pairs whose plan holds only the start A
+// (k_end_whole = 0): plan = the samples 0 .. k_safe of the whole trajectory, then every sample of the safe trajectory (:627-640).
+// k_safe is the index the hand-off chose (choose_r_index, the same function).  A pair commits nothing (count 0) when the whole solve
+// failed (:427-431) or a safe trajectory was needed and not found (:529-533); a pair that needs no safe trajectory commits its whole
+// trajectory (k_safe = indexH = last sample, safe part empty, :462-466).  One wavefront per pair.
+__global__ void __launch_bounds__(64) plan_append_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
+                                                         const fh_problem* __restrict__ safe, const fh_result* __restrict__ sres, int n,
+                                                         double r_frac, fh_pair_rule rule, int max_states, fh_state* __restrict__ plans,
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ k_safe_out) {
+  __shared__ __attribute__((aligned(16))) double tile[64 * 12];
+  __shared__ double coef[FH_MAX_SEG * 12];
+  const int b = blockIdx.x;
+  if (b >= n) return;
+  const int lane = threadIdx.x;
+  const fh_problem& pw = whole[b];
+  const fh_result& rw = wres[b];
+  int count = 0, k = -1;
+  if (rw.solved && pw.n_seg >= 1 && pw.n_seg <= FH_MAX_SEG) {
+    const int size_w = __builtin_amdgcn_readfirstlane(sample_count(pw, rw));
+    const bool need_safe = choose_r_index(pw, rw, r_frac, rule, lane, k);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const fh_problem& ps = safe[b];
+    const fh_result& rs = sres[b];
+    const bool have_safe = need_safe && rs.solved && ps.n_seg >= 1 && ps.n_seg <= FH_MAX_SEG;
+    if (!need_safe || have_safe) {
+      const int size_s = have_safe ? __builtin_amdgcn_readfirstlane(sample_count(ps, rs)) : 0;
+      count = k + 1 + size_s;
+      fh_state* out = plans + (size_t)b * (size_t)max_states;
+      const int nw = (k + 1) < max_states ? (k + 1) : max_states;
+      sample_into(pw, rw, size_w, nw, out, tile, coef, lane);
+      if (have_safe && k + 1 < max_states) {
+        const int ns = (max_states - (k + 1)) < size_s ? (max_states - (k + 1)) : size_s;
+        sample_into(ps, rs, size_s, ns, out + (k + 1), tile, coef, lane);
+      }
+    }
+  }
+  if (lane == 0) {
+    counts[b] = count;
+    if (k_safe_out) k_safe_out[b] = count ? k : -1;
+  }
 }
 
 }  // namespace fh

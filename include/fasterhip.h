@@ -272,6 +272,16 @@ int fh_set_pair_rule(fh_ctx* ctx, const fh_pair_rule* rule);
 int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results,
                         const fh_face* d_faces, int n, double r_frac, double shrink, int max_safe_poly,
                         fh_problem* d_safe, fh_face* d_safe_faces);
+/* Faster::appendToPlan (faster/src/faster.cpp:606-648) for a batch of independent pairs whose plan holds only the start A
+ * (k_end_whole = 0): plan i = the samples 0 .. k_safe of the whole trajectory (fillX semantics), then every sample of the safe
+ * trajectory (:627-640).  k_safe is recomputed by the rule of the hand-off (r_frac, fh_set_pair_rule): the same sample that became x0
+ * of the safe problem.  counts[i] = k_safe + 1 + samples of the safe trajectory; 0 when the pair commits nothing — the whole solve
+ * failed (:427-431), or a safe trajectory was needed and not found (:529-533).  A pair that needs no safe trajectory (rule mode 1,
+ * :462-466) commits its whole trajectory: k_safe = its last sample.  At most max_states states are written per pair (counts still
+ * reports the full length); d_k_safe may be NULL.  Device pointers, asynchronous on the context stream. */
+int fh_append_plans_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const fh_problem* d_safe,
+                           const fh_result* d_safe_results, int n, double r_frac, int max_states, fh_state* d_plans, int32_t* d_counts,
+                           int32_t* d_k_safe);
 
 /* ---- next row N1 on the device: convex decomposition around path segments ------------------------------ */
 /* JPS_Manager::cvxEllipsoidDecomp (faster/src/jps_manager.cpp:80-127) for a batch of path segments that share one obstacle

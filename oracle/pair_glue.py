@@ -82,3 +82,31 @@ def glue(whole, wres, faces, safe_templates, r_frac=0.5, shrink=0.2, max_safe_po
         off += [o] * (abi.FH_MAX_POLY + 1 - len(off))
         safe["face_off"][i] = off
     return safe, sfaces
+
+
+def append_plans(whole, wres, safe, sres, r_frac=0.5, rule=None):
+    """Faster::appendToPlan (faster/src/faster.cpp:606-648) for independent pairs whose plan holds only the start (k_end_whole = 0):
+    plan = X_whole[0 .. k_safe] followed by X_safe (:627-640); nothing is committed when the whole solve failed (:427-431) or a safe
+    trajectory was needed and not found (:529-533); without unknown space on the way (:462-466) the plan is the whole trajectory.
+    -> (list of state arrays (empty: nothing committed), k_safe per pair (-1: nothing committed))"""
+    plans, ks = [], []
+    for i in range(len(whole)):
+        pw, rw = whole[i], wres[i]
+        if not rw["solved"]:
+            plans.append(None); ks.append(-1)
+            continue
+        X = oracle.sample(pw, rw)
+        size = X.shape[0]
+        k, needed = min(max(int(r_frac * size), 0), size - 1), True
+        if rule is not None:
+            index_h, needed = find_index_h(X, pw["x0"][:3], rule["r_known"], rule["drone_radius"], rule.get("delta_h", 1.0))
+            k = find_index_r(X, min(index_h, size - 1), rule.get("delta_a", 0.5), float(pw["a_max"])) if needed else size - 1
+        if needed and not (sres[i]["solved"] and safe[i]["n_seg"] >= 1):
+            plans.append(None); ks.append(-1)
+            continue
+        parts = [X[:k + 1]]
+        if needed:
+            parts.append(oracle.sample(safe[i], sres[i]))
+        plans.append(np.concatenate(parts))
+        ks.append(k)
+    return plans, np.array(ks, dtype=np.int32)

@@ -495,3 +495,65 @@ def test_device_jump_point_search_where_the_freed_cubes_and_3d_jumps_matter(host
         m.close()
     assert (host[1] > 0).mean() > 0.8
     _plans_equal(host, dev, kind)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_plans_appended_on_the_device(ctx, oracle, mode):
+    """fh_append_plans_device = Faster::appendToPlan (faster.cpp:606-648) for a batch of pairs: the committed plan is the whole
+    trajectory's samples 0 .. k_safe followed by the safe trajectory's samples — against the numpy restatement on the ORACLE's
+    samples (oracle/pair_glue.py append_plans): same pairs commit, same k_safe, same lengths, states equal to 1e-9; and bit for bit
+    against the device's own fillX (fh_sample_batch_device) spliced on the host.  mode 1: FASTER's rule for R (pairs whose whole
+    trajectory stays in known space commit the whole trajectory)."""
+    import torch
+
+    from oracle import pair_glue
+
+    B, n_seg = 512, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=910 + mode, n_seg=n_seg, p_choices=(2, 3, 4, 5))
+    tmpl = corridor.safe_templates(whole)
+    goal_dist = np.linalg.norm(whole["xf"][:, :3] - whole["x0"][:, :3], axis=1)
+    rule = dict(r_known=float(np.median(goal_dist)) + 0.3, drone_radius=0.3, delta_h=1.0, delta_a=0.5)   # half of the goals in known space
+    ctx.set_pair_rule(mode=mode, **rule)
+    try:
+        wres, sres, safe, sfaces = fused_pairs(ctx, whole, faces, tmpl, n_seg, 0.05)
+        d_w, d_wr, d_s, d_sr = _dev(whole), _dev(wres), _dev(safe), _dev(sres)
+        max_states = 1024
+        d_plans = torch.zeros(B * max_states * abi.state_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+        d_counts = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+        d_k = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+        ctx.append_plans_device(d_w.data_ptr(), d_wr.data_ptr(), d_s.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states, d_plans.data_ptr(),
+                                d_counts.data_ptr(), d_k.data_ptr())
+        # the device's own samples of both trajectories
+        d_xw = torch.zeros_like(d_plans); d_cw = torch.zeros_like(d_counts)
+        d_xs = torch.zeros_like(d_plans); d_cs = torch.zeros_like(d_counts)
+        ctx.sample_batch_device(d_w.data_ptr(), d_wr.data_ptr(), B, max_states, d_xw.data_ptr(), d_cw.data_ptr())
+        ctx.sample_batch_device(d_s.data_ptr(), d_sr.data_ptr(), B, max_states, d_xs.data_ptr(), d_cs.data_ptr())
+        ctx.sync()
+    finally:
+        ctx.set_pair_rule(mode=0)
+    plans = d_plans.cpu().numpy().view(abi.state_dtype).reshape(B, max_states)
+    counts, ks = d_counts.cpu().numpy(), d_k.cpu().numpy()
+    xw = d_xw.cpu().numpy().view(abi.state_dtype).reshape(B, max_states)
+    xs = d_xs.cpu().numpy().view(abi.state_dtype).reshape(B, max_states)
+    cw, cs = d_cw.cpu().numpy(), d_cs.cpu().numpy()
+    ref_plans, ref_k = pair_glue.append_plans(whole, wres, safe, sres, 0.5, rule if mode == 1 else None)
+    assert np.array_equal(ks, ref_k)
+    committed = 0
+    for i in range(B):
+        if ref_plans[i] is None:
+            assert counts[i] == 0, i
+            continue
+        committed += 1
+        assert counts[i] == len(ref_plans[i]) <= max_states, (i, counts[i], len(ref_plans[i]))
+        got = plans[i, :counts[i]]
+        for f in ("pos", "vel", "accel", "jerk"):
+            np.testing.assert_allclose(got[f], ref_plans[i][f], rtol=0, atol=1e-9)
+        k = ks[i]
+        n_safe = counts[i] - (k + 1)
+        assert n_safe == (cs[i] if safe["n_seg"][i] > 0 else 0)
+        assert got[:k + 1].tobytes() == xw[i, :k + 1].tobytes() and got[k + 1:].tobytes() == xs[i, :n_safe].tobytes()
+        assert k <= cw[i] - 1
+    assert committed > 0.4 * B
+    if mode == 1:
+        whole_only = (safe["n_seg"] == 0) & (wres["solved"] == 1)
+        assert whole_only.any() and np.array_equal(counts[whole_only], cw[whole_only])   # no unknown space on the way: the whole trajectory
