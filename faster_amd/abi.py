@@ -74,6 +74,10 @@ sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("ba
 assert sched_dtype.itemsize == 32
 
 
+voxel_grid_dtype = np.dtype([("origin", "<f8", (3,)), ("res", "<f8"), ("dims", "<i4", (3,)), ("reserved", "<i4")])
+assert voxel_grid_dtype.itemsize == 48
+
+
 pair_rule_dtype = np.dtype([("mode", "<i4"), ("reserved", "<i4"), ("r_known", "<f8"), ("drone_radius", "<f8"), ("delta_h", "<f8"),
                             ("delta_a", "<f8")])
 assert pair_rule_dtype.itemsize == 40

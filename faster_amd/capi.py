@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
     "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule",
-    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_solve_pairs_device",
+    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
@@ -119,6 +119,8 @@ def lib():
         L.fh_sample_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp]
         L.fh_pair_glue_device.restype = i32
         L.fh_pair_glue_device.argtypes = [vp, vp, vp, vp, i32, f64, f64, i32, vp, vp]
+        L.fh_safe_corridor_batch_device.restype = i32
+        L.fh_safe_corridor_batch_device.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, f64, i32, vp, f64, f64, i32, i32, vp, vp, vp, vp]
         L.fh_append_plans_device.restype = i32
         L.fh_append_plans_device.argtypes = [vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp]
         L.fh_solve_pairs_device.restype = i32
@@ -485,6 +487,18 @@ class Context:
                            d_safe_faces, d_safe_results):
         self._check(lib().fh_solve_pairs_device(self._h, d_whole, d_faces, n, max_seg, max_faces, r_frac, shrink, max_safe_poly,
                                                 d_whole_results, d_safe, d_safe_faces, d_safe_results), "fh_solve_pairs_device")
+
+    def safe_corridor_batch_device(self, d_whole, d_whole_results, d_paths, d_n_points, max_points, d_goals, d_cloud, n_cloud, grid_origin, grid_res,
+                                   grid_dims, n, r_frac, max_poly_safe, local_bbox, drone_radius, z_ground, faces_per_problem, n_seg_safe, d_safe,
+                                   d_safe_faces, d_safe_paths=None, d_safe_n_points=None):
+        """fh_safe_corridor_batch_device: the safe corridor of Faster::replan decomposed around R (unknown space modelled)."""
+        g = np.zeros((), dtype=abi.voxel_grid_dtype)
+        g["origin"], g["res"], g["dims"] = grid_origin, grid_res, grid_dims
+        g = np.ascontiguousarray(g).reshape(1)
+        bb = np.ascontiguousarray(local_bbox, dtype=np.float64)
+        self._check(lib().fh_safe_corridor_batch_device(self._h, d_whole, d_whole_results, d_paths, d_n_points, max_points, d_goals, d_cloud, n_cloud,
+                                                        abi.ptr(g), n, r_frac, max_poly_safe, abi.ptr(bb), drone_radius, z_ground, faces_per_problem,
+                                                        n_seg_safe, d_safe, d_safe_faces, d_safe_paths, d_safe_n_points), "fh_safe_corridor_batch_device")
 
     def append_plans_device(self, d_whole, d_whole_results, d_safe, d_safe_results, n, r_frac, max_states, d_plans, d_counts, d_k_safe=None):
         """fh_append_plans_device: Faster::appendToPlan for a batch of pairs (whole samples 0..k_safe, then the safe samples)."""

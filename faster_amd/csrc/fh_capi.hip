@@ -18,6 +18,7 @@
 #include "fh_sample.hip.hpp"
 #include "fh_solve.hip.hpp"
 #include "fh_decomp.hip.hpp"
+#include "fh_safe.hip.hpp"  // (after fh_solve: it switches FP contraction off for what follows, like fh_decomp)
 
 struct fh_ctx {
   int device = 0;
@@ -34,8 +35,9 @@ struct fh_ctx {
   // 10: corridor segments, 11: per-segment polytope rows, 12: per-segment row counts (fh_corridor_batch_device)
   // 13: launch order of a batch (order_kernel), 14: bounding boxes of the cloud's blocks (decomposition)
   // 15: reduced-space basis tables (fh_basis.hip.hpp), uploaded once by fh_create
-  void* d_buf[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_cap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  void* d_buf[20] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, nullptr};
+  size_t d_cap[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
   size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
@@ -354,7 +356,7 @@ void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   if (ctx->device >= 0) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 16; i++)
+    for (int i = 0; i < 20; i++)
       if (ctx->d_buf[i]) (void)hipFree(ctx->d_buf[i]);
     if (ctx->h_abort) (void)hipHostFree(ctx->h_abort);
     if (ctx->h_report) (void)hipHostFree(ctx->h_report);
@@ -770,9 +772,24 @@ int fh_timing_read(fh_ctx* ctx, double* ms, int cap) {
   return count;
 }
 
+static int decompose_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_segments, int n_segments,
+                            const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* d_faces, int32_t* d_counts,
+                            const fh::UnknownLattice& lat, const double* d_seg_spheres);
+
 int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_segments, int n_segments,
                               const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* d_faces,
                               int32_t* d_counts) {
+  fh::UnknownLattice lat;
+  std::memset(&lat, 0, sizeof(lat));
+  return decompose_device(ctx, d_cloud_xyz, n_cloud, d_segments, n_segments, local_bbox, drone_radius, z_ground, max_faces, d_faces, d_counts, lat,
+                          nullptr);
+}
+
+// lat.on + d_seg_spheres: the unknown voxels of a grid (cells farther than sphere[3] from sphere[0..2], per segment) are points of the
+// decomposition as well, listed before the cloud (fh_safe.hip.hpp)
+static int decompose_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud, const double* d_segments, int n_segments,
+                            const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* d_faces, int32_t* d_counts,
+                            const fh::UnknownLattice& lat, const double* d_seg_spheres) {
   if (!ctx || n_cloud < 0 || n_segments < 0 || max_faces < 8 || !local_bbox) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
   DeviceScope device_scope(ctx);
@@ -793,7 +810,7 @@ int fh_decompose_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_clou
   }
   hipLaunchKernelGGL(fh::decomp_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_cloud_xyz, n_cloud, d_segments, n_segments,
                      local_bbox[0], local_bbox[1], local_bbox[2], drone_radius, z_ground, max_faces, (double*)ctx->d_buf[7], d_faces,
-                     d_counts, d_blocks);
+                     d_counts, d_blocks, lat, lat.on ? d_seg_spheres : nullptr);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
@@ -901,6 +918,63 @@ int fh_corridor_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud
     return rc;
   hipLaunchKernelGGL(corridor_assemble_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_n_points, n, max_poly, seg_cap,
                      (const fh_face*)ctx->d_buf[11], (const int32_t*)ctx->d_buf[12], faces_per_problem, d_faces, d_face_off, d_n_poly);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+// The safe corridor of Faster::replan (faster.cpp:446-524) for a batch of pairs: see fh_safe.hip.hpp and include/fasterhip.h.
+int fh_safe_corridor_batch_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const double* d_paths,
+                                  const int32_t* d_n_points, int max_points, const double* d_goals, const double* d_cloud_xyz, int n_cloud,
+                                  const fh_voxel_grid* grid, int n, double r_frac, int max_poly_safe, const double local_bbox[3],
+                                  double drone_radius, double z_ground, int faces_per_problem, int n_seg_safe, fh_problem* d_safe,
+                                  fh_face* d_safe_faces, double* d_safe_paths, int32_t* d_safe_n_points) {
+  if (!ctx || n < 0 || n_cloud < 0 || max_points < 2 || max_points > fh::SAFE_PATH_CAP || max_poly_safe < 1 || max_poly_safe > FH_MAX_POLY ||
+      faces_per_problem < 8 || !local_bbox || !grid || n_seg_safe < 1 || n_seg_safe > FH_MAX_SEG)
+    return FH_ERR_ARG;
+  if (!(grid->res > 0) || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1 || !(r_frac >= 0) || !(r_frac <= 1)) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_whole || !d_whole_results || !d_paths || !d_n_points || !d_goals || !d_safe || !d_safe_faces || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
+  if ((size_t)n * (size_t)faces_per_problem > (size_t)0x7fffffff) return FH_ERR_ARG;
+  const int mp = max_poly_safe + 1;
+  const size_t nseg = (size_t)n * max_poly_safe;
+  // one buffer: safe paths [n][mp][3] | spheres [n][4] | goal M [n][3] | face_off [n][9] | n_poly [n] | np [n]
+  const size_t o_paths = 0, o_sph = o_paths + sizeof(double) * 3 * mp * (size_t)n, o_goal = o_sph + sizeof(double) * 4 * (size_t)n,
+               o_off = o_goal + sizeof(double) * 3 * (size_t)n, o_np = o_off + sizeof(int32_t) * 9 * (size_t)n,
+               o_cnt = o_np + sizeof(int32_t) * (size_t)n, total = o_cnt + sizeof(int32_t) * (size_t)n;
+  int rc;
+  if ((rc = ensure(ctx, 16, total)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 17, sizeof(double) * 4 * nseg)) != FH_OK) return rc;
+  unsigned char* base = (unsigned char*)ctx->d_buf[16];
+  double* w_paths = d_safe_paths ? d_safe_paths : (double*)(base + o_paths);
+  double* w_sph = (double*)(base + o_sph);
+  double* w_goal = (double*)(base + o_goal);
+  int32_t* w_off = (int32_t*)(base + o_off);
+  int32_t* w_npoly = (int32_t*)(base + o_np);
+  int32_t* w_np = d_safe_n_points ? d_safe_n_points : (int32_t*)(base + o_cnt);
+  hipLaunchKernelGGL(fh::safe_path_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole, d_whole_results, d_paths, d_n_points, n, max_points,
+                     r_frac, ctx->pair_rule, max_poly_safe, d_safe, w_paths, w_np, w_sph);
+  hipLaunchKernelGGL(fh::safe_spheres_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, ctx->stream, w_sph, n, max_poly_safe,
+                     (double*)ctx->d_buf[17]);
+  FH_HIP(hipGetLastError());
+  const int seg_cap = FH_MAX_FACES_POLY;
+  if ((rc = ensure(ctx, 10, sizeof(double) * 6 * nseg)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 11, sizeof(fh_face) * nseg * seg_cap)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 12, sizeof(int32_t) * nseg)) != FH_OK) return rc;
+  hipLaunchKernelGGL(corridor_segments_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, ctx->stream, w_paths, w_np, n, mp, max_poly_safe,
+                     (double*)ctx->d_buf[10], w_goal);
+  FH_HIP(hipGetLastError());
+  fh::UnknownLattice lat;
+  lat.ox = grid->origin[0]; lat.oy = grid->origin[1]; lat.oz = grid->origin[2]; lat.res = grid->res;
+  lat.nx = grid->dims[0]; lat.ny = grid->dims[1]; lat.nz = grid->dims[2]; lat.on = 1;
+  if ((rc = decompose_device(ctx, d_cloud_xyz, n_cloud, (const double*)ctx->d_buf[10], (int)nseg, local_bbox, drone_radius, z_ground, seg_cap,
+                             (fh_face*)ctx->d_buf[11], (int32_t*)ctx->d_buf[12], lat, (const double*)ctx->d_buf[17])) != FH_OK)
+    return rc;
+  hipLaunchKernelGGL(corridor_assemble_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, w_np, n, max_poly_safe, seg_cap,
+                     (const fh_face*)ctx->d_buf[11], (const int32_t*)ctx->d_buf[12], faces_per_problem, d_safe_faces, w_off, w_npoly);
+  hipLaunchKernelGGL(fh::safe_finalize_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, w_np, w_goal, d_goals, d_safe_faces, w_off, w_npoly, n,
+                     faces_per_problem, n_seg_safe, d_safe);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }

@@ -106,6 +106,42 @@ __device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt,
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Unknown space as the mapper would report it — one point per voxel it has never seen — MODELLED for a batch of independent
+// problems: the voxels of a grid (cell centres) that lie farther than a radius from a point (the vehicle: it has seen what its
+// sensor reaches and nothing else).  Nothing is stored: a segment enumerates the cells of the grid inside the bounding box of its
+// local box, z-major, x fastest — the order in which a cloud holding ALL such voxels would list them.
+struct UnknownLattice {
+  double ox, oy, oz, res;
+  int nx, ny, nz, on;
+};
+struct LatticeRange {
+  int x0, cx, y0, cy, z0, cz, total;  // sub-block of the grid: first cell and count per axis
+  double ax, ay, az, r2;              // the sphere of known space
+};
+__device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat, const double lo[3], const double hi[3], const double* sphere) {
+  LatticeRange g;
+  g.total = 0; g.x0 = g.y0 = g.z0 = g.cx = g.cy = g.cz = 0;
+  g.ax = g.ay = g.az = g.r2 = 0;
+  if (!lat.on || !sphere) return g;
+  auto first = [](double v, double o, double res, int n) { int i = (int)floor((v - o) / res) - 1; return i < 0 ? 0 : (i > n ? n : i); };
+  auto last = [](double v, double o, double res, int n) { int i = (int)floor((v - o) / res) + 1; return i > n - 1 ? n - 1 : i; };
+  g.x0 = first(lo[0], lat.ox, lat.res, lat.nx); g.cx = last(hi[0], lat.ox, lat.res, lat.nx) - g.x0 + 1;
+  g.y0 = first(lo[1], lat.oy, lat.res, lat.ny); g.cy = last(hi[1], lat.oy, lat.res, lat.ny) - g.y0 + 1;
+  g.z0 = first(lo[2], lat.oz, lat.res, lat.nz); g.cz = last(hi[2], lat.oz, lat.res, lat.nz) - g.z0 + 1;
+  if (g.cx <= 0 || g.cy <= 0 || g.cz <= 0) return g;
+  g.total = g.cx * g.cy * g.cz;
+  g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3];
+  return g;
+}
+// cell number idx of the sub-block: its centre, and whether it is an unknown voxel
+__device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const LatticeRange& g, int idx, D3& q) {
+  if (idx >= g.total) return false;
+  const int iz = idx / (g.cx * g.cy), rem = idx - iz * (g.cx * g.cy), iy = rem / g.cx, ix = rem - iy * g.cx;
+  q = d3(((double)(g.x0 + ix) + 0.5) * lat.res + lat.ox, ((double)(g.y0 + iy) + 0.5) * lat.res + lat.oy, ((double)(g.z0 + iz) + 0.5) * lat.res + lat.oz);
+  const double dx = q.x - g.ax, dy = q.y - g.ay, dz = q.z - g.az;
+  return dx * dx + dy * dy + dz * dz > g.r2;
+}
+
 #define FH_DECOMP_BLIST 1024  // candidate blocks per segment (more: full sweep)
 #define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the list lives in the HBM workspace (dense clouds); more => count = -1
 
@@ -114,25 +150,17 @@ __device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt,
 template <class PD, class PF>
 __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
                                const D3* bn, double inflate, double z_ground, int max_faces, fh_face* __restrict__ out,
-                               int32_t* __restrict__ count_out, int lane, const int* blist, int nb) {
+                               int32_t* __restrict__ count_out, int lane, const int* blist, int nb, const UnknownLattice& lat,
+                               const LatticeRange& lrange) {
   const D3 dvec = p2 - p1;
   const double f = norm(dvec) / 2;
   const Rot Ri = rot_onto(dvec);
   const D3 c = (p1 + p2) * 0.5;
-  // ---- sweep the cloud: keep the points inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
+  // ---- sweep the points: keep those inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
   int cnt = 0;
-  const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;  // (the blocks of 64 cloud points that can touch the box, in cloud order)
-  for (int j = 0; j < n_sweep; j++) {
-    const int base = (nb >= 0 ? blist[j] : j) * 64;
-    const int i = base + lane;
-    bool in = false;
-    D3 q = d3(0, 0, 0);
-    if (i < n_cloud) {
-      q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
-      in = true;
+  auto keep = [&](bool in, D3 q) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
-    }
+    for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
     const unsigned long long m = __ballot(in);
     if (m) {
       if (in) {
@@ -143,6 +171,23 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
       }
       cnt += __popcll(m);
     }
+  };
+  for (int base = 0; base < lrange.total; base += 64) {  // the unknown voxels first (a cloud of unknown + occupied points lists them first)
+    D3 q = d3(0, 0, 0);
+    const bool in = lattice_point(lat, lrange, base + lane, q);
+    keep(in, q);
+  }
+  const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;  // (the blocks of 64 cloud points that can touch the box, in cloud order)
+  for (int j = 0; j < n_sweep; j++) {
+    const int base = (nb >= 0 ? blist[j] : j) * 64;
+    const int i = base + lane;
+    bool in = false;
+    D3 q = d3(0, 0, 0);
+    if (i < n_cloud) {
+      q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
+      in = true;
+    }
+    keep(in, q);
   }
   __syncthreads();
 
@@ -235,7 +280,8 @@ __global__ void __launch_bounds__(64) cloud_blocks_kernel(const double* __restri
 __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
                                                     int n_segments, double bx, double by, double bz, double inflate, double z_ground,
                                                     int max_faces, double* __restrict__ workspace, fh_face* __restrict__ faces,
-                                                    int32_t* __restrict__ counts, const double* __restrict__ blocks) {
+                                                    int32_t* __restrict__ counts, const double* __restrict__ blocks, UnknownLattice lat,
+                                                    const double* __restrict__ spheres) {
   __shared__ double lpx[FH_DECOMP_CAP], lpy[FH_DECOMP_CAP], lpz[FH_DECOMP_CAP];
   __shared__ unsigned char lflag[FH_DECOMP_CAP];  // bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
   __shared__ int lblist[FH_DECOMP_BLIST];         // blocks of the cloud that can touch the local box, ascending
@@ -274,14 +320,15 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
     // hold no point of interest: a mapper's cloud is spatially coherent, so most blocks are skipped.  The candidates are visited in
     // cloud order, so the list of points — and with it every tie rule — is the one of the full sweep.
     int nb = -1;
-    if (blocks) {
-      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
 #pragma unroll
-      for (int corner = 0; corner < 8; corner++) {
-        const D3 e = (corner & 1 ? p2 + dir * bx : p1 - dir * bx) + dh * (corner & 2 ? by : -by) + dv * (corner & 4 ? bz : -bz);
-        lo[0] = fmin(lo[0], e.x); lo[1] = fmin(lo[1], e.y); lo[2] = fmin(lo[2], e.z);
-        hi[0] = fmax(hi[0], e.x); hi[1] = fmax(hi[1], e.y); hi[2] = fmax(hi[2], e.z);
-      }
+    for (int corner = 0; corner < 8; corner++) {
+      const D3 e = (corner & 1 ? p2 + dir * bx : p1 - dir * bx) + dh * (corner & 2 ? by : -by) + dv * (corner & 4 ? bz : -bz);
+      lo[0] = fmin(lo[0], e.x); lo[1] = fmin(lo[1], e.y); lo[2] = fmin(lo[2], e.z);
+      hi[0] = fmax(hi[0], e.x); hi[1] = fmax(hi[1], e.y); hi[2] = fmax(hi[2], e.z);
+    }
+    const LatticeRange lrange = lattice_range(lat, lo, hi, spheres ? spheres + 4 * (size_t)seg : nullptr);
+    if (blocks) {
       const int n_blocks = (n_cloud + 63) / 64;
       nb = 0;
       for (int b0 = 0; b0 < n_blocks && nb >= 0; b0 += 64) {
@@ -303,6 +350,13 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
       __syncthreads();
     }
     int cnt = 0;
+    for (int base = 0; base < lrange.total; base += 64) {
+      D3 q = d3(0, 0, 0);
+      bool in = lattice_point(lat, lrange, base + lane, q);
+#pragma unroll
+      for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
+      cnt += __popcll(__ballot(in));
+    }
     const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;
     for (int j = 0; j < n_sweep; j++) {
       const int base = (nb >= 0 ? lblist[j] : j) * 64;
@@ -317,9 +371,11 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
       cnt += __popcll(__ballot(in));
     }
     if (cnt <= FH_DECOMP_CAP)
-      decomp_segment(lpx, lpy, lpz, lflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb);
+      decomp_segment(lpx, lpy, lpz, lflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat,
+                     lrange);
     else if (cnt <= FH_DECOMP_CAP_GLOBAL)
-      decomp_segment(gpx, gpy, gpz, gflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb);
+      decomp_segment(gpx, gpy, gpz, gflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat,
+                     lrange);
     else if (lane == 0)
       counts[seg] = -1;
   }

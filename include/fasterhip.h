@@ -307,6 +307,35 @@ int fh_corridor_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud
                              int max_points, int max_poly, const double local_bbox[3], double drone_radius, double z_ground,
                              int faces_per_problem, fh_face* d_faces, int32_t* d_face_off, int32_t* d_n_poly, double* d_goal);
 
+/* The SAFE corridor of Faster::replan, decomposed around R (faster/src/faster.cpp:446-524), for a batch of pairs whose whole
+ * trajectories are solved — the faithful alternative to the hand-off of fh_pair_glue_device / fh_solve_pairs_device, which reuses
+ * polytopes of the whole corridor.  Per pair:
+ *   1. the path inside the sphere, JPS_in (d_paths [n][max_points][3], d_n_points [n]: what fh_map_plan_batch_device returns, first
+ *      vertex = the start A), is cut where it first comes within drone_radius of unknown space and backed off by drone_radius
+ *      (getFirstCollisionJPS(..., UNKNOWN_MAP, RETURN_INTERSECTION), :451-452);
+ *   2. R = sample k_safe of the whole trajectory by the rule of the context (fh_set_pair_rule; r_frac in mode 0) becomes the first
+ *      vertex and x0 of the safe problem; at most max_poly_safe legs are kept (:478-490); M = the last vertex;
+ *   3. the path is decomposed against unknown + occupied points (:494): d_cloud_xyz are the occupied ones, the unknown ones are the
+ *      voxels of `grid` (cell centres (i + 0.5) res + origin) farther than r_known from A, enumerated z-major and listed FIRST;
+ *   4. d_safe[i]: x0 = R, xf = G (d_goals[i]) when G lies in the last polytope, else M (:498-499), n_poly / face_off / face_begin
+ *      (= i * faces_per_problem, rows in d_safe_faces), n_seg = n_seg_safe; every other field is left as the caller prepared it.
+ * Unknown space is MODELLED (a batch has no mapper): everything farther than fh_pair_rule.r_known from A.  A pair without a whole
+ * trajectory, without a need for a safe one (rule mode 1) or without a corridor gets n_seg = 0.  Then solve d_safe with
+ * fh_solve_batch_device and splice with fh_append_plans_device.  d_safe_paths [n][max_poly_safe + 1][3] / d_safe_n_points [n]: the
+ * safe paths (may be NULL).  CPU restatement: oracle/pair_glue.py (safe_path, unknown_voxels) + the host decomposition.
+ * Device pointers, asynchronous on the context stream. */
+typedef struct fh_voxel_grid {
+  double origin[3];
+  double res;
+  int32_t dims[3];
+  int32_t reserved;
+} fh_voxel_grid;
+int fh_safe_corridor_batch_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const double* d_paths,
+                                  const int32_t* d_n_points, int max_points, const double* d_goals, const double* d_cloud_xyz, int n_cloud,
+                                  const fh_voxel_grid* grid, int n, double r_frac, int max_poly_safe, const double local_bbox[3],
+                                  double drone_radius, double z_ground, int faces_per_problem, int n_seg_safe, fh_problem* d_safe,
+                                  fh_face* d_safe_faces, double* d_safe_paths, int32_t* d_safe_n_points);
+
 /* Whole solve -> hand-off -> safe solve of every pair in ONE launch: a wavefront takes a pair through fh_solve_batch_device,
  * fh_pair_glue_device and fh_solve_batch_device back to back (the per-pair dependency of Faster::replan, faster.cpp:427 -> :475 ->
  * :521-536), so no safe solve waits for the slowest whole solve of the batch.  Arguments and results are those of the three calls

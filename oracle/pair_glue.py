@@ -110,3 +110,94 @@ def append_plans(whole, wres, safe, sres, r_frac=0.5, rule=None):
         plans.append(np.concatenate(parts))
         ks.append(k)
     return plans, np.array(ks, dtype=np.int32)
+
+
+# ---- the safe corridor decomposed around R (faster/src/faster.cpp:446-524): restatement of faster_amd/csrc/fh_safe.hip.hpp ----------
+def _sphere_crossing(a_in, b_in, r, c):
+    """Point where the segment a -> b leaves the sphere (centre c, radius r): single precision like the reference (utils.cpp:713-776)."""
+    f = np.float32
+    def solve(A, B):
+        x1, y1, z1, x2, y2, z2 = f(A[0]), f(A[1]), f(A[2]), f(B[0]), f(B[1]), f(B[2])
+        x3, y3, z3 = f(c[0]), f(c[1]), f(c[2])
+        a = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1)
+        b = f(2) * ((x2 - x1) * (x1 - x3) + (y2 - y1) * (y1 - y3) + (z2 - z1) * (z1 - z3))
+        cc = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - f(2) * (x3 * x1 + y3 * y1 + z3 * z1) - f(r * r)
+        disc = b * b - f(4) * a * cc
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t = (-b + np.sqrt(disc)) / (f(2) * a)
+            p = np.array([float(x1 + (x2 - x1) * t), float(y1 + (y2 - y1) * t), float(z1 + (z2 - z1) * t)])
+        return disc, p
+    disc, p = solve(a_in, b_in)
+    if disc <= 0:
+        return solve(c, a_in)[1]
+    return p
+
+
+def _sphere_exit(path, r, center):
+    """First point of the path on the sphere (utils.cpp:782-870) -> (point, last index inside, none outside)"""
+    index = -1
+    for i, v in enumerate(path):
+        if np.sqrt(((v - center) ** 2).sum()) > r:
+            index = i
+            break
+    if index == -1:
+        return _sphere_crossing(center, path[-1], r, center), len(path) - 1, True
+    if index == 0:
+        return path[0].copy(), 1, False
+    return _sphere_crossing(path[index - 1], path[index], r, center), index - 1, False
+
+
+def _shorten_by(path, d):
+    acc = 0.0
+    for i in range(len(path) - 1, 0, -1):
+        v = path[i] - path[i - 1]
+        ln = np.sqrt((v * v).sum())
+        acc += ln
+        if acc > d:
+            keep = acc - d
+            path = path[:i]
+            path.append(path[-1] + v / ln * keep)
+            break
+    return path
+
+
+def _norm3(v):
+    return np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+
+
+def safe_path(jps_in, A, R_pos, r_known, drone_radius, max_poly_safe):
+    """JPS_safe of Faster::replan: JPS_in cut where it first comes within drone_radius of unknown space (getFirstCollisionJPS against the
+    unknown map, :451-452 -> :767-926; distance to unknown space modelled as r_known - |p - A|) and backed off by drone_radius, first vertex
+    replaced by R, at most max_poly_safe legs (:478-490)."""
+    orig = [np.array(v, dtype=np.float64) for v in jps_in]
+    cur = [v.copy() for v in orig]
+    iteration = 0
+    while cur:
+        r = max(r_known - _norm3(cur[0] - A), 0.0)
+        if r < drone_radius:
+            if iteration == 0:
+                orig = [orig[0], orig[0] + np.array([0.01, 0.0, 0.0])]
+            else:
+                eliminated = len(orig) - len(cur) + 1
+                orig = orig[:eliminated] + [cur[0]]
+                orig = _shorten_by(orig, drone_radius)
+            break
+        inters, last_id, none_outside = _sphere_exit(cur, r, cur[0])
+        if none_outside:
+            break
+        cur = [inters] + cur[last_id + 1:]
+        iteration += 1
+    orig[0] = np.array(R_pos, dtype=np.float64)
+    return np.array(orig[:max_poly_safe + 1])
+
+
+def unknown_voxels(origin, res, dims, A, r_known):
+    """The mapper's unknown cloud, modelled: centres of the grid cells farther than r_known from A, z-major, x fastest."""
+    ix, iy, iz = np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2])
+    x = (ix + 0.5) * res + origin[0]
+    y = (iy + 0.5) * res + origin[1]
+    z = (iz + 0.5) * res + origin[2]
+    Z, Y, X = np.meshgrid(z, y, x, indexing="ij")
+    dx, dy, dz = X - A[0], Y - A[1], Z - A[2]
+    far = dx * dx + dy * dy + dz * dz > r_known * r_known
+    return np.column_stack([X[far], Y[far], Z[far]])

@@ -557,3 +557,96 @@ def test_plans_appended_on_the_device(ctx, oracle, mode):
     if mode == 1:
         whole_only = (safe["n_seg"] == 0) & (wres["solved"] == 1)
         assert whole_only.any() and np.array_equal(counts[whole_only], cw[whole_only])   # no unknown space on the way: the whole trajectory
+
+
+def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle):
+    """fh_safe_corridor_batch_device: the safe corridor of Faster::replan (faster.cpp:446-524) — JPS_in cut at unknown space, R first,
+    decomposition against unknown + occupied points, xf = G or M — for forest pairs whose corridors and whole trajectories come from
+    the device.  Against oracle/pair_glue.py: the safe paths equal the restatement (1e-9); the polytopes equal the HOST decomposition
+    of the same paths against the explicit cloud [unknown voxels of the map's grid, z-major | occupied points] BIT FOR BIT; xf follows
+    the G-inside rule; the safe problems then solve on the device like the oracle's."""
+    import torch
+
+    from faster_amd import frontend
+    from oracle import pair_glue
+
+    # whole corridors as FASTER builds them: at most 3 polytopes of <= 1.5 m (max_poly_whole 3), so that the whole trajectory comes to
+    # rest about as far out as the vehicle has seen (Ra = r_known = 4 m) — with the 12 m corridors of config C5 the vehicle is still
+    # fast where known space ends and no safe trajectory exists inside it (v_max 5, a_max 5, j_max 8: all 96 infeasible, as they should be)
+    n, N, max_poly, mps = 128, 10, 3, 3
+    res, infl, zmax, r_known, drone_r, decomp_r = 0.2, 0.3, 3.0, 4.0, 0.3, 0.05
+    vmap = capi.Map(0)
+    try:
+        pr, fc, info = frontend.forest_batch(n, 41, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, search="jps")
+        cloud, cells, center, starts, goals = frontend.forest_queries(n, 41)
+        paths, npts, _ = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=1.5, max_poly=max_poly)
+        dims, origin = vmap.dims()
+    finally:
+        vmap.close()
+    kept = info["kept"]
+    paths, npts, goals = paths[kept], npts[kept], goals[kept]
+    B = len(pr)
+    assert B > 0.9 * n and (npts >= 2).all()
+    mf = int(pr["face_off"][np.arange(B), pr["n_poly"]].max())
+    d_pr, d_fc = _dev(pr), _dev(fc)
+    d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    ctx.solve_batch_device(d_pr.data_ptr(), d_fc.data_ptr(), B, N, mf, d_wr.data_ptr())
+    tmpl = corridor.safe_templates(pr)
+    tmpl["n_seg"] = N
+    fpp = 96
+    d_safe = _dev(tmpl)
+    d_sf = torch.zeros(B * fpp * abi.face_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_paths, d_np, d_goals, d_cloud = _dev(paths), _dev(npts.astype(np.int32)), _dev(goals), _dev(cloud)
+    d_sp = torch.zeros(B * (mps + 1) * 3, dtype=torch.float64, device="cuda:0")
+    d_snp = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    rule = dict(r_known=r_known, drone_radius=drone_r, delta_h=1.0, delta_a=0.5)
+    ctx.set_pair_rule(mode=1, **rule)
+    try:
+        ctx.safe_corridor_batch_device(d_pr.data_ptr(), d_wr.data_ptr(), d_paths.data_ptr(), d_np.data_ptr(), max_poly + 1, d_goals.data_ptr(),
+                                       d_cloud.data_ptr(), len(cloud), origin, res, dims, B, 0.5, mps, (2.0, 2.0, 1.0), decomp_r, 0.0, fpp, N,
+                                       d_safe.data_ptr(), d_sf.data_ptr(), d_sp.data_ptr(), d_snp.data_ptr())
+        ctx.sync()
+    finally:
+        ctx.set_pair_rule(mode=0)
+    wres = d_wr.cpu().numpy().view(abi.result_dtype)
+    safe = d_safe.cpu().numpy().view(abi.problem_dtype)
+    sfaces = d_sf.cpu().numpy().view(abi.face_dtype).reshape(B, fpp)
+    spaths, snp = d_sp.cpu().numpy().reshape(B, mps + 1, 3), d_snp.cpu().numpy()
+    assert (wres["solved"] == 1).mean() > 0.9
+    live = np.nonzero(snp >= 2)[0]
+    assert 0.4 * B < len(live) < B        # (the others never come near unknown space: no safe trajectory needed)
+    assert np.array_equal(safe["n_seg"][snp < 2], np.zeros((snp < 2).sum(), dtype=safe["n_seg"].dtype))
+    checked = 0
+    for i in live[:40]:
+        A = pr["x0"][i, :3]
+        want = pair_glue.safe_path(paths[i, :npts[i]], A, safe["x0"][i, :3], r_known, drone_r, mps)
+        assert len(want) == snp[i], (i, len(want), snp[i])
+        np.testing.assert_allclose(spaths[i, :snp[i]], want, rtol=0, atol=1e-9)
+        # known space only: every vertex of the safe path but R's successor chain ends before unknown space
+        assert np.linalg.norm(spaths[i, snp[i] - 1] - A) <= r_known + 1e-6
+        full = np.vstack([pair_glue.unknown_voxels(origin, res, dims, A, r_known), cloud])
+        polys, _ = frontend.decompose(spaths[i, :snp[i]], full, drone_radius=decomp_r, z_ground=0.0, bbox=(2.0, 2.0, 1.0), max_faces=4096)
+        P = int(safe["n_poly"][i])
+        assert safe["n_seg"][i] == N and P == len(polys) == snp[i] - 1 and safe["face_begin"][i] == i * fpp
+        for p, (Ah, bh) in enumerate(polys):
+            f0, f1 = safe["face_off"][i, p], safe["face_off"][i, p + 1]
+            assert f1 - f0 == len(bh), (i, p, f1 - f0, len(bh))
+            assert np.array_equal(sfaces["a"][i, f0:f1], Ah) and np.array_equal(sfaces["b"][i, f0:f1], bh), (i, p)
+        Al, bl = polys[-1]
+        inside = not np.any(Al @ goals[i] - bl > 0)
+        assert np.array_equal(safe["xf"][i, :3], goals[i] if inside else spaths[i, snp[i] - 1]), i
+        # R inside its first polytope (the corridor is decomposed around it)
+        A0, b0 = polys[0]
+        assert np.all(A0 @ safe["x0"][i, :3] - b0 <= 1e-9)
+        checked += 1
+    assert checked >= 30
+    # the safe problems solve, and as the oracle solves them
+    sel = live
+    sp = safe[sel].copy()
+    d_sp2 = _dev(sp)
+    d_sr = torch.zeros(len(sel) * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    ctx.solve_batch_device(d_sp2.data_ptr(), d_sf.data_ptr(), len(sel), N, fpp, d_sr.data_ptr())
+    ctx.sync()
+    sres = d_sr.cpu().numpy().view(abi.result_dtype)
+    compare(sres[:32], oracle.solve_batch(sp[:32], sfaces.reshape(-1)))
+    assert (sres["solved"] == 1).mean() > 0.8, ((sres["solved"] == 1).mean(), np.unique(sres["status"], return_counts=True), sp[0], sres[0]["trials"])
