@@ -350,6 +350,7 @@ def main():
             if args.workload == "c4":
                 out["config"]["safe_solved_frac_literal_8d"] = literal_leg(make_pipe, run_step, fused, abi, B)
                 out["c5"] = c5_leg(torch, dev, local_rank, par, args.r_margin)
+                out["replan_faithful"] = replan_leg(torch, dev, local_rank, par)
         if not args.no_cpu and world == 1:  # the CPU baseline is a property of the host: reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(whole, faces, safe_h, sfaces_h, args.cpu_seconds)
         print(json.dumps(out))
@@ -530,6 +531,87 @@ def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batch
                     "H2D problems+faces+safe templates -> fused pair launch -> pack -> D2H of the packed result records (%d B instead of "
                     "%d), so that the copies of one batch overlap the solve of the next; serial_full_records: one batch at a time on one "
                     "stream with the full records (round 2's figure)" % (batches, PK, RES)}
+
+
+def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
+    """One Faster::replan per pair with FASTER's own parameters (faster.yaml: N_whole = N_safe = 6, max_poly_whole = max_poly_safe = 3,
+    dist_max_vertexes 1.5 m, Ra 4 m, delta_H 1, delta_a 0.5) and its own steps, all on the device and outside the C4 timed region:
+    map + jump point search + corridor of the whole path (front-end), whole solve, the safe corridor decomposed around R against unknown +
+    occupied space (fh_safe_corridor_batch_device; unknown space modelled: farther than Ra from the start), safe solve, appendToPlan.
+    Median of `reps` fenced passes per stage."""
+    import numpy as np
+
+    from faster_amd import abi, capi, corridor, frontend
+
+    N, max_poly, r_known, drone_r, decomp_r, fpp, max_states = 6, 3, 4.0, 0.3, 0.05, 96, 512
+    ctx, vmap = capi.Context(local_rank), capi.Map(local_rank)
+    try:
+        frontend.forest_batch(256, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank, search="jps")
+        pr, fc, info = frontend.forest_batch(pairs, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank,
+                                             search="jps")
+        cloud, cells, center, starts, goals = frontend.forest_queries(pairs, 7)
+        paths, npts, _ = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=1.5, max_poly=max_poly)  # JPS_in per pair
+        dims, origin = vmap.dims()
+    finally:
+        vmap.close()
+    kept = info["kept"]
+    paths, npts, goals = paths[kept], npts[kept].astype(np.int32), goals[kept]
+    B = len(pr)
+    mf = int(pr["face_off"][np.arange(B), pr["n_poly"]].max())
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+
+    tmpl = corridor.safe_templates(pr)
+    tmpl["n_seg"] = N
+    d_pr, d_fc, d_tmpl = to_dev(pr), to_dev(fc), to_dev(tmpl)
+    d_paths, d_np, d_goals, d_cloud = to_dev(paths), to_dev(npts), to_dev(goals), to_dev(cloud)
+    RES = abi.result_dtype.itemsize
+    d_wr, d_sr = torch.zeros(B * RES, dtype=torch.uint8, device=dev), torch.zeros(B * RES, dtype=torch.uint8, device=dev)
+    d_safe = torch.zeros_like(d_tmpl)
+    d_sf = torch.zeros(B * fpp * abi.face_dtype.itemsize, dtype=torch.uint8, device=dev)
+    d_plans = torch.zeros(B * max_states * abi.state_dtype.itemsize, dtype=torch.uint8, device=dev)
+    d_counts, d_k = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    ctx.set_params(par)
+    ctx.set_pair_rule(mode=1, r_known=r_known, drone_radius=drone_r, delta_h=1.0, delta_a=0.5)
+    stages = {"whole_solve": [], "safe_corridor": [], "safe_solve": [], "append_plans": []}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fn()
+        ctx.sync()
+        stages[name].append(1e3 * (time.perf_counter() - t))
+
+    for _ in range(reps + 1):
+        d_safe.copy_(d_tmpl)
+        timed("whole_solve", lambda: ctx.solve_batch_device(d_pr.data_ptr(), d_fc.data_ptr(), B, N, mf, d_wr.data_ptr()))
+        timed("safe_corridor", lambda: ctx.safe_corridor_batch_device(d_pr.data_ptr(), d_wr.data_ptr(), d_paths.data_ptr(), d_np.data_ptr(), max_poly + 1,
+                                                                      d_goals.data_ptr(), d_cloud.data_ptr(), len(cloud), origin, 0.2, dims, B, 0.5,
+                                                                      max_poly, (2.0, 2.0, 1.0), decomp_r, 0.0, fpp, N, d_safe.data_ptr(),
+                                                                      d_sf.data_ptr()))
+        timed("safe_solve", lambda: ctx.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, fpp, d_sr.data_ptr()))
+        timed("append_plans", lambda: ctx.append_plans_device(d_pr.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states,
+                                                              d_plans.data_ptr(), d_counts.data_ptr(), d_k.data_ptr()))
+    wres, sres = d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype)
+    safe = d_safe.cpu().numpy().view(abi.problem_dtype)
+    counts = d_counts.cpu().numpy()
+    ctx.close()
+    med = {k: float(np.median(v[1:])) for k, v in stages.items()}
+    ft = info["front_timing"]
+    front_ms = 1e3 * (ft["map_s"] + ft["path_search_s"] + ft["decomposition_s"])
+    total_ms = front_ms + sum(med.values())
+    need = safe["n_seg"] > 0
+    return {"workload": "one Faster::replan per pair, FASTER's own parameters (N 6, max_poly 3, Ra 4 m): %d start/goal pairs in a random forest, "
+                        "%d with a path; device-resident, one stage at a time" % (pairs, B),
+            "stages_ms": {"front_end (map, jump point search, whole corridor)": front_ms, **med},
+            "replans_per_s": B / (total_ms * 1e-3), "total_ms": total_ms,
+            "whole_solved_frac": float(wres["solved"].mean()), "pairs_needing_a_safe_trajectory": int(need.sum()),
+            "safe_solved_frac": float(sres["solved"][need].mean()) if need.any() else None,
+            "plans_committed_frac": float((counts > 0).mean()), "mean_plan_states": float(counts[counts > 0].mean()) if (counts > 0).any() else 0.0,
+            "note": "unknown space is MODELLED (a batch has no mapper): everything farther than Ra from the start — distance queries use "
+                    "Ra - |p - A|, the decomposition sees the voxels of the map's grid out there; the problem records of the whole solve are "
+                    "assembled on the host between front-end and solver (not timed), JPS_in is read from a second, untimed search call"}
 
 
 def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
