@@ -559,7 +559,8 @@ def test_plans_appended_on_the_device(ctx, oracle, mode):
         assert whole_only.any() and np.array_equal(counts[whole_only], cw[whole_only])   # no unknown space on the way: the whole trajectory
 
 
-def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle):
+@pytest.mark.parametrize("r_known", [4.0, 100.0, 0.2])
+def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle, r_known):
     """fh_safe_corridor_batch_device: the safe corridor of Faster::replan (faster.cpp:446-524) — JPS_in cut at unknown space, R first,
     decomposition against unknown + occupied points, xf = G or M — for forest pairs whose corridors and whole trajectories come from
     the device.  Against oracle/pair_glue.py: the safe paths equal the restatement (1e-9); the polytopes equal the HOST decomposition
@@ -573,8 +574,10 @@ def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle):
     # whole corridors as FASTER builds them: at most 3 polytopes of <= 1.5 m (max_poly_whole 3), so that the whole trajectory comes to
     # rest about as far out as the vehicle has seen (Ra = r_known = 4 m) — with the 12 m corridors of config C5 the vehicle is still
     # fast where known space ends and no safe trajectory exists inside it (v_max 5, a_max 5, j_max 8: all 96 infeasible, as they should be)
-    n, N, max_poly, mps = 128, 10, 3, 3
-    res, infl, zmax, r_known, drone_r, decomp_r = 0.2, 0.3, 3.0, 4.0, 0.3, 0.05
+    # r_known 100: nobody comes near unknown space (no safe problem at all); 0.2 < drone_radius: the start itself is at the boundary —
+    # the reference's 1 cm stub path, a corridor squeezed between unknown voxels
+    n, N, max_poly, mps = (128 if r_known == 4.0 else 48), 10, 3, 3
+    res, infl, zmax, drone_r, decomp_r = 0.2, 0.3, 3.0, 0.3, 0.05
     vmap = capi.Map(0)
     try:
         pr, fc, info = frontend.forest_batch(n, 41, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, search="jps")
@@ -614,7 +617,14 @@ def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle):
     spaths, snp = d_sp.cpu().numpy().reshape(B, mps + 1, 3), d_snp.cpu().numpy()
     assert (wres["solved"] == 1).mean() > 0.9
     live = np.nonzero(snp >= 2)[0]
-    assert 0.4 * B < len(live) < B        # (the others never come near unknown space: no safe trajectory needed)
+    if r_known == 100.0:
+        assert len(live) == 0 and (safe["n_seg"] == 0).all()
+        return
+    if r_known == 0.2:
+        assert len(live) == (wres["solved"] == 1).sum()
+        assert np.allclose(spaths[live, 1], pr["x0"][live, :3] + [0.01, 0.0, 0.0], atol=1e-12) and (snp[live] == 2).all()
+    else:
+        assert 0.4 * B < len(live) < B        # (the others never come near unknown space: no safe trajectory needed)
     assert np.array_equal(safe["n_seg"][snp < 2], np.zeros((snp < 2).sum(), dtype=safe["n_seg"].dtype))
     checked = 0
     for i in live[:40]:
@@ -623,7 +633,7 @@ def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle):
         assert len(want) == snp[i], (i, len(want), snp[i])
         np.testing.assert_allclose(spaths[i, :snp[i]], want, rtol=0, atol=1e-9)
         # known space only: every vertex of the safe path but R's successor chain ends before unknown space
-        assert np.linalg.norm(spaths[i, snp[i] - 1] - A) <= r_known + 1e-6
+        assert r_known < 1.0 or np.linalg.norm(spaths[i, snp[i] - 1] - A) <= r_known + 1e-6
         full = np.vstack([pair_glue.unknown_voxels(origin, res, dims, A, r_known), cloud])
         polys, _ = frontend.decompose(spaths[i, :snp[i]], full, drone_radius=decomp_r, z_ground=0.0, bbox=(2.0, 2.0, 1.0), max_faces=4096)
         P = int(safe["n_poly"][i])
@@ -637,9 +647,11 @@ def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle):
         assert np.array_equal(safe["xf"][i, :3], goals[i] if inside else spaths[i, snp[i] - 1]), i
         # R inside its first polytope (the corridor is decomposed around it)
         A0, b0 = polys[0]
-        assert np.all(A0 @ safe["x0"][i, :3] - b0 <= 1e-9)
+        assert r_known < 1.0 or np.all(A0 @ safe["x0"][i, :3] - b0 <= 1e-9)
         checked += 1
     assert checked >= 30
+    if r_known < 1.0:
+        return
     # the safe problems solve, and as the oracle solves them
     sel = live
     sp = safe[sel].copy()
