@@ -546,10 +546,12 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
     N, max_poly, r_known, drone_r, decomp_r, fpp, max_states = 6, 3, 4.0, 0.3, 0.05, 96, 512
     ctx, vmap = capi.Context(local_rank), capi.Map(local_rank)
     try:
-        frontend.forest_batch(256, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank, search="jps")
+        frontend.forest_batch(256, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank, search="jps",
+                              sphere_ra=r_known)
         pr, fc, info = frontend.forest_batch(pairs, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank,
-                                             search="jps")
+                                             search="jps", sphere_ra=r_known)   # the whole corridor around JPS_in (the path inside the sphere Ra)
         cloud, cells, center, starts, goals = frontend.forest_queries(pairs, 7)
+        vmap.set_sphere(r_known)
         paths, npts, _ = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=1.5, max_poly=max_poly)  # JPS_in per pair
         dims, origin = vmap.dims()
     finally:

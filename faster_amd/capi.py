@@ -20,7 +20,7 @@ SYMBOLS = [
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
-    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_sync", "fh_map_read", "fh_map_read_device",
+    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_set_sphere", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
     "fh_packed_result_size", "fh_pack_results_device", "fh_pack_results", "fh_unpack_results",
@@ -85,6 +85,8 @@ def lib():
         L.fh_map_set_sched.argtypes = [vp, i32, i32]
         L.fh_map_set_search.restype = i32
         L.fh_map_set_search.argtypes = [vp, i32]
+        L.fh_map_set_sphere.restype = i32
+        L.fh_map_set_sphere.argtypes = [vp, f64]
         L.fh_set_pair_margin.restype = i32
         L.fh_set_pair_margin.argtypes = [vp, f64]
         L.fh_set_pair_rule.restype = i32
@@ -277,6 +279,10 @@ class Map:
     def set_sched(self, waves_per_cu=0, launch_order=1):
         """fh_map_set_sched: wavefronts per CU that hold a search workspace (0 = default 12), far-apart pairs first (default 1)."""
         self._check(lib().fh_map_set_sched(self._h, int(waves_per_cu), int(launch_order)), "fh_map_set_sched")
+
+    def set_sphere(self, ra):
+        """fh_map_set_sphere: clip every path to JPS_in (sphere of radius min(|goal - start| - 0.001, ra) around the start); 0: off."""
+        self._check(lib().fh_map_set_sphere(self._h, float(ra)), "fh_map_set_sphere")
 
     def set_search(self, mode):
         """fh_map_set_search: "astar" (default; an optimal path, total order of its own) or "jps" (jump point search in jps3d's own

@@ -37,6 +37,7 @@ struct fh_map {
   int sched_waves_per_cu = 0, sched_launch_order = 1;  // fh_map_set_sched (0: 12 wavefronts per CU for A*, 16 for the jump point search)
   int* d_order = nullptr;  // 128 counters + launch order
   size_t order_cap = 0;
+  double sphere_ra = 0.0;                 // fh_map_set_sphere
   int search_mode = 0;                    // fh_map_set_search: 0 A* with a total order, 1 jump point search in jps3d's order
   unsigned char* d_jps_tables = nullptr;  // neighbour tables of the jump point search (uploaded by the first fh_map_set_search(1))
   short* d_jps_entries = nullptr;         // jump tables of the current grid [cells][32] (fhp::jps_table_kernel), built by the first search in mode 1
@@ -188,6 +189,14 @@ int fh_map_set_search(fh_map* m, int mode) {
   return FH_OK;
 }
 
+// JPS_in of Faster::replan (faster.cpp:370-382): with ra > 0 every path is cut at its first crossing of the sphere of radius
+// min(|goal - start| - 0.001, ra) around its start, the crossing point appended, BEFORE createMoreVertexes / deleteVertexes.  0 (default): off.
+int fh_map_set_sphere(fh_map* m, double ra) {
+  if (!m || !(ra >= 0.0)) return FH_ERR_ARG;
+  m->sphere_ra = ra;
+  return FH_OK;
+}
+
 int fh_map_sync(fh_map* m) {
   if (!m) return FH_ERR_ARG;
   MapDeviceScope scope(m);
@@ -293,6 +302,7 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.cells = m->d_cells; pa.chunks = m->d_chunks; pa.serials = m->d_serials; pa.ticket = m->d_ticket;
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
   pa.jps_tables = m->d_jps_tables;
+  pa.sphere_ra = m->sphere_ra;
   FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
   pa.jps_entries = nullptr;
   if (m->search_mode == 1) {

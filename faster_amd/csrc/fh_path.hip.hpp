@@ -63,6 +63,7 @@ struct PlanArgs {
   // corridor post-processing (Faster::createMoreVertexes, faster.cpp:80-97; deleteVertexes, utils.cpp:1117-1124); 0 = off
   double max_vertex_dist;
   int max_poly;
+  double sphere_ra;       // > 0: the path is clipped to JPS_in first (Faster::replan, faster.cpp:370-382), see clip in plan_kernel
   const unsigned char* jps_tables;  // jump point search only: the neighbour tables, see Planner::init_jps
   const short* jps_entries;         // ... and the jump tables of this map [total][32], see jps_table_kernel
 };
@@ -85,6 +86,27 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   v = dpp_min_step<0x142, 0xa>(v);
   v = dpp_min_step<0x143, 0xc>(v);
   return __builtin_amdgcn_readlane(v, 63);
+}
+
+// getIntersectionWithSphere (faster/src/utils.cpp:713-776) with its arithmetic: single precision, except that pow(float, 2) is a
+// double (the squares are summed in double, rounded once) and `- r * r` is a double subtraction.  The same expressions as
+// fhfront::sphere_crossing (host/corridor_frontend.hpp).
+__device__ inline void sphere_crossing(const double a_in[3], const double b_in[3], double r, const double c[3], double out[3]) {
+  auto solve = [&](const double* A, const double* B, float& disc) {
+    const float x1 = (float)A[0], y1 = (float)A[1], z1 = (float)A[2], x2 = (float)B[0], y2 = (float)B[1], z2 = (float)B[2];
+    const float x3 = (float)c[0], y3 = (float)c[1], z3 = (float)c[2];
+    const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    const float a = (float)((double)dx * (double)dx + (double)dy * (double)dy + (double)dz * (double)dz);
+    const float b = 2.0f * (dx * (x1 - x3) + dy * (y1 - y3) + dz * (z1 - z3));
+    const float cf = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - 2.0f * (x3 * x1 + y3 * y1 + z3 * z1);
+    const float cc = (float)((double)cf - r * r);
+    disc = b * b - 4.0f * a * cc;
+    const float t = (-b + sqrtf(disc)) / (2.0f * a);
+    out[0] = (double)(x1 + dx * t); out[1] = (double)(y1 + dy * t); out[2] = (double)(z1 + dz * t);
+  };
+  float disc;
+  solve(a_in, b_in, disc);
+  if (disc <= 0) solve(c, a_in, disc);
 }
 
 struct Planner {
@@ -1137,11 +1159,36 @@ __global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
           put(p);
         };
         put(last);
-        double a[3] = {st[0], st[1], st[2]};  // start of the current leg: always the ORIGINAL vertex, as in createMoreVertexes
-        for (int i = 1; i < count; i++) {
-          double b[3];
-          if (i == count - 1) { b[0] = gl[0]; b[1] = gl[1]; b[2] = gl[2]; }
+        // JPS_in (faster.cpp:370-382): the path up to its first crossing of the sphere of radius min(|goal - start| - 0.001, Ra) around
+        // the start, the crossing point E appended (getFirstIntersectionWithSphere, utils.cpp:782-870)
+        auto vertex = [&](int i, double b[3]) {
+          if (i == 0) { b[0] = st[0]; b[1] = st[1]; b[2] = st[2]; }
+          else if (i == count - 1) { b[0] = gl[0]; b[1] = gl[1]; b[2] = gl[2]; }
           else pl.center(pl.va[i], b);
+        };
+        int n_in = count;
+        bool has_e = false;
+        double E[3] = {0, 0, 0};
+        if (pa.sphere_ra > 0.0) {
+          const double ra = fmin(Planner::dist(gl, st) - 0.001, pa.sphere_ra);
+          for (int i = 1; i < count; i++) {
+            double b[3];
+            vertex(i, b);
+            if (Planner::dist(b, st) > ra) {
+              double p[3];
+              vertex(i - 1, p);
+              sphere_crossing(p, b, ra, st, E);
+              n_in = i + 1;  // vertices 0 .. i-1, then E
+              has_e = true;
+              break;
+            }
+          }
+        }
+        double a[3] = {st[0], st[1], st[2]};  // start of the current leg: always the ORIGINAL vertex, as in createMoreVertexes
+        for (int i = 1; i < n_in; i++) {
+          double b[3];
+          if (has_e && i == n_in - 1) { b[0] = E[0]; b[1] = E[1]; b[2] = E[2]; }
+          else vertex(i, b);
           if (pa.max_vertex_dist > 0.0) {
             const double d = Planner::dist(b, a);
             if (d > pa.max_vertex_dist) {

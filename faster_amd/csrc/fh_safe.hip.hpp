@@ -28,17 +28,20 @@ __device__ __forceinline__ double dist3(P3 a, P3 b) {
   return sqrt(dx * dx + dy * dy + dz * dz);
 }
 
-// point where the segment a -> b leaves the sphere (centre c, radius r): single precision, like the reference (utils.cpp:713-776)
+// point where the segment a -> b leaves the sphere (centre c, radius r): the reference's arithmetic (utils.cpp:713-776; the same
+// expressions as fhfront::sphere_crossing, host/corridor_frontend.hpp)
 __device__ inline P3 sphere_crossing(P3 a_in, P3 b_in, double r, P3 c) {
   auto solve = [&](P3 A, P3 B, float& disc) {
     const float x1 = (float)A.x, y1 = (float)A.y, z1 = (float)A.z, x2 = (float)B.x, y2 = (float)B.y, z2 = (float)B.z;
     const float x3 = (float)c.x, y3 = (float)c.y, z3 = (float)c.z;
-    const float a = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
-    const float b = 2 * ((x2 - x1) * (x1 - x3) + (y2 - y1) * (y1 - y3) + (z2 - z1) * (z1 - z3));
-    const float cc = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - 2 * (x3 * x1 + y3 * y1 + z3 * z1) - (float)(r * r);
-    disc = b * b - 4 * a * cc;
-    const float t = (-b + sqrtf(disc)) / (2 * a);
-    return p3(x1 + (x2 - x1) * t, y1 + (y2 - y1) * t, z1 + (z2 - z1) * t);
+    const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    const float a = (float)((double)dx * (double)dx + (double)dy * (double)dy + (double)dz * (double)dz);  // pow(float, 2) is a double
+    const float b = 2.0f * (dx * (x1 - x3) + dy * (y1 - y3) + dz * (z1 - z3));
+    const float cf = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - 2.0f * (x3 * x1 + y3 * y1 + z3 * z1);
+    const float cc = (float)((double)cf - r * r);                                                            // `- r * r`: a double subtraction
+    disc = b * b - 4.0f * a * cc;
+    const float t = (-b + sqrtf(disc)) / (2.0f * a);
+    return p3((double)(x1 + dx * t), (double)(y1 + dy * t), (double)(z1 + dz * t));
   };
   float disc;
   const P3 first = solve(a_in, b_in, disc);

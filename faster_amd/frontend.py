@@ -25,6 +25,8 @@ def lib():
         L.ff_plan.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, vp, i32]
         L.ff_set_search_mode.restype = i32
         L.ff_set_search_mode.argtypes = [i32]
+        L.ff_set_sphere.restype = i32
+        L.ff_set_sphere.argtypes = [f64]
         L.ff_plan_jps.restype = i32
         L.ff_plan_jps.argtypes = [vp, i32, i32, i32, i32, f64, vp, f64, f64, f64, vp, vp, vp, i32, vp, vp]
         L.ff_jps_tables.restype = None
@@ -85,6 +87,12 @@ def set_search(mode):
     bit) or "jps" (jump point search in jps3d's own order: the path FASTER itself gets)."""
     if lib().ff_set_search_mode({"astar": 0, "jps": 1}[mode]) != 0:
         raise ValueError(mode)
+
+
+def set_sphere(ra):
+    """Clip every path of plan_batch / forest_batch(front="host") to JPS_in (Faster::replan, faster.cpp:370-382) before the vertex
+    refinement: sphere of radius min(|goal - start| - 0.001, ra) around the start; 0: off."""
+    lib().ff_set_sphere(float(ra))
 
 
 def jps_tables():
@@ -163,7 +171,7 @@ def forest_cloud(seed, size=(20.0, 20.0, 3.0), density=0.1, radius=0.3, spacing=
 
 
 def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation, starts, goals, max_poly, max_vertex_dist, faces_per_problem,
-                          drone_radius, z_ground=0.0, device=0, search="astar"):
+                          drone_radius, z_ground=0.0, device=0, search="astar", sphere_ra=0.0):
     """The corridor front-end on the device: fh_map_read + fh_map_plan_batch_device (path search, createMoreVertexes,
     deleteVertexes) + fh_corridor_batch_device (decomposition, rows in fh_problem's layout).  `ctx`: capi.Context, `vmap`: capi.Map.
     Returns host copies (faces [n][fpp][4], face_off [n][9], n_poly [n], goal [n][3]) and the device times in seconds."""
@@ -183,6 +191,7 @@ def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation
     d_npoly = torch.zeros(n, dtype=torch.int32, device=dev)
     d_goal = torch.zeros((n, 3), dtype=torch.float64, device=dev)
     vmap.set_search(search)
+    vmap.set_sphere(sphere_ra)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     vmap.read_device(d_cloud.data_ptr(), len(d_cloud), cells, res, center, z_ground, z_max, inflation)
@@ -203,7 +212,7 @@ def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation
 
 def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20.0, 3.0), res=0.2, inflation=0.3, drone_radius=0.05,
                  max_vertex_dist=1.5, faces_per_problem=abi.FH_MAX_FACES, min_goal_dist=6.0, front="host", ctx=None, vmap=None, device=0,
-                 search="astar", **kw):
+                 search="astar", sphere_ra=0.0, **kw):
     """BASELINE config 5: n start/goal pairs in one random forest; corridors from the voxel path search + ellipsoid
     decomposition: front="host" this CPU front-end (OpenMP), front="device" the same steps through the C ABI on the GPU
     (capi.Map + capi.Context; no CPU fallback).  search: "astar" (an optimal path, total order of its own) or "jps" (jump point search in
@@ -215,7 +224,7 @@ def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20
     if front == "device":
         faces, face_off, n_poly, goal_out, timing = corridor_batch_device(ctx, vmap, cloud, cells, res, center, size[2], inflation, starts, goals,
                                                                           max_poly, max_vertex_dist, faces_per_problem, drone_radius, device=device,
-                                                                          search=search)
+                                                                          search=search, sphere_ra=sphere_ra)
         overflow = 0
     else:
         faces = np.zeros((n, faces_per_problem, 4))
@@ -223,10 +232,12 @@ def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20
         n_poly = np.zeros(n, dtype=np.int32)
         goal_out = np.zeros((n, 3))
         set_search(search)
+        set_sphere(sphere_ra)
         overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
                                            inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
                                            faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
         set_search("astar")
+        set_sphere(0.0)
         timing = None
     ok = n_poly > 0
     counts = face_off[np.arange(n), n_poly]

@@ -371,12 +371,18 @@ void jps_neighbour_tables(int* ns, int* f1, int* f2) {  // [27][3][26], [27][3][
 // Which search the batch entry points below run: 0 (default) plan_path — A* with a total order, what the device search
 // (csrc/fh_path.hip.hpp) reproduces bit for bit; 1 plan_path_jps — jump point search in jps3d's own order, FASTER's exact path.
 static int g_search_mode = 0;
+static double g_sphere_ra = 0.0;  // ff_set_sphere: clip every path to JPS_in (Faster::replan, faster.cpp:370-382) before the vertex refinement
 static bool run_search(fhfront::VoxelGrid& g, const fhfront::V3& s, const fhfront::V3& t, double inflation, std::vector<fhfront::V3>& path,
                        long long* expansions = nullptr) {
   return g_search_mode == 1 ? fhfront::plan_path_jps(g, s, t, inflation, path, expansions) : fhfront::plan_path(g, s, t, inflation, path, expansions);
 }
 
 extern "C" {
+
+int ff_set_sphere(double ra) {
+  g_sphere_ra = ra > 0.0 ? ra : 0.0;
+  return 0;
+}
 
 int ff_set_search_mode(int mode) {
   if (mode != 0 && mode != 1) return -1;
@@ -511,6 +517,7 @@ int ff_plan_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cells_y
     n_points[i] = 0;
     if (!ok) continue;
     // the clean-up walks past max_points like the device: deleteVertexes may bring an over-long list back under the limit
+    fhfront::clip_to_sphere(path, g_sphere_ra);
     refine_vertices(path, max_vertex_dist, max_poly);
     if ((int)path.size() > max_points) { n_points[i] = -1; continue; }
     n_points[i] = (int)path.size();
@@ -546,6 +553,7 @@ int ff_corridor_batch(const double* cloud_xyz, int n_cloud, int cells_x, int cel
     const V3 s(starts[3 * i], starts[3 * i + 1], starts[3 * i + 2]), t(goals[3 * i], goals[3 * i + 1], goals[3 * i + 2]);
     goal_out[3 * i] = t.x; goal_out[3 * i + 1] = t.y; goal_out[3 * i + 2] = t.z;
     if (!run_search(g, s, t, inflation, path)) continue;
+    fhfront::clip_to_sphere(path, g_sphere_ra);
     refine_vertices(path, max_vertex_dist, max_poly);
     const std::vector<LinearConstraint> cs = decompose_path(path, cloud, drone_radius, z_ground);
     int total = 0;

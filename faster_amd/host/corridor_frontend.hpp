@@ -360,6 +360,43 @@ struct VoxelGrid {
   }
 };
 
+// Point where the segment a -> b leaves the sphere (centre c, radius r): getIntersectionWithSphere (faster/src/utils.cpp:713-776) with
+// its arithmetic — single precision, except where the language promotes: pow(float, 2) is a double (so the squares are summed in
+// double and rounded once) and `- r * r` is a double subtraction.  Tangent / no crossing: the ray centre -> a.
+inline V3 sphere_crossing(const V3& a_in, const V3& b_in, double r, const V3& c) {
+  auto solve = [&](const V3& A, const V3& B, float& disc) {
+    const float x1 = (float)A.x, y1 = (float)A.y, z1 = (float)A.z, x2 = (float)B.x, y2 = (float)B.y, z2 = (float)B.z;
+    const float x3 = (float)c.x, y3 = (float)c.y, z3 = (float)c.z;
+    const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    const float a = (float)((double)dx * (double)dx + (double)dy * (double)dy + (double)dz * (double)dz);
+    const float b = 2.0f * (dx * (x1 - x3) + dy * (y1 - y3) + dz * (z1 - z3));
+    const float cf = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - 2.0f * (x3 * x1 + y3 * y1 + z3 * z1);
+    const float cc = (float)((double)cf - r * r);
+    disc = b * b - 4.0f * a * cc;
+    const float t = (-b + std::sqrt(disc)) / (2.0f * a);
+    return V3((double)(x1 + dx * t), (double)(y1 + dy * t), (double)(z1 + dz * t));
+  };
+  float disc;
+  const V3 first = solve(a_in, b_in, disc);
+  if (disc <= 0) return solve(c, a_in, disc);
+  return first;
+}
+// JPS_in of Faster::replan (faster/src/faster.cpp:370-382): the path up to its first crossing of the sphere of radius
+// ra = min(|goal - start| - 0.001, Ra) around its first vertex (getFirstIntersectionWithSphere, utils.cpp:782-870), the crossing
+// point E appended; start and goal are the ends of the path (jps_manager.cpp:175-186 forces them there).  Ra <= 0: the path as it is.
+inline void clip_to_sphere(std::vector<V3>& path, double Ra) {
+  if (!(Ra > 0.0) || path.size() < 2) return;
+  const V3 center = path[0];
+  const double ra = std::min((path.back() - center).norm() - 0.001, Ra);
+  int index = -1;
+  for (size_t i = 0; i < path.size(); i++)
+    if ((path[i] - center).norm() > ra) { index = (int)i; break; }
+  if (index <= 0) return;  // nothing outside (or, impossibly, the first vertex): JPS_in is the whole path
+  const V3 E = sphere_crossing(path[index - 1], path[index], ra, center);
+  path.resize(index);
+  path.push_back(E);
+}
+
 // 26-connected A* with Euclidean step costs and heuristic (graph_search.cpp:73-75), then jps3d's path clean-up
 // (jps_planner.cpp:286-291).  Returns false if start/goal are not free or no path exists.
 bool plan_path(VoxelGrid& grid, const V3& start, const V3& goal, double inflation, std::vector<V3>& path,

@@ -69,22 +69,7 @@ inline V3 project_to_box(const V3& c, const V3& p, double wx, double wy, double 
   return out;
 }
 
-// point where the segment a->b leaves the sphere (centre c, radius r); single precision like the reference (utils.cpp:713-776)
-inline V3 sphere_crossing(const V3& a_in, const V3& b_in, double r, const V3& c) {
-  auto solve = [&](const V3& A, const V3& B) {
-    const float x1 = (float)A.x, y1 = (float)A.y, z1 = (float)A.z, x2 = (float)B.x, y2 = (float)B.y, z2 = (float)B.z;
-    const float x3 = (float)c.x, y3 = (float)c.y, z3 = (float)c.z;
-    const float a = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
-    const float b = 2 * ((x2 - x1) * (x1 - x3) + (y2 - y1) * (y1 - y3) + (z2 - z1) * (z1 - z3));
-    const float cc = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - 2 * (x3 * x1 + y3 * y1 + z3 * z1) - (float)(r * r);
-    const float disc = b * b - 4 * a * cc;
-    const float t = (-b + std::sqrt(disc)) / (2 * a);
-    return std::make_pair(disc, V3(x1 + (x2 - x1) * t, y1 + (y2 - y1) * t, z1 + (z2 - z1) * t));
-  };
-  auto first = solve(a_in, b_in);
-  if (first.first <= 0) return solve(c, a_in).second;  // tangent / no crossing: fall back to the ray centre -> a
-  return first.second;
-}
+using fhfront::sphere_crossing;  // getIntersectionWithSphere (utils.cpp:713-776): corridor_frontend.hpp
 
 // first point of `path` on the sphere around `center` (utils.cpp:782-870).  last_inside: index of the last vertex inside.
 inline V3 sphere_exit(const std::vector<V3>& path, double r, const V3& center, int* last_inside, bool* none_outside) {

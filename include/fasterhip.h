@@ -406,6 +406,10 @@ int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
  * for vertex to the reference's compiled sources.  Limits in mode 1: 60432 open entries, 4096 jump points on the path.
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
+/* JPS_in of Faster::replan (faster/src/faster.cpp:370-382): with ra > 0 every path of fh_map_plan_batch* is cut at its first crossing of
+ * the sphere of radius min(|goal - start| - 0.001, ra) around its start (getFirstIntersectionWithSphere, utils.cpp:782-870, with the
+ * reference's single-precision crossing), the crossing point E appended, BEFORE createMoreVertexes / deleteVertexes.  0 (default): off. */
+int fh_map_set_sphere(fh_map* map, double ra);
 int fh_map_sync(fh_map* map);
 int fh_map_read(fh_map* map, const double* cloud_xyz, int n_cloud, const int32_t cells[3], double res, const double center[3],
                 double z_ground, double z_max, double inflation);

@@ -114,18 +114,21 @@ def append_plans(whole, wres, safe, sres, r_frac=0.5, rule=None):
 
 # ---- the safe corridor decomposed around R (faster/src/faster.cpp:446-524): restatement of faster_amd/csrc/fh_safe.hip.hpp ----------
 def _sphere_crossing(a_in, b_in, r, c):
-    """Point where the segment a -> b leaves the sphere (centre c, radius r): single precision like the reference (utils.cpp:713-776)."""
+    """Point where the segment a -> b leaves the sphere (centre c, radius r): getIntersectionWithSphere (utils.cpp:713-776) with its
+    arithmetic — single precision except where the language promotes (pow(float, 2), `- r * r`)."""
     f = np.float32
     def solve(A, B):
         x1, y1, z1, x2, y2, z2 = f(A[0]), f(A[1]), f(A[2]), f(B[0]), f(B[1]), f(B[2])
         x3, y3, z3 = f(c[0]), f(c[1]), f(c[2])
-        a = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1)
-        b = f(2) * ((x2 - x1) * (x1 - x3) + (y2 - y1) * (y1 - y3) + (z2 - z1) * (z1 - z3))
-        cc = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - f(2) * (x3 * x1 + y3 * y1 + z3 * z1) - f(r * r)
+        dx, dy, dz = x2 - x1, y2 - y1, z2 - z1
+        a = f(float(dx) * float(dx) + float(dy) * float(dy) + float(dz) * float(dz))   # pow(float, 2) is a double: summed in double, rounded once
+        b = f(2) * (dx * (x1 - x3) + dy * (y1 - y3) + dz * (z1 - z3))
+        cf = x3 * x3 + y3 * y3 + z3 * z3 + x1 * x1 + y1 * y1 + z1 * z1 - f(2) * (x3 * x1 + y3 * y1 + z3 * z1)
+        cc = f(float(cf) - r * r)                                                       # `- r * r`: a double subtraction
         disc = b * b - f(4) * a * cc
         with np.errstate(invalid="ignore", divide="ignore"):
             t = (-b + np.sqrt(disc)) / (f(2) * a)
-            p = np.array([float(x1 + (x2 - x1) * t), float(y1 + (y2 - y1) * t), float(z1 + (z2 - z1) * t)])
+            p = np.array([float(x1 + dx * t), float(y1 + dy * t), float(z1 + dz * t)])
         return disc, p
     disc, p = solve(a_in, b_in)
     if disc <= 0:
@@ -145,6 +148,21 @@ def _sphere_exit(path, r, center):
     if index == 0:
         return path[0].copy(), 1, False
     return _sphere_crossing(path[index - 1], path[index], r, center), index - 1, False
+
+
+def clip_to_sphere(path, Ra):
+    """JPS_in of Faster::replan (faster.cpp:370-382): the path up to its first crossing of the sphere of radius min(|goal - start| - 0.001,
+    Ra) around its first vertex, the crossing point appended (goal, start: the ends of the path)."""
+    path = [np.array(v, dtype=np.float64) for v in path]
+    if not Ra > 0 or len(path) < 2:
+        return np.array(path)
+    ra = min(_norm3(path[-1] - path[0]) - 0.001, Ra)
+    for i, v in enumerate(path):
+        if _norm3(v - path[0]) > ra:
+            if i == 0:
+                break
+            return np.array(path[:i] + [_sphere_crossing(path[i - 1], path[i], ra, path[0])])
+    return np.array(path)
 
 
 def _shorten_by(path, d):

@@ -580,8 +580,9 @@ def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle, r_known):
     res, infl, zmax, drone_r, decomp_r = 0.2, 0.3, 3.0, 0.3, 0.05
     vmap = capi.Map(0)
     try:
-        pr, fc, info = frontend.forest_batch(n, 41, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, search="jps")
+        pr, fc, info = frontend.forest_batch(n, 41, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, search="jps", sphere_ra=4.0)
         cloud, cells, center, starts, goals = frontend.forest_queries(n, 41)
+        vmap.set_sphere(4.0)   # JPS_in: the path inside the sphere Ra (faster.cpp:370-382), as for the whole corridor above
         paths, npts, _ = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=1.5, max_poly=max_poly)
         dims, origin = vmap.dims()
     finally:
@@ -662,3 +663,30 @@ def test_safe_corridor_decomposed_around_r_on_the_device(ctx, oracle, r_known):
     sres = d_sr.cpu().numpy().view(abi.result_dtype)
     compare(sres[:32], oracle.solve_batch(sp[:32], sfaces.reshape(-1)))
     assert (sres["solved"] == 1).mean() > 0.8, ((sres["solved"] == 1).mean(), np.unique(sres["status"], return_counts=True), sp[0], sres[0]["trials"])
+
+
+def test_device_paths_clipped_to_the_sphere_equal_host(host_jps):
+    """fh_map_set_sphere: JPS_in of Faster::replan (the path cut at the sphere of radius min(|goal - start| - 0.001, Ra) around the
+    start, crossing point appended, then createMoreVertexes / deleteVertexes) on the device == the host front-end bit for bit."""
+    frontend = host_jps
+    cloud, cells, center, starts, goals = frontend.forest_queries(2048, 10)
+    res, zmax, infl, Ra = 0.2, 3.0, 0.3, 4.0
+    m = capi.Map(0)
+    try:
+        m.read(cloud, cells, res, center, 0.0, zmax, infl)
+        m.set_search("jps")
+        m.set_sphere(Ra)
+        frontend.set_sphere(Ra)
+        for kw in (dict(max_points=64), dict(max_points=4, max_vertex_dist=1.5, max_poly=3)):
+            host = frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, **kw)
+            dev = m.plan_batch(starts, goals, **kw)
+            _plans_equal(host, dev, str(kw))
+            ends = np.array([host[0][i, host[1][i] - 1] for i in np.nonzero(host[1] > 0)[0]])
+            first = np.array([host[0][i, 0] for i in np.nonzero(host[1] > 0)[0]])
+            assert (np.linalg.norm(ends - first, axis=1) <= Ra + 1.5 + 1e-6).all()
+        m.set_sphere(0.0)
+        frontend.set_sphere(0.0)
+        _plans_equal(frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals), m.plan_batch(starts, goals), "off again")
+    finally:
+        frontend.set_sphere(0.0)
+        m.close()

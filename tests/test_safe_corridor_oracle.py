@@ -61,3 +61,32 @@ def test_unknown_voxels_bound_the_corridor():
     for q in unk[::7]:
         assert np.any(Ab @ q - bb > -1e-9)   # every unknown voxel is outside (or on) the polytope
     assert np.all(Ab @ path[0] - bb < 0) and np.all(Ab @ path[1] - bb < 0)
+
+
+def test_host_paths_clipped_to_the_sphere_equal_the_restatement():
+    """ff_set_sphere (JPS_in of Faster::replan, faster.cpp:370-382) in the C++ front-end against oracle/pair_glue.clip_to_sphere applied
+    to the unclipped paths: the same vertices bit for bit (the crossing point in the reference's mixed single/double arithmetic), and
+    every clipped path ends on the sphere of radius min(|goal - start| - 0.001, Ra)."""
+    cloud, cells, center, starts, goals = frontend.forest_queries(192, 9)
+    res, zmax, infl, Ra = 0.2, 3.0, 0.3, 4.0
+    frontend.set_search("jps")
+    try:
+        plain = frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, max_points=64)
+        frontend.set_sphere(Ra)
+        clipped = frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, max_points=64)
+    finally:
+        frontend.set_sphere(0.0)
+        frontend.set_search("astar")
+    n_cut = 0
+    for i in range(len(starts)):
+        if plain[1][i] <= 0:
+            assert clipped[1][i] == plain[1][i]
+            continue
+        want = pair_glue.clip_to_sphere(plain[0][i, :plain[1][i]], Ra)
+        got = clipped[0][i, :clipped[1][i]]
+        assert got.shape == want.shape and np.array_equal(got, want), i
+        if len(want) != plain[1][i] or not np.array_equal(want[-1], plain[0][i, plain[1][i] - 1]):
+            n_cut += 1
+            ra = min(np.linalg.norm(plain[0][i, plain[1][i] - 1] - plain[0][i, 0]) - 0.001, Ra)
+            assert abs(np.linalg.norm(got[-1] - got[0]) - ra) < 1e-4   # (the crossing point is a single-precision result)
+    assert n_cut > 100
