@@ -535,85 +535,106 @@ def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batch
 
 def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
     """One Faster::replan per pair with FASTER's own parameters (faster.yaml: N_whole = N_safe = 6, max_poly_whole = max_poly_safe = 3,
-    dist_max_vertexes 1.5 m, Ra 4 m, delta_H 1, delta_a 0.5) and its own steps, all on the device and outside the C4 timed region:
-    map + jump point search + corridor of the whole path (front-end), whole solve, the safe corridor decomposed around R against unknown +
-    occupied space (fh_safe_corridor_batch_device; unknown space modelled: farther than Ra from the start), safe solve, appendToPlan.
-    Median of `reps` fenced passes per stage."""
+    dist_max_vertexes 1.5 m, Ra 4 m, delta_H 1, delta_a 0.5) and its own steps, device-resident from the point cloud and the
+    start/goal pairs to the committed plans, outside the C4 timed region: map, jump point search, JPS_in (the path inside the sphere Ra),
+    createMoreVertexes / deleteVertexes, whole corridor, problem records (E = G or the last vertex), whole solve, the safe corridor
+    decomposed around R against unknown + occupied space (unknown space modelled: farther than Ra from the start), safe solve,
+    appendToPlan.  Median of `reps` fenced passes per stage."""
     import numpy as np
 
     from faster_amd import abi, capi, corridor, frontend
 
     N, max_poly, r_known, drone_r, decomp_r, fpp, max_states = 6, 3, 4.0, 0.3, 0.05, 96, 512
-    ctx, vmap = capi.Context(local_rank), capi.Map(local_rank)
-    try:
-        frontend.forest_batch(256, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank, search="jps",
-                              sphere_ra=r_known)
-        pr, fc, info = frontend.forest_batch(pairs, seed=7, n_seg=N, max_poly=max_poly, front="device", ctx=ctx, vmap=vmap, device=local_rank,
-                                             search="jps", sphere_ra=r_known)   # the whole corridor around JPS_in (the path inside the sphere Ra)
-        cloud, cells, center, starts, goals = frontend.forest_queries(pairs, 7)
-        vmap.set_sphere(r_known)
-        paths, npts, _ = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=1.5, max_poly=max_poly)  # JPS_in per pair
-        dims, origin = vmap.dims()
-    finally:
-        vmap.close()
-    kept = info["kept"]
-    paths, npts, goals = paths[kept], npts[kept].astype(np.int32), goals[kept]
-    B = len(pr)
-    mf = int(pr["face_off"][np.arange(B), pr["n_poly"]].max())
+    res, infl, zmax = 0.2, 0.3, 3.0
+    cloud, cells, center, starts, goals, rng = frontend.forest_queries(pairs, 7, return_rng=True)
+    B = pairs
+    whole = abi.make_problems(B)
+    whole["n_seg"], whole["force_final_pos"], whole["dc"] = N, 1, 0.01
+    whole["v_max"], whole["a_max"], whole["j_max"] = 5.0, 5.0, 8.0
+    whole["f_init"], whole["f_final"], whole["f_inc"] = 1.0, 10.0, 1.0
+    u = goals - starts
+    u /= np.maximum(np.linalg.norm(u, axis=1, keepdims=True), 1e-9)
+    whole["x0"][:, 0:3] = starts
+    whole["x0"][:, 3:6] = u * rng.uniform(0, 1.5, size=(B, 1))
+    tmpl = corridor.safe_templates(whole)
+    tmpl["n_seg"] = N
 
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
-    tmpl = corridor.safe_templates(pr)
-    tmpl["n_seg"] = N
-    d_pr, d_fc, d_tmpl = to_dev(pr), to_dev(fc), to_dev(tmpl)
-    d_paths, d_np, d_goals, d_cloud = to_dev(paths), to_dev(npts), to_dev(goals), to_dev(cloud)
+    ctx, vmap = capi.Context(local_rank), capi.Map(local_rank)
+    mp = max_poly + 1
+    d_cloud, d_starts, d_goals = to_dev(cloud), to_dev(starts), to_dev(goals)
+    d_whole_t, d_tmpl = to_dev(whole), to_dev(tmpl)
+    d_whole, d_safe = torch.zeros_like(d_whole_t), torch.zeros_like(d_tmpl)
+    f64, i32 = torch.float64, torch.int32
+    d_paths, d_np, d_ex = torch.zeros((B, mp, 3), dtype=f64, device=dev), torch.zeros(B, dtype=i32, device=dev), torch.zeros(B, dtype=torch.int64, device=dev)
+    FB = abi.face_dtype.itemsize
+    d_wf, d_sf = torch.zeros(B * fpp * FB, dtype=torch.uint8, device=dev), torch.zeros(B * fpp * FB, dtype=torch.uint8, device=dev)
+    d_off, d_npoly, d_last = torch.zeros((B, 9), dtype=i32, device=dev), torch.zeros(B, dtype=i32, device=dev), torch.zeros((B, 3), dtype=f64, device=dev)
     RES = abi.result_dtype.itemsize
     d_wr, d_sr = torch.zeros(B * RES, dtype=torch.uint8, device=dev), torch.zeros(B * RES, dtype=torch.uint8, device=dev)
-    d_safe = torch.zeros_like(d_tmpl)
-    d_sf = torch.zeros(B * fpp * abi.face_dtype.itemsize, dtype=torch.uint8, device=dev)
     d_plans = torch.zeros(B * max_states * abi.state_dtype.itemsize, dtype=torch.uint8, device=dev)
-    d_counts, d_k = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    d_counts, d_k = torch.zeros(B, dtype=i32, device=dev), torch.zeros(B, dtype=i32, device=dev)
     ctx.set_params(par)
     ctx.set_pair_rule(mode=1, r_known=r_known, drone_radius=drone_r, delta_h=1.0, delta_a=0.5)
-    stages = {"whole_solve": [], "safe_corridor": [], "safe_solve": [], "append_plans": []}
+    vmap.set_search("jps")
+    vmap.set_sphere(r_known)
+    stages = {"map": [], "path_search": [], "whole_corridor": [], "whole_solve": [], "safe_corridor": [], "safe_solve": [], "append_plans": []}
 
-    def timed(name, fn):
+    def timed(name, fn, sync):
         torch.cuda.synchronize()
         t = time.perf_counter()
         fn()
-        ctx.sync()
+        sync()
         stages[name].append(1e3 * (time.perf_counter() - t))
 
-    for _ in range(reps + 1):
-        d_safe.copy_(d_tmpl)
-        timed("whole_solve", lambda: ctx.solve_batch_device(d_pr.data_ptr(), d_fc.data_ptr(), B, N, mf, d_wr.data_ptr()))
-        timed("safe_corridor", lambda: ctx.safe_corridor_batch_device(d_pr.data_ptr(), d_wr.data_ptr(), d_paths.data_ptr(), d_np.data_ptr(), max_poly + 1,
-                                                                      d_goals.data_ptr(), d_cloud.data_ptr(), len(cloud), origin, 0.2, dims, B, 0.5,
-                                                                      max_poly, (2.0, 2.0, 1.0), decomp_r, 0.0, fpp, N, d_safe.data_ptr(),
-                                                                      d_sf.data_ptr()))
-        timed("safe_solve", lambda: ctx.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, fpp, d_sr.data_ptr()))
-        timed("append_plans", lambda: ctx.append_plans_device(d_pr.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states,
-                                                              d_plans.data_ptr(), d_counts.data_ptr(), d_k.data_ptr()))
-    wres, sres = d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype)
-    safe = d_safe.cpu().numpy().view(abi.problem_dtype)
-    counts = d_counts.cpu().numpy()
-    ctx.close()
+    dims = origin = None
+    try:
+        for _ in range(reps + 1):
+            d_whole.copy_(d_whole_t)
+            d_safe.copy_(d_tmpl)
+            timed("map", lambda: vmap.read_device(d_cloud.data_ptr(), len(cloud), cells, res, center, 0.0, zmax, infl), vmap.sync)
+            timed("path_search", lambda: vmap.plan_batch_device(d_starts.data_ptr(), d_goals.data_ptr(), B, mp, d_paths.data_ptr(), d_np.data_ptr(),
+                                                                d_ex.data_ptr(), 1.5, max_poly), vmap.sync)
+            if dims is None:
+                dims, origin = vmap.dims()
+
+            def corridor_stage():
+                ctx.corridor_batch_device(d_cloud.data_ptr(), len(cloud), d_paths.data_ptr(), d_np.data_ptr(), B, mp, max_poly, fpp, d_wf.data_ptr(),
+                                          d_off.data_ptr(), d_npoly.data_ptr(), d_last.data_ptr(), decomp_r, 0.0)
+                ctx.corridor_problems_device(d_np.data_ptr(), d_last.data_ptr(), d_goals.data_ptr(), d_wf.data_ptr(), d_off.data_ptr(), d_npoly.data_ptr(),
+                                             B, fpp, N, d_whole.data_ptr())
+            timed("whole_corridor", corridor_stage, ctx.sync)
+            timed("whole_solve", lambda: ctx.solve_batch_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, d_wr.data_ptr()), ctx.sync)
+            timed("safe_corridor", lambda: ctx.safe_corridor_batch_device(d_whole.data_ptr(), d_wr.data_ptr(), d_paths.data_ptr(), d_np.data_ptr(), mp,
+                                                                          d_goals.data_ptr(), d_cloud.data_ptr(), len(cloud), origin, res, dims, B, 0.5,
+                                                                          max_poly, (2.0, 2.0, 1.0), decomp_r, 0.0, fpp, N, d_safe.data_ptr(),
+                                                                          d_sf.data_ptr()), ctx.sync)
+            timed("safe_solve", lambda: ctx.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, fpp, d_sr.data_ptr()), ctx.sync)
+            timed("append_plans", lambda: ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5,
+                                                                  max_states, d_plans.data_ptr(), d_counts.data_ptr(), d_k.data_ptr()), ctx.sync)
+        wres, sres = d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype)
+        wprob, safe = d_whole.cpu().numpy().view(abi.problem_dtype), d_safe.cpu().numpy().view(abi.problem_dtype)
+        counts = d_counts.cpu().numpy()
+        pops = int(d_ex.sum().item())
+    finally:
+        vmap.close()
+        ctx.close()
     med = {k: float(np.median(v[1:])) for k, v in stages.items()}
-    ft = info["front_timing"]
-    front_ms = 1e3 * (ft["map_s"] + ft["path_search_s"] + ft["decomposition_s"])
-    total_ms = front_ms + sum(med.values())
+    total_ms = sum(med.values())
+    have = wprob["n_seg"] > 0
     need = safe["n_seg"] > 0
-    return {"workload": "one Faster::replan per pair, FASTER's own parameters (N 6, max_poly 3, Ra 4 m): %d start/goal pairs in a random forest, "
-                        "%d with a path; device-resident, one stage at a time" % (pairs, B),
-            "stages_ms": {"front_end (map, jump point search, whole corridor)": front_ms, **med},
-            "replans_per_s": B / (total_ms * 1e-3), "total_ms": total_ms,
-            "whole_solved_frac": float(wres["solved"].mean()), "pairs_needing_a_safe_trajectory": int(need.sum()),
+    return {"workload": "one Faster::replan per pair, FASTER's own parameters (N 6, max_poly 3, Ra 4 m): %d start/goal pairs in a random forest "
+                        "(20x20x3 m, 0.1 trees/m^2), %d with a path; device-resident from the cloud and the queries to the committed plans, one "
+                        "stage at a time" % (pairs, int(have.sum())),
+            "stages_ms": med, "replans_per_s": B / (total_ms * 1e-3), "total_ms": total_ms, "heap_pops_of_the_path_search": pops,
+            "whole_solved_frac": float(wres["solved"][have].mean()), "pairs_needing_a_safe_trajectory": int(need.sum()),
             "safe_solved_frac": float(sres["solved"][need].mean()) if need.any() else None,
             "plans_committed_frac": float((counts > 0).mean()), "mean_plan_states": float(counts[counts > 0].mean()) if (counts > 0).any() else 0.0,
             "note": "unknown space is MODELLED (a batch has no mapper): everything farther than Ra from the start — distance queries use "
-                    "Ra - |p - A|, the decomposition sees the voxels of the map's grid out there; the problem records of the whole solve are "
-                    "assembled on the host between front-end and solver (not timed), JPS_in is read from a second, untimed search call"}
+                    "Ra - |p - A|, the decomposition sees the voxels of the map's grid out there; path_search includes building the jump tables "
+                    "of the map; whole_corridor includes fh_corridor_problems_device (E = G or the last vertex)"}
 
 
 def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):

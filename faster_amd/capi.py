@@ -16,7 +16,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
     "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule",
-    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_solve_pairs_device",
+    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_corridor_problems_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
@@ -121,6 +121,8 @@ def lib():
         L.fh_sample_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp]
         L.fh_pair_glue_device.restype = i32
         L.fh_pair_glue_device.argtypes = [vp, vp, vp, vp, i32, f64, f64, i32, vp, vp]
+        L.fh_corridor_problems_device.restype = i32
+        L.fh_corridor_problems_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
         L.fh_safe_corridor_batch_device.restype = i32
         L.fh_safe_corridor_batch_device.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, f64, i32, vp, f64, f64, i32, i32, vp, vp, vp, vp]
         L.fh_append_plans_device.restype = i32
@@ -493,6 +495,11 @@ class Context:
                            d_safe_faces, d_safe_results):
         self._check(lib().fh_solve_pairs_device(self._h, d_whole, d_faces, n, max_seg, max_faces, r_frac, shrink, max_safe_poly,
                                                 d_whole_results, d_safe, d_safe_faces, d_safe_results), "fh_solve_pairs_device")
+
+    def corridor_problems_device(self, d_n_points, d_last_vertex, d_goals, d_faces, d_face_off, d_n_poly, n, faces_per_problem, n_seg, d_problems):
+        """fh_corridor_problems_device: polytope table and xf of every problem record from fh_corridor_batch_device's outputs."""
+        self._check(lib().fh_corridor_problems_device(self._h, d_n_points, d_last_vertex, d_goals, d_faces, d_face_off, d_n_poly, n, faces_per_problem,
+                                                      n_seg, d_problems), "fh_corridor_problems_device")
 
     def safe_corridor_batch_device(self, d_whole, d_whole_results, d_paths, d_n_points, max_points, d_goals, d_cloud, n_cloud, grid_origin, grid_res,
                                    grid_dims, n, r_frac, max_poly_safe, local_bbox, drone_radius, z_ground, faces_per_problem, n_seg_safe, d_safe,

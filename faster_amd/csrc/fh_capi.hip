@@ -922,6 +922,22 @@ int fh_corridor_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud
   return FH_OK;
 }
 
+// Problem records from corridors (fh_corridor_batch_device's outputs): the polytope table and xf of record i — see include/fasterhip.h.
+int fh_corridor_problems_device(fh_ctx* ctx, const int32_t* d_n_points, const double* d_last_vertex, const double* d_goals, const fh_face* d_faces,
+                                const int32_t* d_face_off, const int32_t* d_n_poly, int n, int faces_per_problem, int n_seg,
+                                fh_problem* d_problems) {
+  if (!ctx || n < 0 || faces_per_problem < 8 || n_seg < 1 || n_seg > FH_MAX_SEG) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_n_points || !d_last_vertex || !d_goals || !d_faces || !d_face_off || !d_n_poly || !d_problems) return FH_ERR_ARG;
+  if ((size_t)n * (size_t)faces_per_problem > (size_t)0x7fffffff) return FH_ERR_ARG;
+  hipLaunchKernelGGL(fh::safe_finalize_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_n_points, d_last_vertex, d_goals, d_faces, d_face_off,
+                     d_n_poly, n, faces_per_problem, n_seg, d_problems);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
 // The safe corridor of Faster::replan (faster.cpp:446-524) for a batch of pairs: see fh_safe.hip.hpp and include/fasterhip.h.
 int fh_safe_corridor_batch_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const double* d_paths,
                                   const int32_t* d_n_points, int max_points, const double* d_goals, const double* d_cloud_xyz, int n_cloud,

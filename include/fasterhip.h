@@ -307,6 +307,15 @@ int fh_corridor_batch_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud
                              int max_points, int max_poly, const double local_bbox[3], double drone_radius, double z_ground,
                              int faces_per_problem, fh_face* d_faces, int32_t* d_face_off, int32_t* d_n_poly, double* d_goal);
 
+/* Problem records from corridors, on the device: the step between fh_corridor_batch_device and a solve (faster.cpp:393-404 for the whole
+ * trajectory).  For every pair with a corridor (d_n_points[i] >= 2, d_n_poly[i] >= 1) record i gets its polytope table (n_poly, face_off,
+ * face_begin = i * faces_per_problem), n_seg, and xf = the goal d_goals[i] when it lies in the LAST polytope, else the last vertex of the
+ * path d_last_vertex[i] (E.pos, :399-400); everything else (x0, bounds, dc, factor window, force_final_pos) is left as the caller
+ * prepared it.  Pairs without a corridor get n_seg = 0 (their results report FH_ST_BAD_INPUT).  Device pointers, asynchronous. */
+int fh_corridor_problems_device(fh_ctx* ctx, const int32_t* d_n_points, const double* d_last_vertex, const double* d_goals, const fh_face* d_faces,
+                                const int32_t* d_face_off, const int32_t* d_n_poly, int n, int faces_per_problem, int n_seg,
+                                fh_problem* d_problems);
+
 /* The SAFE corridor of Faster::replan, decomposed around R (faster/src/faster.cpp:446-524), for a batch of pairs whose whole
  * trajectories are solved — the faithful alternative to the hand-off of fh_pair_glue_device / fh_solve_pairs_device, which reuses
  * polytopes of the whole corridor.  Per pair:

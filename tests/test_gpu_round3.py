@@ -690,3 +690,55 @@ def test_device_paths_clipped_to_the_sphere_equal_host(host_jps):
     finally:
         frontend.set_sphere(0.0)
         m.close()
+
+
+def test_problem_records_from_corridors_on_the_device(ctx):
+    """fh_corridor_problems_device (faster.cpp:393-404): polytope table of every pair's record and xf = G when G lies in the last polytope
+    of the whole corridor, else the last vertex of the path; pairs without a path get n_seg = 0; the caller's fields are left alone."""
+    import torch
+
+    from faster_amd import frontend
+
+    n, N, max_poly, fpp = 512, 6, 3, 96
+    cloud, cells, center, starts, goals = frontend.forest_queries(n, 12)
+    goals[:64] = starts[:64] + np.array([0.6, 0.4, 0.0])      # goals close by: inside the last (only) polytope
+    starts[64] = [-40.0, 3.0, 1.0]                             # outside the map: no path
+    vmap = capi.Map(0)
+    try:
+        vmap.read(cloud, cells, 0.2, center, 0.0, 3.0, 0.3)
+        vmap.set_search("jps")
+        vmap.set_sphere(4.0)
+        paths, npts, _ = vmap.plan_batch(starts, goals, max_points=max_poly + 1, max_vertex_dist=1.5, max_poly=max_poly)
+    finally:
+        vmap.close()
+    tmpl = abi.make_problems(n)
+    tmpl["n_seg"], tmpl["dc"], tmpl["v_max"], tmpl["f_init"] = 99, 0.01, 5.0, 2.0
+    tmpl["x0"][:, :3] = starts
+    d_paths, d_np, d_goals, d_cloud, d_pr = _dev(paths), _dev(npts.astype(np.int32)), _dev(goals), _dev(cloud), _dev(tmpl)
+    d_f = torch.zeros(n * fpp * abi.face_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_off = torch.zeros((n, 9), dtype=torch.int32, device="cuda:0")
+    d_npoly = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    d_last = torch.zeros((n, 3), dtype=torch.float64, device="cuda:0")
+    ctx.corridor_batch_device(d_cloud.data_ptr(), len(cloud), d_paths.data_ptr(), d_np.data_ptr(), n, max_poly + 1, max_poly, fpp, d_f.data_ptr(),
+                              d_off.data_ptr(), d_npoly.data_ptr(), d_last.data_ptr())
+    ctx.corridor_problems_device(d_np.data_ptr(), d_last.data_ptr(), d_goals.data_ptr(), d_f.data_ptr(), d_off.data_ptr(), d_npoly.data_ptr(), n, fpp, N,
+                                 d_pr.data_ptr())
+    ctx.sync()
+    pr = d_pr.cpu().numpy().view(abi.problem_dtype)
+    faces = d_f.cpu().numpy().view(abi.face_dtype).reshape(n, fpp)
+    off, npoly, last = d_off.cpu().numpy(), d_npoly.cpu().numpy(), d_last.cpu().numpy()
+    assert pr["n_seg"][64] == 0 and npts[64] == 0
+    inside_count = 0
+    for i in range(n):
+        if npts[i] < 2 or npoly[i] < 1:
+            assert pr["n_seg"][i] == 0
+            continue
+        assert pr["n_seg"][i] == N and pr["n_poly"][i] == npoly[i] and pr["face_begin"][i] == i * fpp
+        assert np.array_equal(pr["face_off"][i], off[i])
+        P = npoly[i]
+        A, b = faces["a"][i, off[i, P - 1]:off[i, P]], faces["b"][i, off[i, P - 1]:off[i, P]]
+        inside = not np.any(A[:, 0] * goals[i, 0] + A[:, 1] * goals[i, 1] + A[:, 2] * goals[i, 2] - b > 0)
+        inside_count += inside
+        assert np.array_equal(pr["xf"][i, :3], goals[i] if inside else last[i]), i
+        assert np.array_equal(pr["x0"][i], tmpl["x0"][i]) and pr["dc"][i] == 0.01 and pr["f_init"][i] == 2.0
+    assert inside_count >= 32 and inside_count < n
