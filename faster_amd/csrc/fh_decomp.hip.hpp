@@ -240,7 +240,8 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
     } else too_many = true;
     rows++;
   };
-  for (int guard = 0; guard <= cnt; guard++) {
+  const int cnt_planes = cnt;  // (every plane puts at least the point it passes through away)
+  for (int guard = 0; guard <= cnt_planes; guard++) {
     const int ic = closest_in(px, py, pz, flag, cnt, 4, Rf, axes, c, lane);
     if (ic < 0) break;
     const D3 cp = d3(px[ic], py[ic], pz[ic]);
@@ -250,9 +251,28 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
     if (!(gn > 0) || !isfinite(gn)) break;  // degenerate ellipsoid: no separating planes (as the host version)
     const D3 n = d3(g.x / gn, g.y / gn, g.z / gn);
     emit(cp, n);
-    for (int i = lane; i < cnt; i += 64)
-      if ((flag[i] & 4) && !(dot(n, d3(px[i], py[i], pz[i]) - cp) < 0)) flag[i] &= (unsigned char)~4;
-    __syncthreads();
+    // the points the plane puts away are never looked at again: the list is compacted in place (order kept — the tie rule of
+    // closest_in is the lowest index), so that the scans of the following planes get shorter
+    int alive = 0;
+    for (int i0 = 0; i0 < cnt; i0 += 64) {
+      const int i = i0 + lane;
+      bool stay = false;
+      D3 q = d3(0, 0, 0);
+      unsigned char f = 0;
+      if (i < cnt) {
+        f = flag[i];
+        q = d3(px[i], py[i], pz[i]);
+        stay = (f & 4) && (dot(n, q - cp) < 0);
+      }
+      const unsigned long long m = __ballot(stay);
+      if (stay) {
+        const int pos = alive + __popcll(m & ((1ull << lane) - 1ull));
+        px[pos] = q.x; py[pos] = q.y; pz[pos] = q.z; flag[pos] = f;
+      }
+      alive += __popcll(m);
+      __syncthreads();
+    }
+    cnt = alive;
   }
 #pragma unroll
   for (int k = 0; k < 6; k++) emit(bp[k], bn[k]);
