@@ -129,7 +129,8 @@ __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat,
   g.y0 = first(lo[1], lat.oy, lat.res, lat.ny); g.cy = last(hi[1], lat.oy, lat.res, lat.ny) - g.y0 + 1;
   g.z0 = first(lo[2], lat.oz, lat.res, lat.nz); g.cz = last(hi[2], lat.oz, lat.res, lat.nz) - g.z0 + 1;
   if (g.cx <= 0 || g.cy <= 0 || g.cz <= 0) return g;
-  g.total = g.cx * g.cy * g.cz;
+  const long long cells = (long long)g.cx * g.cy * g.cz;
+  g.total = cells > (1ll << 28) ? -1 : (int)cells;  // -1: a grid far too fine for the local box — the segment reports failure (count -1)
   g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3];
   return g;
 }
@@ -348,6 +349,10 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
       hi[0] = fmax(hi[0], e.x); hi[1] = fmax(hi[1], e.y); hi[2] = fmax(hi[2], e.z);
     }
     const LatticeRange lrange = lattice_range(lat, lo, hi, spheres ? spheres + 4 * (size_t)seg : nullptr);
+    if (lrange.total < 0) {
+      if (lane == 0) counts[seg] = -1;
+      continue;
+    }
     if (blocks) {
       const int n_blocks = (n_cloud + 63) / 64;
       nb = 0;

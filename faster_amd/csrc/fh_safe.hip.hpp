@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
                                                        int max_points, double r_frac, fh_pair_rule rule, int max_poly_safe,
                                                        fh_problem* __restrict__ safe, double* __restrict__ safe_paths,
                                                        int32_t* __restrict__ safe_np, double* __restrict__ spheres) {
+  __shared__ P3 s_orig[SAFE_PATH_CAP + 2], s_cur[SAFE_PATH_CAP + 2];  // (LDS, not per-lane arrays: those would be 2 KB of scratch per lane)
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n) return;
   const fh_problem& pw = whole[b];
@@ -123,7 +124,8 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
       }
       if (lane == 0) {  // a handful of vertices: one lane walks them
         const P3 A = p3(pw.x0[0], pw.x0[1], pw.x0[2]);
-        P3 orig[SAFE_PATH_CAP + 2], cur[SAFE_PATH_CAP + 2];
+        P3* orig = s_orig;
+        P3* cur = s_cur;
         int no = np_in, nc = np_in;
         for (int i = 0; i < np_in; i++) {
           const double* v = paths + 3 * ((size_t)b * max_points + i);
