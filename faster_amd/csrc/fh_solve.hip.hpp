@@ -322,7 +322,7 @@ struct Solver {
                                                       //           ~1e-9, so a float's relative 6e-8 is 1e-16 absolute)
   fh_face* faces;                                     // [n_faces] NORMALISED rows: a/|a| and bt = -(b + feas_tol)/|a|, so that
                                                       //           a.cp + bt > 0  <=>  the original row is violated by more than feas_tol
-  int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *face_off;
+  int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *stk_keep, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
          TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_WORDS = 18 };  // TB_WORK: active-set iterations of the unit in hand (reported with `done`);
@@ -333,7 +333,7 @@ struct Solver {
     // (the hardware hands out LDS in granules of 1280 B — measured with a residency census: 14 080 B admit 11 workgroups per CU,
     // 14 336 B only 10 — so every few hundred bytes of this carve decide a wavefront per CU)
     return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 2 * NVP + NXP + NSEG * ZS + 3 * NT * 3 + 12) +
-           sizeof(int) * (8 * NSEG + FH_MAX_POLY + 1 + TB_WORDS) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
+           sizeof(int) * (9 * NSEG + FH_MAX_POLY + 1 + TB_WORDS) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
            (sizeof(fh_face) + sizeof(float)) * max_faces + 16;
   }
 
@@ -391,7 +391,7 @@ struct Solver {
     xfl = p; p += 12;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
-    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_q = ip; ip += NSEG;  stk_mask = ip; ip += NSEG;
+    stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_q = ip; ip += NSEG;  stk_mask = ip; ip += NSEG;  stk_keep = ip; ip += NSEG;
     face_off = ip; ip += FH_MAX_POLY + 1;
     tb = ip; ip += TB_WORDS;
     stk_order = reinterpret_cast<signed char*>(ip);
@@ -432,16 +432,22 @@ struct Solver {
       }
     }
   }
-  __device__ void snapshot_save(double* __restrict__ ws_level) {
+  // stk_keep[level]: the columns of Q and R below this index have not changed in LDS since the snapshot of the level was taken (rows are
+  // appended on the right; only dropping row k rewrites the columns from k on, drop_row), so a restore fetches the others only
+  __device__ void snapshot_save(double* __restrict__ ws_level, int level) {
     const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     FH_SYNC();
     copy_out(ws_level, x, SNAP_TAIL);
     copy_out(ws_level + SNAP_QOFF, Q, q * S);
     copy_out(ws_level + SNAP_ROFF, R, (q * (q + 1)) / 2);
+    if (lane == 0) stk_keep[level] = q;
   }
   // q_saved: number of active rows in the snapshot; the current q may be larger (columns to clear) or smaller
-  __device__ void snapshot_restore(const double* __restrict__ ws_level, int q_saved) {
+  __device__ void snapshot_restore(const double* __restrict__ ws_level, int q_saved, int level) {
     const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
+    int keep = uniform_i32(stk_keep[level]);
+    keep = keep < 0 ? 0 : (keep > q_saved ? q_saved : keep);
+    keep &= ~1;  // (the copies move 16 bytes per lane: an even number of doubles from an even offset; S is odd)
     // the workspace was written by this same wavefront (snapshot_save of an ancestor node): drain its outstanding stores
     // before reading them back
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -449,9 +455,10 @@ struct Solver {
       for (int c = q_saved; c < q; c++) Q[c * S + lane] = 0.0;  // keep the zero padding beyond the active columns
     FH_SYNC();
     // the tail and the first 2 KiB of R are requested before the Q copy starts, so that the three round trips overlap
-    const int nr = (q_saved * (q_saved + 1)) / 2, nr2 = (nr + 1) >> 1;
+    const int r0 = ((keep * (keep + 1)) / 2) & ~1;  // first double of R that is fetched (columns >= keep)
+    const int nr = (q_saved * (q_saved + 1)) / 2 - r0, nr2 = (nr + 1) >> 1;
     const double2* st2 = reinterpret_cast<const double2*>(ws_level);
-    const double2* sr2 = reinterpret_cast<const double2*>(ws_level + SNAP_ROFF);
+    const double2* sr2 = reinterpret_cast<const double2*>(ws_level + SNAP_ROFF + r0);
     constexpr int TAIL2 = SNAP_TAIL / 2, TAIL_TRIPS = (TAIL2 + 63) / 64;
     static_assert(SNAP_TAIL % 2 == 0, "the tail is copied 16 B at a time");
     double2 tail[TAIL_TRIPS];
@@ -460,15 +467,16 @@ struct Solver {
     double2 rr[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) rr[j] = sr2[(j * 64 + lane) < nr2 ? j * 64 + lane : 0];
-    copy_in(Q, ws_level + SNAP_QOFF, q_saved * S);
+    copy_in(Q + keep * S, ws_level + SNAP_QOFF + keep * S, (q_saved - keep) * S);
 #pragma unroll
     for (int j = 0; j < TAIL_TRIPS; j++)
       if (j * 64 + lane < TAIL2) reinterpret_cast<double2*>(x)[j * 64 + lane] = tail[j];
 #pragma unroll
     for (int j = 0; j < 2; j++)
-      if (j * 64 + lane < nr2) reinterpret_cast<double2*>(R)[j * 64 + lane] = rr[j];
-    if (nr2 > 128) copy_in(R + 256, ws_level + SNAP_ROFF + 256, nr - 256);  // more than 22 active rows
+      if (j * 64 + lane < nr2) reinterpret_cast<double2*>(R + r0)[j * 64 + lane] = rr[j];
+    if (nr2 > 128) copy_in(R + r0 + 256, ws_level + SNAP_ROFF + r0 + 256, nr - 256);  // more than 22 active rows to fetch
     q = q_saved;
+    if (lane == 0) stk_keep[level] = q_saved;
     FH_SYNC();
   }
 
@@ -1024,6 +1032,7 @@ struct Solver {
     }
     if (lane >= kpos && lane < q - 1) rinv[lane] = 1.0 / R[rp(lane, lane)];
     if (lane < NVP) Q[(q - 1) * S + lane] = 0.0;  // keep the zero padding beyond the active columns
+    if (lane < NSEG && stk_keep[lane] > kpos) stk_keep[lane] = kpos;  // the snapshots of all levels: columns from kpos on differ now
     q--;
     FH_SYNC();
   }
@@ -1684,6 +1693,7 @@ struct Solver {
     screen_constant_rows(pr);  // allowed_first / allowed_last of this trial
     qe = uniform_i32(tb[TB_QE]);
     q = 0;  // (LDS factors are all zero after init_problem: nothing to clear when the snapshot is restored)
+    if (lane < NSEG) stk_keep[lane] = 0;  // ... and nothing of the snapshot is in LDS yet
     depth0 = uniform_i32(tb[TB_DEPTH0]);
     cur_key = tb_get64(TB_KEY);
     // the incumbent's (rounded-up) cost prunes; its key is only compared under the record's lock (publish_incumbent)
@@ -1834,7 +1844,7 @@ struct Solver {
           if (nx < stk_cnt[d_]) {
             FH_SYNC();
             if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
-            { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED, stk_q[d_]); FH_T1(11); }  // restart from the parent's optimum, not from scratch
+            { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED, stk_q[d_], d_); FH_T1(11); }  // restart from the parent's optimum, not from scratch
             const int sh = 3 * (15 - (depth0 + d_));
             cur_key = ((cur_key >> (sh + 3)) << (sh + 3)) | ((unsigned long long)nx << sh);
             have_node = true;
@@ -1909,7 +1919,7 @@ struct Solver {
             if (rec >= 0) publish_incumbent(sa, cost);
           }
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
-          { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED); FH_T1(10); }  // the children inherit this node's factorisation
+          { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED, depth); FH_T1(10); }  // the children inherit this node's factorisation
           {  // child order: candidates sorted by how far the segment is outside each (ascending, ties by polytope index — the order
              // a stable insertion sort gives), by counting: lane p ranks polytope p among the candidates, no serial loop over LDS
             const unsigned am = allowed_mask(bseg) & (P ? ((1u << P) - 1u) : 0u);
