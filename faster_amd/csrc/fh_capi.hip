@@ -716,12 +716,11 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
 int fh_append_plans_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const fh_problem* d_safe,
                            const fh_result* d_safe_results, int n, double r_frac, int max_states, fh_state* d_plans, int32_t* d_counts,
                            int32_t* d_k_safe) {
-  if (!ctx || n < 0 || max_states < 0) return FH_ERR_ARG;
+  if (!ctx || n < 0 || max_states < 0 || !(r_frac >= 0) || !(r_frac <= 1)) return FH_ERR_ARG;
   if (ctx->device < 0) return FH_ERR_DEVICE;
   DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe || !d_safe_results || !d_counts || (max_states > 0 && !d_plans)) return FH_ERR_ARG;
-  if (!(r_frac >= 0) || !(r_frac <= 1)) return FH_ERR_ARG;
   hipLaunchKernelGGL(fh::plan_append_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole, d_whole_results, d_safe, d_safe_results, n,
                      r_frac, ctx->pair_rule, max_states, d_plans, d_counts, d_k_safe);
   FH_HIP(hipGetLastError());

@@ -89,6 +89,19 @@ def test_no_cpu_fallback_without_gpu(built):
     res = np.zeros(1, dtype=abi.result_dtype)
     assert capi.lib().fh_solve_batch(h, abi.ptr(pr), None, 0, 1, abi.ptr(res)) == -2
     assert capi.lib().fh_sync(h) == -2
+    # the entry points of the faithful replan: arguments are checked first (FH_ERR_ARG = -1), then the missing device is reported — never a CPU path
+    L, vp = capi.lib(), ctypes.c_void_p
+    dummy = np.zeros(64)
+    d = abi.ptr(dummy)
+    grid = np.zeros(1, dtype=abi.voxel_grid_dtype)
+    grid["res"], grid["dims"] = 0.2, (4, 4, 4)
+    bbox = np.array([2.0, 2.0, 1.0])
+    assert L.fh_append_plans_device(h, d, d, d, d, 4, 2.0, 8, d, d, None) == -1          # r_frac > 1
+    assert L.fh_append_plans_device(h, d, d, d, d, 4, 0.5, 8, d, d, None) == -2
+    assert L.fh_corridor_problems_device(h, d, d, d, d, d, d, 4, 96, 99, d) == -1        # n_seg > FH_MAX_SEG
+    assert L.fh_corridor_problems_device(h, d, d, d, d, d, d, 4, 96, 6, d) == -2
+    assert L.fh_safe_corridor_batch_device(h, d, d, d, d, 100, d, d, 4, abi.ptr(grid), 4, 0.5, 3, abi.ptr(bbox), 0.05, 0.0, 96, 6, d, d, None, None) == -1  # max_points
+    assert L.fh_safe_corridor_batch_device(h, d, d, d, d, 4, d, d, 4, abi.ptr(grid), 4, 0.5, 3, abi.ptr(bbox), 0.05, 0.0, 96, 6, d, d, None, None) == -2
     capi.lib().fh_destroy(h)
     # the voxel map / path search and the device pool have no CPU path either
     with pytest.raises(capi.FasterHipError):
