@@ -795,7 +795,7 @@ static int decompose_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud,
   if (n_segments == 0) return FH_OK;
   if (!d_segments || !d_faces || !d_counts || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
   if (!(local_bbox[0] > 0) || !(local_bbox[1] > 0) || !(local_bbox[2] > 0) || !(drone_radius >= 0)) return FH_ERR_ARG;
-  const int grid = std::min(n_segments, ctx->n_cu * 4);  // LDS: 29 KB per workgroup
+  const int grid = std::min(n_segments, ctx->n_cu * 12);  // LDS: 10.5 KB per workgroup
   int rc;
   if ((rc = ensure(ctx, 7, sizeof(double) * (size_t)grid * (3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8))) != FH_OK) return rc;
   // bounding boxes of the blocks of 64 cloud points: most blocks cannot touch a segment's local box and are skipped (same results)

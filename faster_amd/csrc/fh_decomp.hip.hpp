@@ -22,7 +22,8 @@
 
 namespace fh {
 
-#define FH_DECOMP_CAP 1024  // obstacle points of interest per segment (points inside the local box); more => count = -1
+#define FH_DECOMP_CAP 256  // points inside the local box that fit the LDS list of a segment; more: the list lives in the workgroup's HBM workspace
+                            // (256: 10.5 KB of LDS, 12 workgroups per CU at 165 VGPRs — with 1024 and 4 per CU the same launches took 1.6x as long)
 #define FH_DECOMP_EPS 1e-10  // DecompUtil's epsilon_
 
 struct D3 {
