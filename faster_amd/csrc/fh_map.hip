@@ -34,7 +34,7 @@ struct fh_map {
   unsigned* d_chunks = nullptr;
   unsigned* d_serials = nullptr;
   int* d_ticket = nullptr;
-  int sched_waves_per_cu = 0, sched_launch_order = 1;  // fh_map_set_sched (0: 12 wavefronts per CU for A*, 16 for the jump point search)
+  int sched_waves_per_cu = 0, sched_launch_order = 1;  // fh_map_set_sched (0: 12 wavefronts per CU for A*, 20 for the jump point search)
   int* d_order = nullptr;  // 128 counters + launch order
   size_t order_cap = 0;
   double sphere_ra = 0.0;                 // fh_map_set_sphere
@@ -87,8 +87,8 @@ int stage(fh_map* m, int slot, size_t bytes) {
 int ensure_workspace(fh_map* m) {
   const size_t total = (size_t)m->nx * m->ny * m->nz;
   const size_t per_wave = total * sizeof(fhp::CellState) + (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS * 4;
-  // LDS: 12.5 KB per wavefront (A*: 12 per CU), 10 KB and <= 128 VGPRs (jump point search: 16 per CU)
-  int waves = m->n_cu * (m->sched_waves_per_cu > 0 ? m->sched_waves_per_cu : (m->search_mode == 1 ? 16 : 12));
+  // LDS: 12.5 KB per wavefront (A*: 12 per CU), 7.5 KB and 96 VGPRs (jump point search: 20 per CU)
+  int waves = m->n_cu * (m->sched_waves_per_cu > 0 ? m->sched_waves_per_cu : (m->search_mode == 1 ? 20 : 12));
   const size_t budget = (size_t)48 << 30;
   if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);
   if (m->d_cells && m->ws_total == total && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
@@ -156,7 +156,7 @@ int fh_map_set_stream(fh_map* m, void* stream) {
 }
 
 int fh_map_set_sched(fh_map* m, int waves_per_cu, int launch_order) {
-  if (!m || waves_per_cu < 0 || waves_per_cu > 16) return FH_ERR_ARG;
+  if (!m || waves_per_cu < 0 || waves_per_cu > 20) return FH_ERR_ARG;
   if (waves_per_cu != m->sched_waves_per_cu) m->ws_total = 0;  // the search workspace is sized by the number of wavefronts: reallocated by the next search
   m->sched_waves_per_cu = waves_per_cu;
   m->sched_launch_order = launch_order ? 1 : 0;

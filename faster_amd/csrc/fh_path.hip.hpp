@@ -518,10 +518,11 @@ struct Planner {
   //   * a space-diagonal jump does the same for 8 diagonal cells x (3 straight + 3 plane-diagonal jumps), one jump per lane.
   // A jump only returns "some cell of this ray ends it" and the diagonal cell it happened at, so the order in which the lanes
   // find that out does not matter: the successor list and its order are jps3d's.
-  // The heap is jps3d's binary heap, top 432 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
+  // The heap is jps3d's binary heap, top 312 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
   // program that all lanes execute; the position of an entry whose key decreases is found by a lane-parallel scan.
   // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
-  static constexpr int CAP_L = 432, CAP_G = 60000;  // (432: 10 044 B of LDS with the tables -> 16 workgroups per CU)
+  static constexpr int CAP_L = 312, CAP_G = 60000;  // (312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;
+                                                   //  432 and 16 per CU: 67 ms instead of 63 for 65536 forest queries; 248 and 24 per CU at 80 VGPRs, spilling: 65 ms)
   double* hf;            // LDS [CAP_L]
   double* hg;
   int* hid;
@@ -1105,7 +1106,7 @@ constexpr unsigned JPS_SERIAL_LIMIT = (1u << 26) - 1u;
 // One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
 // (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
 template <bool JPS>
-__global__ void __launch_bounds__(64) plan_kernel(MapView mv, PlanArgs pa) {
+__global__ void __launch_bounds__(64, JPS ? 5 : 3) plan_kernel(MapView mv, PlanArgs pa) {
   __shared__ __attribute__((aligned(16))) char lds[JPS ? JPS_LDS_BYTES : PLAN_LDS_BYTES];
   Planner pl(mv, lds);
   if (JPS) pl.init_jps(lds, pa.jps_tables, pa.jps_entries);

@@ -404,15 +404,15 @@ int fh_map_create(fh_map** out, int device);
 void fh_map_destroy(fh_map* map);
 const char* fh_map_last_error(const fh_map* map);
 int fh_map_set_stream(fh_map* map, void* hip_stream);
-/* Scheduling of the path search (results do not depend on it): wavefronts per CU that hold a search workspace (1..16; 0 = default:
- * 12 for the A* search, 16 for the jump point search),
+/* Scheduling of the path search (results do not depend on it): wavefronts per CU that hold a search workspace (1..20; 0 = default:
+ * 12 for the A* search, 20 for the jump point search),
  * and whether batches larger than the number of wavefronts start with the far-apart start/goal pairs (default 1). */
 int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
 /* Which search fh_map_plan_batch* runs.  0 (default): A* with a total order of its own — an optimal path; equals the host restatement
  * plan_path bit for bit.  1: jump point search with jps3d's pruning rules, successor order, tolerance comparator and binary heap
  * (thirdparty/jps3d/src/jps_planner/graph_search.cpp:123-470) — of the optimal paths, the one FASTER itself gets from
  * planner_ptr_->plan(start, goal, 1, true) (faster/src/jps_manager.cpp:166); equals plan_path_jps bit for bit, which is pinned vertex
- * for vertex to the reference's compiled sources.  Limits in mode 1: 60432 open entries, 4096 jump points on the path.
+ * for vertex to the reference's compiled sources.  Limits in mode 1: 60312 open entries, 4096 jump points on the path.
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
 /* JPS_in of Faster::replan (faster/src/faster.cpp:370-382): with ra > 0 every path of fh_map_plan_batch* is cut at its first crossing of

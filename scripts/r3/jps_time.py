@@ -14,7 +14,7 @@ d_s = torch.from_numpy(starts).to(dev); d_g = torch.from_numpy(goals).to(dev)
 d_p = torch.zeros((n, 64, 3), dtype=torch.float64, device=dev); d_n = torch.zeros(n, dtype=torch.int32, device=dev); d_e = torch.zeros(n, dtype=torch.int64, device=dev)
 for mode in ("astar", "jps"):
     m.set_search(mode)
-    for waves in ([16, 12, 6, 3] if len(sys.argv) > 2 else [0]):
+    for waves in ([20, 16, 12] if len(sys.argv) > 2 else [0]):
         m.set_sched(waves, 1)
         best = 1e9
         for rep in range(3):
