@@ -1225,8 +1225,15 @@ struct Solver {
   }
 
   // ---- leaf test / branching choice for the node just solved. returns branch segment or -1 (leaf) ----
+  // The segment to branch on: the one least inside any polytope (the quickest way to a good leaf) — unless the ROOT relaxation of
+  // the trial ends outside the corridor (its last segment is inside no polytope: a trajectory that cannot stop in time, the typical
+  // infeasible safe problem).  Below the root of such a trial the EARLIEST violated segment is taken: the trajectory is causal
+  // (segment t depends on the jerks 0..t only), so deciding the early segments first makes the children's QPs tight and an
+  // infeasible trial is refuted in a fraction of the nodes.  The rule is a function of the trial's root alone (bit 16 of
+  // tb[TB_QE], handed on with every frame that is given away), not of the order in which the tree is explored or of who explores
+  // it; any rule is exact (it only orders the search), and the oracle uses the same one.
   template <class PR>
-  __device__ int analyze(const PR& pr) {
+  __device__ int analyze(const PR& pr, bool root) {
     const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     if (P == 0) {
       if (lane < N) fullassign[lane] = -1;
@@ -1286,7 +1293,13 @@ struct Solver {
     const double bw = wave_max_nonneg(score);
     FH_SYNC();
     if (!(bw > 0.0)) return -1;  // (normalised rows carry the tolerance)
-    return first_lane(score == bw);
+    if (root) {
+      const bool ends_outside = __ballot(lane == N - 1 && score > 0.0) != 0ull;
+      if (lane == 0) tb[TB_QE] = ends_outside ? (1 << 16) : 0;
+      return first_lane(score == bw);
+    }
+    const bool earliest = (uniform_i32(tb[TB_QE]) >> 16) != 0;
+    return first_lane(earliest ? score > 0.0 : score == bw);
   }
 
   // =================================================================================================================
@@ -1503,7 +1516,7 @@ struct Solver {
       wt_store(&th->w[TH_BASE], tb_lane0_64(TB_BASE));
       wt_store(&th->w[TH_TRIALS_SEG], pack2(trial + 1, stk_seg[d]));
       wt_store(&th->w[TH_CNT_NEXT], pack2(stk_cnt[d], stk_next[d]));
-      wt_store(&th->w[TH_Q_QE], pack2(qs, qe));
+      wt_store(&th->w[TH_Q_QE], pack2(qs, tb[TB_QE]));  // (qe = 0 | the trial's branching rule << 16)
       wt_store(&th->w[TH_ORDER], olo);
       wt_store(&th->w[TH_ASSIGN_LO], alo);
       wt_store(&th->w[TH_ASSIGN_HI], ahi);
@@ -1691,7 +1704,7 @@ struct Solver {
   template <class PR>
   __device__ void install_frame(const PR& pr, const ShareArgs& sa, double& best_cost) {
     screen_constant_rows(pr);  // allowed_first / allowed_last of this trial
-    qe = uniform_i32(tb[TB_QE]);
+    qe = uniform_i32(tb[TB_QE]) & 0xffff;
     q = 0;  // (LDS factors are all zero after init_problem: nothing to clear when the snapshot is restored)
     if (lane < NSEG) stk_keep[lane] = 0;  // ... and nothing of the snapshot is in LDS yet
     depth0 = uniform_i32(tb[TB_DEPTH0]);
@@ -1815,6 +1828,7 @@ struct Solver {
       }
       reset_qp();  // y = 0: the minimum-norm point of the final-state equalities (setup_trial)
       qe = 0;
+      if (lane == 0) tb[TB_QE] = 0;
       if (!eq_ok) return FH_ST_INFEASIBLE;
     } else {
       depth = 1;
@@ -1908,7 +1922,7 @@ struct Solver {
 #endif
       if (st == 0) {
         int bseg;
-        { FH_T0(); bseg = analyze(pr); FH_T1(9); }
+        { FH_T0(); bseg = analyze(pr, entry == 0 && local_nodes == 1); FH_T1(9); }
         if (bseg < 0) {  // leaf: feasible for the MIQP.  The optimum is the lexicographic minimum of (cost, DFS key)
           if (cost < best_cost || (cost == best_cost && cur_key < best_key)) {
             best_cost = cost;
