@@ -1229,7 +1229,8 @@ struct Solver {
   // the trial ends outside the corridor (its last segment is inside no polytope: a trajectory that cannot stop in time, the typical
   // infeasible safe problem).  Below the root of such a trial the EARLIEST violated segment is taken: the trajectory is causal
   // (segment t depends on the jerks 0..t only), so deciding the early segments first makes the children's QPs tight and an
-  // infeasible trial is refuted in a fraction of the nodes.  The rule is a function of the trial's root alone (bit 16 of
+  // infeasible trial is refuted in a fraction of the nodes; when the root overshoots the corridor by more than 1.2 braking distances
+  // from v_max (v_max^2 / 2 a_max), the root itself branches that way too.  The rule is a function of the trial's root alone (bit 16 of
   // tb[TB_QE], handed on with every frame that is given away), not of the order in which the tree is explored or of who explores
   // it; any rule is exact (it only orders the search), and the oracle uses the same one.
   template <class PR>
@@ -1295,8 +1296,9 @@ struct Solver {
     if (!(bw > 0.0)) return -1;  // (normalised rows carry the tolerance)
     if (root) {
       const bool ends_outside = __ballot(lane == N - 1 && score > 0.0) != 0ull;
+      const bool far_outside = __ballot(lane == N - 1 && score > 1.2 * (vmax * vmax) / (2.0 * amax)) != 0ull;
       if (lane == 0) tb[TB_QE] = ends_outside ? (1 << 16) : 0;
-      return first_lane(score == bw);
+      return first_lane(far_outside ? score > 0.0 : score == bw);
     }
     const bool earliest = (uniform_i32(tb[TB_QE]) >> 16) != 0;
     return first_lane(earliest ? score > 0.0 : score == bw);
