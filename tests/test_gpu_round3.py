@@ -742,3 +742,34 @@ def test_problem_records_from_corridors_on_the_device(ctx):
         assert np.array_equal(pr["xf"][i, :3], goals[i] if inside else last[i]), i
         assert np.array_equal(pr["x0"][i], tmpl["x0"][i]) and pr["dc"][i] == 0.01 and pr["f_init"][i] == 2.0
     assert inside_count >= 32 and inside_count < n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_seg,p_choices", [(5, (2, 3)), (10, (3, 4, 5)), (15, (4, 5))])
+def test_fast_safe_problems_follow_the_oracle_tree(oracle, n_seg, p_choices):
+    """Safe problems that start fast and still accelerating in a corridor pulled in by 0.4 m: many trials end outside the corridor at
+    their root, so the search branches on the earliest violated segment (below the root, or at it when the overshoot exceeds 1.2
+    braking distances).  Results against the oracle; without work sharing the device explores the oracle's tree minus the subtrees
+    the conflict sets let it skip (never more nodes), and with it the results are the same bit for bit."""
+    pr, faces, verts = corridor.safe_batch(512, seed=600 + n_seg, n_seg=n_seg, p_choices=p_choices)
+    faces = faces.copy()
+    faces["b"] -= 0.4
+    u = verts[:, 1] - verts[:, 0]
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    pr["x0"][:, 3:6], pr["x0"][:, 6:9] = 4.8 * u, 2.0 * u
+    ref = oracle.solve_batch(pr, faces)
+    assert 0.3 < ref["solved"].mean() < 0.98
+    par = abi.default_params()
+    shared, solo = capi.Context(0), capi.Context(0)
+    try:
+        shared.set_params(par)
+        par["share"] = 0
+        solo.set_params(par)
+        got, alone = shared.solve_batch(pr, faces), solo.solve_batch(pr, faces)
+    finally:
+        shared.close()
+        solo.close()
+    compare(alone, ref)
+    assert np.all(alone["nodes"] <= ref["nodes"]) and (alone["nodes"] == ref["nodes"]).mean() > 0.5
+    for f in ("solved", "trials", "status", "factor", "dt", "cost", "coeff", "assign"):
+        assert np.array_equal(alone[f], got[f]), f

@@ -46,6 +46,38 @@ def test_safe_problems_equal_exhaustive_enumeration(oracle):
         assert bf["cost"] == pytest.approx(res[i]["cost"], rel=1e-9, abs=1e-9)
 
 
+def test_fast_safe_problems_every_trial_equals_exhaustive_enumeration(oracle):
+    """Safe problems that start fast (the root relaxation of a trial ends outside the corridor, so the branch and bound takes the
+    earliest violated segment below the root — or at the root, when it overshoots by more than 1.2 braking distances): EVERY trial
+    of the factor window, feasible or not, against all P^N assignments (N = 5, P = 3: 243 QPs per trial)."""
+    pr, faces, verts = corridor.safe_batch(32, seed=104, n_seg=5, p_choices=(2, 3))
+    faces = faces.copy()
+    faces["b"] -= 0.4  # (unit normals: every face 0.4 m closer; the start stays inside)
+    u = verts[:, 1] - verts[:, 0]
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    pr["x0"][:, 3:6], pr["x0"][:, 6:9] = 4.8 * u, 2.0 * u  # fast and still accelerating along the corridor
+    res = oracle.solve_batch(pr, faces)
+    assert 0.1 < res["solved"].mean() < 1.0   # a mix: some of these cannot stop inside their corridor for any factor
+    infeasible_trials = feasible_trials = 0
+    for i in range(len(pr)):
+        base = oracle.dt_initial(pr[i])
+        base = max(base, 2 * float(pr[i]["dc"]))
+        f = float(pr[i]["f_init"])
+        for _ in range(4):
+            dt = f * base
+            st, r = oracle.miqp_dt(pr[i], faces, dt)
+            nfeas, bf = oracle.bruteforce_dt(pr[i], faces, dt)
+            if nfeas == 0:
+                assert st == abi.FH_ST_INFEASIBLE, (i, f)
+                infeasible_trials += 1
+            else:
+                assert st == abi.FH_ST_OPTIMAL, (i, f)
+                assert bf["cost"] == pytest.approx(r["cost"], rel=1e-9, abs=1e-9)
+                feasible_trials += 1
+            f += float(pr[i]["f_inc"])
+    assert infeasible_trials >= 20 and feasible_trials >= 20
+
+
 def test_scipy_unreduced_model_agrees_on_random_corridors(oracle):
     """SLSQP on the 12N-coefficient model with the oracle's assignment must not find a better or different optimum."""
     from oracle import py_model
