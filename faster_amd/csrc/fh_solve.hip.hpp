@@ -406,6 +406,14 @@ struct Solver {
   // 16-B-per-lane copy granularity.
   static constexpr int SNAP_TAIL = 3 * NVP + NVP / 2;  // x, u, 1/diag, active row ids
   static constexpr int SNAP_QOFF = (SNAP_TAIL + 127) & ~127;
+#ifdef FH_PARENT_BOUND
+  // experimental (not in the default build): the lower bounds of a frame's children, by rank, in the padding behind the tail of the
+  // frame's workspace slot (they travel with a frame that is given away)
+  static constexpr int SNAP_BOUNDS = SNAP_TAIL, SNAP_TAIL_COPY = SNAP_TAIL + FH_MAX_POLY;
+  static_assert(SNAP_TAIL + FH_MAX_POLY <= ((SNAP_TAIL + 127) & ~127), "the child bounds live in the padding behind the tail");
+#else
+  static constexpr int SNAP_TAIL_COPY = SNAP_TAIL;
+#endif
   static constexpr int SNAP_ROFF = SNAP_QOFF + ((NVP * S + 127) & ~127) + 128;
   static constexpr int SNAP_PADDED = SNAP_ROFF + ((RPSZ + 127) & ~127) + 128;  // doubles per workspace slot
   __device__ __forceinline__ void copy_out(double* __restrict__ dst, const double* src, int count) const {
@@ -1528,7 +1536,7 @@ struct Solver {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const double* src = ws + (size_t)d * SNAP_PADDED;
     double* snap = slot_snap(sa, pos);
-    copy_out_shared(snap, src, SNAP_TAIL);
+    copy_out_shared(snap, src, SNAP_TAIL_COPY);
     copy_out_shared(snap + SNAP_QOFF, src + SNAP_QOFF, qs * S);
     copy_out_shared(snap + SNAP_ROFF, src + SNAP_ROFF, (qs * (qs + 1)) / 2);
     drain_stores();
@@ -1685,7 +1693,7 @@ struct Solver {
     }
     const int qs = uniform_i32((int)(unsigned)w_q_qe);
     const double* snap = slot_snap(sa, pos);
-    copy_in_shared(ws, snap, SNAP_TAIL);
+    copy_in_shared(ws, snap, SNAP_TAIL_COPY);
     copy_in_shared(ws + SNAP_QOFF, snap + SNAP_QOFF, qs * S);
     copy_in_shared(ws + SNAP_ROFF, snap + SNAP_ROFF, (qs * (qs + 1)) / 2);
     drain_stores();  // (the loads have returned: their values were stored)
@@ -1858,6 +1866,21 @@ struct Solver {
           carry_inf = false;
           const int nx = stk_next[d_];
           if (nx < stk_cnt[d_]) {
+#ifdef FH_PARENT_BOUND
+            if (best_cost < INFINITY) {  // the child's lower bound (written when the frame was made) against the incumbent: qp_loop's test, before the visit
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+              const double lb = uniform_f64(ws[(size_t)d_ * SNAP_PADDED + SNAP_BOUNDS + uniform_i32(nx)]);
+              const int shp = 3 * (15 - (depth0 + d_));
+              const unsigned long long ckey = ((cur_key >> (shp + 3)) << (shp + 3)) | ((unsigned long long)(unsigned)uniform_i32(nx) << shp);
+              const double ubp = best_cost * (1.0 - par.mip_gap);
+              if (lb > ubp || (ckey > best_key && lb == ubp)) {
+                FH_SYNC();
+                if (lane == 0) stk_next[d_] = nx + 1;
+                FH_SYNC();
+                continue;  // (not infeasible: the next pass clears this level's all-infeasible bit)
+              }
+            }
+#endif
             FH_SYNC();
             if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
             { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED, stk_q[d_], d_); FH_T1(11); }  // restart from the parent's optimum, not from scratch
@@ -1935,6 +1958,9 @@ struct Solver {
             if (rec >= 0) publish_incumbent(sa, cost);
           }
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
+#ifdef FH_PARENT_BOUND
+          double lb_first = 0.0;  // lower bound of the first child
+#endif
           { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED, depth); FH_T1(10); }  // the children inherit this node's factorisation
           {  // child order: candidates sorted by how far the segment is outside each (ascending, ties by polytope index — the order
              // a stable insertion sort gives), by counting: lane p ranks polytope p among the candidates, no serial loop over LDS
@@ -1950,6 +1976,47 @@ struct Solver {
               stk_order[depth * FH_MAX_POLY + rank] = (signed char)lane;
               if (rank == 0) assign[bseg] = lane;
             }
+#ifdef FH_PARENT_BOUND
+            {  // A lower bound of every child without visiting it.  The multipliers of this node's optimum y* together with ONE
+               // multiplier on a row n of the child (violation v > 0 at y*) are dual feasible for the child's QP, and the best such
+               // multiplier gives cost* + v^2 / |n|^2 (objective |y|^2): the largest of these over the rows of polytope p and the four
+               // control points of the segment bounds child p from below.  |n| in the reduced space is 1 / wcp of lane (segment,
+               // control point) for a normalised row — the scaled violation of the row scan, squared.
+              const int sb = uniform_i32(bseg);
+              const int lp = (lane >> 2) & 7, lk = lane & 3;
+              const bool on = lane < 4 * FH_MAX_POLY && lp < P && ((am >> lp) & 1u);
+              const int f0b = face_off[lp], Fb = on ? face_off[lp + 1] - f0b : 0;
+              double cb[3];
+#pragma unroll
+              for (int i = 0; i < 3; i++) cb[i] = cp_of(lk, Pc[3 * sb + i], Vc[3 * sb + i], Ac[3 * sb + i], Pc[3 * sb + 3 + i]);
+              double m = 0.0;
+              const int flb = Fb > 0 ? Fb - 1 : 0;
+              for (int f = 0; f < maxF; f++) {
+                const fh_face fc = faces[f0b + min(f, flb)];
+                const double vt = fma(fc.a[0], cb[0], fma(fc.a[1], cb[1], fma(fc.a[2], cb[2], fc.b)));
+                m = (f < Fb && vt > m) ? vt : m;
+              }
+              double w = 0.0;
+#pragma unroll
+              for (int k2 = 0; k2 < 4; k2++) {
+                const double wk = readlane_f64(wcp, 4 * sb + k2);
+                w = (lk == k2) ? wk : w;
+              }
+              double bnd = m * w;
+              bnd = bnd * bnd;
+              double bmax = 0.0;  // lane p < P: the bound of polytope p
+              for (int p2 = 0; p2 < P; p2++) {
+                double b4 = 0.0;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) b4 = fmax(b4, readlane_f64(bnd, 4 * p2 + k2));
+                bmax = (lane == p2) ? b4 : bmax;
+              }
+              const double lbv = cost + bmax * (1.0 - 1e-9);
+              if (cand) ws[(size_t)depth * SNAP_PADDED + SNAP_BOUNDS + rank] = lbv;
+              const int l0 = first_lane(cand && rank == 0);
+              lb_first = readlane_f64(lbv, l0 < 0 ? 0 : l0);
+            }
+#endif
             if (lane == 0) {
               stk_cnt[depth] = __builtin_popcount(am);
               stk_seg[depth] = bseg;
@@ -1962,6 +2029,12 @@ struct Solver {
           depth++;
           FH_SYNC();
           backtrack = false;  // first child (rank 0: the key does not change): continue from the parent's factorisation
+#ifdef FH_PARENT_BOUND
+          if (best_cost < INFINITY) {  // ... unless its lower bound already loses against the incumbent
+            const double ubp = best_cost * (1.0 - par.mip_gap);
+            backtrack = lb_first > ubp || (cur_key > best_key && lb_first == ubp);
+          }
+#endif
         }
       }
     }
