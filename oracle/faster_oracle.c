@@ -658,8 +658,66 @@ static void bnb_node(bnb_ctx* B, int8_t* assign) {
       order[b] = order[b - 1];
       order[b - 1] = tmp;
     }
+#ifdef ORC_PARENT_BOUND
+  /* Experimental (make CFLAGS+=-DORC_PARENT_BOUND; the kernels' -DFH_PARENT_BOUND): a child is not visited when a lower bound of
+   * its QP, known at this node, already loses against the incumbent.  The multipliers of this node's optimum x* together with one
+   * multiplier on a single row n of the child (violation v > 0 at x*) are dual feasible for the child's QP; the best such
+   * multiplier gives cost* + v^2 / |n'|^2, n' = n projected off the equality rows (their multipliers are free).  v is taken
+   * beyond the feasibility tolerance, as the kernels' normalised rows carry it. */
+  double qeq[9][NV_MAX];
+  int nq = 0;
+  for (int e = 0; e < me; e++) { /* orthonormal basis of the equality rows (Gram-Schmidt, twice) */
+    double v[NV_MAX];
+    memcpy(v, B->eq[e].a, sizeof(double) * M->n);
+    for (int pass = 0; pass < 2; pass++)
+      for (int j = 0; j < nq; j++) {
+        double d = 0;
+        for (int i = 0; i < M->n; i++) d += qeq[j][i] * v[i];
+        for (int i = 0; i < M->n; i++) v[i] -= d * qeq[j][i];
+      }
+    double nn = 0;
+    for (int i = 0; i < M->n; i++) nn += v[i] * v[i];
+    if (nn > 1e-20) {
+      nn = sqrt(nn);
+      for (int i = 0; i < M->n; i++) qeq[nq][i] = v[i] / nn;
+      nq++;
+    }
+  }
+#endif
   for (int c = 0; c < pr->n_poly; c++) {
     if (!((B->allowed[bseg] >> order[c]) & 1u)) continue;
+#ifdef ORC_PARENT_BOUND
+    if (B->best_cost < INFINITY) {
+      const int p = order[c];
+      double best = 0;
+      for (int f = pr->face_off[p]; f < pr->face_off[p + 1]; f++) {
+        const double* a3 = M->faces[f].a;
+        const double na3 = sqrt(a3[0] * a3[0] + a3[1] * a3[1] + a3[2] * a3[2]);
+        for (int k = 0; k < 4; k++) {
+          double wp, wv, wa;
+          int nx;
+          cp_weights(M->h, k, &wp, &wv, &wa, &nx);
+          orc_row r;
+          make_row(M, bseg + nx, a3, wp, wv, wa, M->faces[f].b, &r);
+          if (r.nrm == 0) continue;
+          double ax = 0;
+          for (int v = 0; v < M->n; v++) ax += r.a[v] * x[v];
+          const double vio = ax - r.rhs - M->par.feas_tol * (na3 > 0 ? 1.0 : 0.0);
+          if (!(vio > 0)) continue;
+          double n2 = r.nrm * r.nrm;
+          for (int j = 0; j < nq; j++) {
+            double d = 0;
+            for (int i = 0; i < M->n; i++) d += qeq[j][i] * r.a[i];
+            n2 -= d * d;
+          }
+          if (n2 < 1e-12 * r.nrm * r.nrm) continue; /* a row that does not depend on the free unknowns */
+          const double bnd = vio * vio / n2;
+          if (bnd > best) best = bnd;
+        }
+      }
+      if (cost + best * (1.0 - 1e-9) >= B->best_cost * (1.0 - M->par.mip_gap)) continue;
+    }
+#endif
     assign[bseg] = (int8_t)order[c];
     bnb_node(B, assign);
   }
