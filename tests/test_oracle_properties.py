@@ -199,3 +199,45 @@ def test_first_feasible_factor_against_highs(oracle):
             assert py_model.milp_feasible(args[0], float(dt_prev), *common) is False
         checked += 1
     assert checked >= 3
+
+
+def test_child_bound_variant_gives_the_same_results(oracle, tmp_path):
+    """The experimental variant (-DORC_PARENT_BOUND: children whose one-row dual bound at the parent already loses against the
+    incumbent are not visited; the kernels' -DFH_PARENT_BOUND) only skips nodes that hold no better leaf: same solved / trials /
+    factor / cost / trajectory, never more nodes, on whole and on fast safe problems."""
+    import ctypes
+    import os
+    import subprocess
+
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    so = str(tmp_path / "liboracle_pb.so")
+    subprocess.check_call(["gcc", "-O2", "-march=native", "-fPIC", "-fopenmp", "-ffp-contract=off", "-DORC_PARENT_BOUND", "-shared", "-o", so,
+                           os.path.join(here, "faster_oracle.c"), "-lm"])
+    L = ctypes.CDLL(so)
+    L.orc_solve_batch_mt.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+
+    def variant(pr, faces):
+        pr, faces = np.ascontiguousarray(pr), np.ascontiguousarray(faces)
+        res = np.zeros(len(pr), dtype=abi.result_dtype)
+        par = abi.default_params()
+        L.orc_solve_batch_mt(abi.ptr(pr), abi.ptr(faces), abi.ptr(par.reshape(1)), len(pr), abi.ptr(res), 0)
+        return res
+
+    whole, wf, _ = corridor.whole_batch(256, seed=105, n_seg=10, p_choices=(3, 4, 5, 6))
+    safe, sf, verts = corridor.safe_batch(256, seed=106, n_seg=8, p_choices=(3, 4))
+    sf = sf.copy()
+    sf["b"] -= 0.4
+    u = verts[:, 1] - verts[:, 0]
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    safe["x0"][:, 3:6], safe["x0"][:, 6:9] = 4.8 * u, 2.0 * u
+    fewer = 0
+    for pr, faces in ((whole, wf), (safe, sf)):
+        ref, got = oracle.solve_batch(pr, faces), variant(pr, faces)
+        for f in ("solved", "trials", "factor", "dt", "status"):
+            assert np.array_equal(ref[f], got[f]), f
+        ok = ref["solved"] == 1
+        np.testing.assert_allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(got["coeff"][ok], ref["coeff"][ok], rtol=0, atol=1e-7)
+        assert np.all(got["nodes"] <= ref["nodes"])
+        fewer += int((got["nodes"] < ref["nodes"]).sum())
+    assert fewer >= 64
