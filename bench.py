@@ -82,6 +82,104 @@ def host_cores():
     return n
 
 
+def launch_own_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks ourselves (one process per
+    device under torch.distributed.run, rendezvous on 127.0.0.1) and exit with their status.  Fails loudly when fewer than N devices
+    are visible — a 1-GPU number must never be printed under --gpus N.  Returns only when there is nothing to launch (N = 1, or the
+    ranks were already started by a launcher: WORLD_SIZE is set)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not args.dry_run:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but %d HIP device(s) visible" % (args.gpus, have))
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def rank_devices(torch, dist, rank, world, local_rank):
+    """What every rank really runs on (rank 0 prints it): the world size the process group saw, the device of each rank."""
+    if torch.cuda.is_available() and torch.cuda.device_count() > local_rank:
+        p = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device": local_rank, "name": p.name, "arch": getattr(p, "gcnArchName", ""), "pid": os.getpid()}
+    else:
+        mine = {"rank": rank, "device": None, "name": "cpu (dry run)", "pid": os.getpid()}
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def dry_run(args, rank, world, local_rank):
+    """--dry-run: everything of the N>1 run except the solves — process group (gloo or nccl), contiguous sharding (faster_amd/shard.py),
+    the per-step gather of packed result records (zeroed, CPU tensors), barrier + max-over-ranks timing — and one JSON line without
+    a `value`.  Touches neither the HIP library nor the oracle."""
+    import torch
+    import torch.distributed as dist
+
+    from faster_amd import corridor, shard
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    devices = rank_devices(torch, dist, rank, world, local_rank)
+    strong = args.scaling == "strong" and world > 1
+    pairs = min(args.pairs, 4096)
+    whole, faces, _ = corridor.whole_batch(pairs, seed=3 if strong else 3 + 1000 * rank, n_seg=args.n_seg,
+                                           p_choices=tuple(range(args.min_poly, args.max_poly + 1)))
+    if strong:
+        whole, faces = shard.shard_batch(whole, faces, rank, world)
+    B = len(whole)
+    per_rank = -(-pairs // world) if strong else B
+    PK = 64 + 96 * args.n_seg  # fh_pack_results record
+    wp, sp = torch.zeros(per_rank * PK, dtype=torch.uint8), torch.zeros(per_rank * PK, dtype=torch.uint8)
+    wp[: B * PK] = rank + 1
+    gather = None
+    if world > 1:
+        gather = [torch.zeros(world * per_rank * PK, dtype=torch.uint8) for _ in range(2)] if strong else (
+            [[torch.zeros(per_rank * PK, dtype=torch.uint8) for _ in range(world)] for _ in range(2)] if rank == 0 else None)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            shard.gather_result_blocks(dist, wp, sp, gather, strong, rank)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ok = True
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        if strong:
+            for r in range(world):
+                lo, hi = shard.shard_range(pairs, r, world)
+                ok &= bool((gather[0][r * per_rank * PK: (r * per_rank + hi - lo) * PK] == r + 1).all())
+        elif rank == 0:
+            ok = all(bool((gather[0][r] == r + 1).all()) for r in range(world))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "trajectory solves/sec (whole+safe pairs) at N=%d, deg=3" % args.n_seg, "value": None,
+                          "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "strong" if strong else "weak",
+                          "backend": args.backend if world > 1 else None, "devices": devices, "pairs_per_rank": B, "gather_ok": bool(ok),
+                          "ms_per_step": 1e3 * elapsed / max(args.steps, 1)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,19 +209,32 @@ def main():
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     ap.add_argument("--no-share", action="store_true", help="one wavefront per problem (fh_params.share = 0)")
     ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N>1 run: nccl (= RCCL over xGMI, default); gloo only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, shard the batch and run the per-step gather of (zeroed) packed result records, but solve nothing: "
+                         "checks the launcher and the N>1 plumbing where there is no GPU (tests/test_distributed_gloo.py); prints no `value`")
     args = ap.parse_args()
+    if args.backend == "gloo" and not args.dry_run:
+        raise SystemExit("bench.py: --backend gloo is for --dry-run only (the hot path has no CPU fallback)")
 
     # more hardware queues than the HIP default (4) so that the in-flight pipelines really run concurrently
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    launch_own_ranks(args)  # (--gpus N > 1 outside torch.distributed.run: does not return)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: refusing to report a %d-GPU number under "
+                         "--gpus %d" % (args.gpus, world, world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -132,6 +243,7 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    devices = rank_devices(torch, dist, rank, world, local_rank)
 
     from faster_amd import abi, capi, corridor, shard
 
@@ -281,6 +393,7 @@ def main():
             "value": value,
             "unit": "pairs/s",
             "n_gpus": world,
+            "devices": devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

@@ -127,3 +127,38 @@ def test_two_rank_gloo_sharding(tmp_path, oracle):
 def test_four_rank_gloo_sharding(tmp_path, oracle):
     """37 problems over 4 ranks: shards of 10, 10, 10, 7 — the gathered fh_result blocks equal the 1-way run record for record."""
     _run_world(tmp_path, 4)
+
+
+def _bench(args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus N` with no torch.distributed environment starts N ranks itself (it used to run ONE rank and
+    print n_gpus 1).  --dry-run --backend gloo: the launcher, the sharding and the per-step gather without a GPU; n_gpus is the world
+    size the process group really saw, one device record per rank."""
+    import json
+
+    for scaling in ("weak", "strong"):
+        p = _bench(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "2", "--pairs", "37", "--scaling", scaling])
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, p.stdout  # ONE JSON line, from rank 0
+        out = json.loads(line[0])
+        assert out["n_gpus"] == 2 and out["dry_run"] and out["value"] is None and out["gather_ok"]
+        assert [d["rank"] for d in out["devices"]] == [0, 1] and len({d["pid"] for d in out["devices"]}) == 2
+        assert out["pairs_per_rank"] == (19 if scaling == "strong" else 37)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """--gpus 8 inside a 1-rank environment must not print a 1-GPU number; and without devices the launcher fails loudly."""
+    p = _bench(["--gpus", "8", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "refusing" in p.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        p = _bench(["--gpus", "2", "--steps", "1"])
+        assert p.returncode != 0 and "HIP device" in p.stderr
