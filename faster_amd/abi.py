@@ -85,7 +85,7 @@ assert pair_rule_dtype.itemsize == 40
 
 def default_sched():
     s = np.zeros((), dtype=sched_dtype)
-    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"] = 1, 4, 32, 16, 1
+    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"] = 1, 4, 32, 2, 1
     return s
 
 

@@ -40,7 +40,12 @@ def packed_result_size(n_seg):
 def pack_results(results, n_seg):
     """numpy array of fh_result records -> uint8 array of packed records (host side)."""
     results = np.ascontiguousarray(results)
-    out = np.zeros(len(results) * packed_result_size(n_seg), dtype=np.uint8)
+    rec = packed_result_size(n_seg)
+    if rec <= 0:
+        raise FasterHipError("fh_pack_results: n_seg=%r has no packed record (1 <= n_seg <= FH_MAX_SEG)" % (n_seg,))
+    if results.dtype != abi.result_dtype:
+        raise FasterHipError("fh_pack_results: an array of fh_result records is expected, got dtype %s" % (results.dtype,))
+    out = np.zeros(len(results) * rec, dtype=np.uint8)
     rc = lib().fh_pack_results(abi.ptr(results), len(results), int(n_seg), abi.ptr(out))
     if rc != 0:
         raise FasterHipError("fh_pack_results: rc=%d" % rc)
@@ -50,6 +55,12 @@ def pack_results(results, n_seg):
 def unpack_results(packed, n, n_seg):
     """Packed records (bytes-like / uint8 array) -> numpy array of fh_result records (host side, no device needed)."""
     buf = np.ascontiguousarray(np.frombuffer(packed, dtype=np.uint8) if not isinstance(packed, np.ndarray) else packed.view(np.uint8).reshape(-1))
+    rec = packed_result_size(n_seg)
+    n = int(n)
+    if rec <= 0 or n < 0:
+        raise FasterHipError("fh_unpack_results: n=%r, n_seg=%r (1 <= n_seg <= FH_MAX_SEG, n >= 0)" % (n, n_seg))
+    if buf.size < n * rec:  # a short RCCL / PCIe buffer or a wrong n_seg must not make the C side read past the end
+        raise FasterHipError("fh_unpack_results: %d records of %d bytes need %d bytes, the buffer holds %d" % (n, rec, n * rec, buf.size))
     out = np.zeros(n, dtype=abi.result_dtype)
     rc = lib().fh_unpack_results(abi.ptr(buf), n, int(n_seg), abi.ptr(out))
     if rc != 0:
@@ -256,6 +267,7 @@ class Map:
         if rc != 0:
             self._h = None
             raise FasterHipError("fh_map_create: rc=%d (no HIP device? there is no CPU fallback)" % rc)
+        self.search, self.sphere = "astar", 0.0  # what fh_map_create starts with (mirrored: callers that change them put them back)
 
     def close(self):
         if self._h:
@@ -285,11 +297,13 @@ class Map:
     def set_sphere(self, ra):
         """fh_map_set_sphere: clip every path to JPS_in (sphere of radius min(|goal - start| - 0.001, ra) around the start); 0: off."""
         self._check(lib().fh_map_set_sphere(self._h, float(ra)), "fh_map_set_sphere")
+        self.sphere = max(float(ra), 0.0)
 
     def set_search(self, mode):
         """fh_map_set_search: "astar" (default; an optimal path, total order of its own) or "jps" (jump point search in jps3d's own
         order: the optimal path FASTER itself gets)."""
         self._check(lib().fh_map_set_search(self._h, {"astar": 0, "jps": 1}[mode]), "fh_map_set_search")
+        self.search = mode
 
     def read(self, cloud, cells, res, center, z_ground, z_max, inflation):
         cloud = np.ascontiguousarray(cloud, dtype=np.float64).reshape(-1, 3)

@@ -283,7 +283,7 @@ void fh_default_sched(fh_sched* s) {
   s->publish_factor = 4;
   s->backlog = 32;
   s->waiting_workgroups = 0;
-  s->min_nodes = 16;
+  s->min_nodes = 2;
   s->cloud_blocks = 1;
 }
 

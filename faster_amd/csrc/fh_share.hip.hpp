@@ -133,7 +133,7 @@ struct ShareArgs {
   int enabled;                // 0: no frames are given away (workers leave when the tickets are exhausted)
   int total_units;
   int max_hungry;             // at most this many workgroups poll the queue; the others leave when the tickets are exhausted
-  int min_nodes;              // a problem gives work away only after this many branch-and-bound nodes (all trials so far): small trees
+  int min_nodes;              // a problem gives work to an idle workgroup only after this many branch-and-bound nodes (all trials so far): small trees
                               // are cheaper to finish than to hand over (a hop costs about as much as 2-3 nodes)
   int backlog;                // frames that may be published AHEAD of the takers: a problem that has proved hard does not have to wait
                               // for the fresh problems to run out before it gets help — every workgroup looks for a pending frame

@@ -7,7 +7,7 @@
 //
 // Mapping to the machine
 //   * one problem (= one genNewTraj call) per 64-lane wavefront, one wavefront per workgroup; the grid is what is
-//     resident at once (8 workgroups per CU: LDS and VGPR limited) and every workgroup pulls problems from a
+//     resident at once (up to 12 workgroups per CU: LDS limited — fh_capi.hip computes it from the carve —, 3 wavefronts per SIMD by VGPRs) and every workgroup pulls problems from a
 //     device-scope ticket counter, so problems of different difficulty balance across the 256 CUs;
 //   * control flow is wave-uniform: the whole search (factor loop -> branch and bound -> dual active set) is a
 //     scalar program; the 64 lanes are the data-parallel axis inside every step (rows of the constraint scan,
@@ -1913,7 +1913,7 @@ struct Solver {
         // gives its shallowest open frame away, and — once it is shared — the factor trials after this one, or a second frame.
         // (sa.enabled is 0 with a work cap or a MIP gap.)
         // (idle takers: nothing to lose by sharing early; no idle taker but room in the backlog: only the giants publish ahead)
-        if ((fl & 2) && ((fl & 4) ? (rec >= 0 || nodes + local_nodes >= 2) : (nodes + local_nodes >= sa.giant_nodes || (fl & 8)))) {
+        if ((fl & 2) && ((fl & 4) ? (rec >= 0 || nodes + local_nodes >= sa.min_nodes) : (nodes + local_nodes >= sa.giant_nodes || (fl & 8)))) {
           if (depth > 0) donate(sa, ws, depth, best_cost);
           // ... and the factor trials after this one (a narrow tree may never have an open frame to give, but its trials are
           // independent), or, when it has none left to give, a second frame

@@ -1,7 +1,9 @@
 """ctypes binding of the CPU corridor front-end (faster_amd/libfasterfront.so) and the Monte-Carlo
 forest workload of BASELINE config 5."""
+import contextlib
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -82,17 +84,43 @@ def plan_jps(cloud, cells, res, center, z_ground, z_max, inflation, start, goal,
     return (out[:k].copy() if k > 0 else None), cost.value, ex.value
 
 
+# The host front-end keeps its search mode and sphere radius as process-wide settings (ff_set_search_mode / ff_set_sphere).  This module
+# mirrors them so that a call which needs other values can put the caller's back (host_settings), under a lock: the batch entry
+# points read the settings while they run.
+_HOST = {"search": "astar", "sphere": 0.0}
+_HOST_LOCK = threading.RLock()
+
+
 def set_search(mode):
     """Which search plan_batch / forest_batch(front="host") run: "astar" (default: the total-order A* the device search reproduces bit for
     bit) or "jps" (jump point search in jps3d's own order: the path FASTER itself gets)."""
-    if lib().ff_set_search_mode({"astar": 0, "jps": 1}[mode]) != 0:
-        raise ValueError(mode)
+    with _HOST_LOCK:
+        if lib().ff_set_search_mode({"astar": 0, "jps": 1}[mode]) != 0:
+            raise ValueError(mode)
+        _HOST["search"] = mode
 
 
 def set_sphere(ra):
     """Clip every path of plan_batch / forest_batch(front="host") to JPS_in (Faster::replan, faster.cpp:370-382) before the vertex
     refinement: sphere of radius min(|goal - start| - 0.001, ra) around the start; 0: off."""
-    lib().ff_set_sphere(float(ra))
+    with _HOST_LOCK:
+        lib().ff_set_sphere(float(ra))
+        _HOST["sphere"] = max(float(ra), 0.0)
+
+
+@contextlib.contextmanager
+def host_settings(search, sphere_ra):
+    """The host front-end with this search and sphere radius for the duration of the block; the caller's settings come back afterwards,
+    also when the block raises.  Holds the lock: concurrent callers with other settings wait."""
+    with _HOST_LOCK:
+        prev = dict(_HOST)
+        try:
+            set_search(search)
+            set_sphere(sphere_ra)
+            yield
+        finally:
+            set_search(prev["search"])
+            set_sphere(prev["sphere"])
 
 
 def jps_tables():
@@ -190,16 +218,23 @@ def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation
     d_off = torch.zeros((n, 9), dtype=torch.int32, device=dev)
     d_npoly = torch.zeros(n, dtype=torch.int32, device=dev)
     d_goal = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-    vmap.set_search(search)
-    vmap.set_sphere(sphere_ra)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    vmap.read_device(d_cloud.data_ptr(), len(d_cloud), cells, res, center, z_ground, z_max, inflation)
-    vmap.sync()
-    t1 = time.perf_counter()
-    vmap.plan_batch_device(d_s.data_ptr(), d_g.data_ptr(), n, mp, d_paths.data_ptr(), d_np.data_ptr(), d_ex.data_ptr(), max_vertex_dist, max_poly)
-    vmap.sync()
-    t2 = time.perf_counter()
+    prev = (vmap.search, vmap.sphere)  # the caller's Map comes back as it was (changing the search mode invalidates its workspace:
+    try:                               # only touched when it differs)
+        if vmap.search != search:
+            vmap.set_search(search)
+        vmap.set_sphere(sphere_ra)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vmap.read_device(d_cloud.data_ptr(), len(d_cloud), cells, res, center, z_ground, z_max, inflation)
+        vmap.sync()
+        t1 = time.perf_counter()
+        vmap.plan_batch_device(d_s.data_ptr(), d_g.data_ptr(), n, mp, d_paths.data_ptr(), d_np.data_ptr(), d_ex.data_ptr(), max_vertex_dist, max_poly)
+        vmap.sync()
+        t2 = time.perf_counter()
+    finally:
+        if vmap.search != prev[0]:
+            vmap.set_search(prev[0])
+        vmap.set_sphere(prev[1])
     ctx.corridor_batch_device(d_cloud.data_ptr(), len(d_cloud), d_paths.data_ptr(), d_np.data_ptr(), n, mp, max_poly, faces_per_problem,
                               d_faces.data_ptr(), d_off.data_ptr(), d_npoly.data_ptr(), d_goal.data_ptr(), drone_radius, z_ground)
     ctx.sync()
@@ -231,13 +266,10 @@ def forest_batch(n, seed, n_seg=15, max_poly=8, force_final=True, size=(20.0, 20
         face_off = np.zeros((n, 9), dtype=np.int32)
         n_poly = np.zeros(n, dtype=np.int32)
         goal_out = np.zeros((n, 3))
-        set_search(search)
-        set_sphere(sphere_ra)
-        overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
-                                           inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
-                                           faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
-        set_search("astar")
-        set_sphere(0.0)
+        with host_settings(search, sphere_ra):
+            overflow = lib().ff_corridor_batch(abi.ptr(_c(cloud)), len(cloud), cells[0], cells[1], cells[2], res, abi.ptr(_c(center)), 0.0, size[2],
+                                               inflation, drone_radius, abi.ptr(_c(starts)), abi.ptr(_c(goals)), n, max_poly, max_vertex_dist,
+                                               faces_per_problem, abi.ptr(faces), abi.ptr(face_off), abi.ptr(n_poly), abi.ptr(goal_out))
         timing = None
     ok = n_poly > 0
     counts = face_off[np.arange(n), n_poly]

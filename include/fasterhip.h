@@ -166,7 +166,7 @@ typedef struct fh_sched {
                                  frames ahead of the idle workgroups (default 4; 0: never)                                      */
   int32_t backlog;            /* frames that may be published ahead of the takers (default 32; 0: none)                        */
   int32_t waiting_workgroups; /* workgroups that keep waiting for frames when the fresh problems run out (0 = default: CUs / 16) */
-  int32_t min_nodes;          /* a tree gives work away only after this many nodes, unless somebody is idle (default 16)        */
+  int32_t min_nodes;          /* a problem gives work to an IDLE workgroup only after this many nodes of its trees (default 2)  */
   int32_t cloud_blocks;       /* 1 (default): the decomposition skips blocks of 64 cloud points whose bounding box misses the
                                  local box of a segment                                                                         */
   int32_t workgroups_per_cu;  /* resident solves per CU (0 = default: as many as LDS and registers admit, 11 for the C4 kernel)    */
@@ -412,7 +412,8 @@ int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
  * plan_path bit for bit.  1: jump point search with jps3d's pruning rules, successor order, tolerance comparator and binary heap
  * (thirdparty/jps3d/src/jps_planner/graph_search.cpp:123-470) — of the optimal paths, the one FASTER itself gets from
  * planner_ptr_->plan(start, goal, 1, true) (faster/src/jps_manager.cpp:166); equals plan_path_jps bit for bit, which is pinned vertex
- * for vertex to the reference's compiled sources.  Limits in mode 1: 60312 open entries, 4096 jump points on the path.
+ * for vertex to the reference's compiled sources behind a test-only Boost.Heap shim (oracle/ref_frontend/shim: the sift discipline that
+ * decides between equal-cost paths is the shim author's reading of Boost's, not Boost itself).  Limits in mode 1: 60312 open entries, 4096 jump points on the path.
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
 /* JPS_in of Faster::replan (faster/src/faster.cpp:370-382): with ra > 0 every path of fh_map_plan_batch* is cut at its first crossing of

@@ -215,3 +215,25 @@ def test_path_search_equals_pure_python_restatement(seed):
         assert hn[i] == len(path) and ex == hex_[i], (i, hn[i], len(path), ex, hex_[i])
         assert np.array_equal(np.array(path), hp[i, :hn[i]]), i
     assert solved >= 7
+
+
+def test_host_settings_come_back():
+    """forest_batch(front="host") used to leave the process-wide search mode / sphere radius of the host front-end at
+    astar / 0 whatever the caller had set.  The caller's settings survive a call that needs other ones, and an exception inside it."""
+    from faster_amd import frontend
+
+    frontend.set_search("jps")
+    frontend.set_sphere(3.5)
+    try:
+        frontend.forest_batch(8, seed=2, n_seg=6, max_poly=3, search="astar", sphere_ra=0.0)
+        assert frontend._HOST == {"search": "jps", "sphere": 3.5}
+        try:
+            with frontend.host_settings("astar", 1.0):
+                assert frontend._HOST == {"search": "astar", "sphere": 1.0}
+                raise KeyError("inside")
+        except KeyError:
+            pass
+        assert frontend._HOST == {"search": "jps", "sphere": 3.5}
+    finally:
+        frontend.set_search("astar")
+        frontend.set_sphere(0.0)
