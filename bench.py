@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the timed region (solo launch, copies, flop rate)")
+    ap.add_argument("--solo-only", action="store_true", help="of the legs outside the timed region run the solo launch only (A/B runs)")
     ap.add_argument("--pipeline", choices=["fused", "split"], default="fused",
                     help="fused: one launch per step, each unit of work is a pair taken through whole solve, hand-off and safe solve; "
                          "split: whole launch -> hand-off launch -> safe launch (same results)")
@@ -457,6 +458,11 @@ def main():
                                 "launches_timed": rf["launches_timed"], "pipelines_in_flight": rf["pipelines_in_flight"]}
             mean_solo_launch = float(np.mean(so["launch_ms_median"]))
             rf["achieved"], rf["frac"], rf["avg_launch_ms"], rf["mode"] = so["achieved"], so["frac"], mean_solo_launch, "one launch alone (solo leg)"
+            if args.solo_only:
+                print(json.dumps(out))
+                for pp in pipes:
+                    pp.ctx.close()
+                return
             out["roofline"]["compute"] = compute_leg(torch, dev, pipes[0], whole, faces, solo_res, N, max_faces,
                                                      out["roofline"]["solo"]["step_ms_median"], elapsed / args.steps, to_dev)
             out["e2e_with_copies"] = e2e_leg(torch, dev, pipes[0], whole, faces, safe_t, B, N, max_faces)

@@ -70,7 +70,7 @@ assert params_dtype.itemsize == 48
 
 
 sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("backlog", "<i4"), ("waiting_workgroups", "<i4"),
-                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("reserved", "<i4")])
+                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("child_bound", "<i4")])
 assert sched_dtype.itemsize == 32
 
 
@@ -85,7 +85,7 @@ assert pair_rule_dtype.itemsize == 40
 
 def default_sched():
     s = np.zeros((), dtype=sched_dtype)
-    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"] = 1, 4, 32, 2, 1
+    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"], s["child_bound"] = 1, 4, 32, 2, 1, 1
     return s
 
 

@@ -39,7 +39,7 @@ def build_device(force=False, verbose=False):
         # -sink-insts-to-avoid-spills / -disable-machine-licm: the solve kernels are compiled for 3 wavefronts per SIMD (168 vector
         # registers); with the default hoisting of loop invariants out of the branch-and-bound loops they spill ~150 registers to
         # scratch (HBM round trips in the per-problem code), with these two options ~20 (measured: +6 % pairs/s).
-        # FASTERHIP_EXTRA_FLAGS: diagnostic / experimental builds only (e.g. -DFH_PARENT_BOUND)
+        # FASTERHIP_EXTRA_FLAGS: diagnostic / experimental builds only (e.g. -DFH_PROFILE)
         extra = os.environ.get("FASTERHIP_EXTRA_FLAGS", "").split()
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-sink-insts-to-avoid-spills",
                "-mllvm", "-disable-machine-licm"] + extra + ["-o", SO] + SOURCES

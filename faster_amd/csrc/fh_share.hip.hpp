@@ -140,6 +140,7 @@ struct ShareArgs {
                               // before it draws its next problem (the hard problems started early otherwise finish last, alone)
   int giant_nodes;            // ... but only a problem that has already needed this many nodes publishes ahead of the takers
   int giant_factor;           // ... or this many times the mean number of active-set iterations of the units finished so far (0: off)
+  int child_bound;            // 1: a child whose one-row dual bound at the parent already loses against the incumbent is not visited (fh_sched.child_bound)
 };
 
 #define FH_AGENT __HIP_MEMORY_SCOPE_AGENT

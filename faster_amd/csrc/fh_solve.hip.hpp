@@ -68,6 +68,15 @@ namespace fh {
 #ifndef FH_REORTH_THRESHOLD
 #define FH_REORTH_THRESHOLD 0.05
 #endif
+// Tree levels (of a worker's own stack) whose snapshot tail — the parent's optimum, its multipliers and active row ids — and child
+// bounds stay in LDS instead of the HBM workspace: going back to a parent whose factor columns are still intact in LDS then costs two
+// LDS copies and no memory round trip.  N <= 10: two levels (almost every tree); the N = 15 / 16 carves have no LDS to spare.
+#ifndef FH_TAIL_LEVELS
+#define FH_TAIL_LEVELS 2
+#endif
+#ifndef FH_TAIL_LEVELS_BIG
+#define FH_TAIL_LEVELS_BIG 0
+#endif
 
 enum { K_EQ = 0, K_JBOX = 1, K_VBOX = 2, K_ABOX = 3, K_POLY = 4 };
 // weight kinds of a row: which linear functional of the state at the start of segment tt
@@ -234,7 +243,9 @@ __device__ inline double polish3(double c3, double c2, double c1, double c0, dou
 // the CPU oracle's sequential loops; the minimum over the positive roots and the maximum over the axes do not depend on the
 // order).  The double-precision cbrt / acos / cos behind a cubic are hundreds of instructions each: done once per wavefront
 // instead of once per axis and root, they are ~4 % instead of ~25 % of a typical problem.  0: no positive root.
-__device__ inline double cubic_root_of_lane(double c3, double c2, double c1, double c0, int j) {
+// (noinline: the solve kernels evaluate the candidates one per lane, the preparation kernel of a big batch — prepare_kernel — nine per
+// thread; both call THIS code, so a root is the same double wherever it was computed)
+__device__ __noinline__ double cubic_root_of_lane(double c3, double c2, double c1, double c0, int j) {
   const double B = c2 / c3, C = c1 / c3, D = c0 / c3;
   const double p = C - B * B / 3.0;
   const double q = 2.0 * B * B * B / 27.0 - B * C / 3.0 + D;
@@ -256,7 +267,7 @@ __device__ inline double cubic_root_of_lane(double c3, double c2, double c1, dou
   }
   return cand;
 }
-__device__ inline double quad_root_of_lane(double c2, double c1, double c0, int j) {
+__device__ __noinline__ double quad_root_of_lane(double c2, double c1, double c0, int j) {
   const double disc = c1 * c1 - 4.0 * c2 * c0;
   if (disc < 0) return (j == 0 && sqrt(-disc) / fabs(2.0 * c2) < 1e-12) ? -c1 / (2.0 * c2) : 0.0;
   const double s = sqrt(disc);
@@ -295,6 +306,34 @@ __device__ inline double dt_initial(const PR& pr, int lane) {
   return dt0;
 }
 
+// The same, all nine candidates by one thread (prepare_kernel: one thread per problem of a big batch, so that the solve kernel's
+// wavefronts — nine useful lanes of 64 in dt_initial — do not spend ~1500 instructions per problem on it).  Same candidate
+// functions, same casts, exact minima / maxima: the same double as dt_initial.
+template <class PR>
+__device__ inline double dt_initial_serial(const PR& pr) {
+  float mx = 0.f;
+  for (int i = 0; i < 3; i++) {
+    const double x0p = pr.x0[i], x0v = pr.x0[3 + i], x0a = pr.x0[6 + i], xfp = pr.xf[i];
+    const double dx = xfp - x0p;
+    const float tv = (float)(fabs(dx) / pr.v_max);
+    const float jerk = (float)(copysign(1.0, dx) * pr.j_max);
+    const float a0 = (float)x0a, v0 = (float)x0v;
+    const float acc = (float)(copysign(1.0, dx) * pr.a_max);
+    double bj = INFINITY, ba = INFINITY;
+    for (int j = 0; j < 3; j++) {
+      const double rj = cubic_root_of_lane((double)jerk / 6.0, (double)a0 / 2.0, (double)v0, -dx, j);
+      const double ra = quad_root_of_lane(0.5 * (double)acc, (double)v0, -dx, j);
+      bj = (rj > 0 && rj < bj) ? rj : bj;
+      ba = (ra > 0 && ra < ba) ? ra : ba;
+    }
+    const float tj = (float)(bj < INFINITY ? bj : 0.0), ta = (float)(ba < INFINITY ? ba : 0.0);
+    mx = fmaxf(mx, fmaxf(tv, fmaxf(ta, tj)));
+  }
+  double dt0 = (double)(mx / (float)pr.n_seg);
+  if (dt0 > 10000) dt0 = 0;
+  return dt0;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 template <int NSEG>
 struct Solver {
@@ -313,6 +352,8 @@ struct Solver {
   // ---- LDS carve (doubles first) ----
   double *Q, *R;                                      // Q1 column major [NVP cols][S] (column c = active slot); R packed upper triangular [RPSZ]
   double *x, *z, *g, *d, *r, *u, *rinv;               // [NVP] x = the reduced unknowns y (r aliases d: only live inside the re-orthogonalisation pass)
+  double *tcache, *tbnd;                              // [TC][SNAP_TAIL] snapshot tails and [TC][FH_MAX_POLY] child bounds of the first TC tree levels
+  static constexpr int TC = NSEG <= 10 ? FH_TAIL_LEVELS : FH_TAIL_LEVELS_BIG;
   double* xs;                                         // [NXP] x-space scratch: Z y (compute_states), a row normal in x space (build_g)
   double* Zm;                                         // [NSEG][ZS] orthogonal basis of this N (fh_basis.hip.hpp), kept across problems
   double *Pc, *Vc, *Ac;                               // [NT*3] current states at segment starts
@@ -332,7 +373,7 @@ struct Solver {
   static __host__ __device__ constexpr size_t lds_bytes(int max_faces) {
     // (the hardware hands out LDS in granules of 1280 B — measured with a residency census: 14 080 B admit 11 workgroups per CU,
     // 14 336 B only 10 — so every few hundred bytes of this carve decide a wavefront per CU)
-    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 2 * NVP + NXP + NSEG * ZS + 3 * NT * 3 + 12) +
+    return sizeof(double) * (NVP * S + RPSZ + 3 * NVP + NVP / 2 + 2 * NVP + NXP + NSEG * ZS + 3 * NT * 3 + 12 + TC * (2 * NVP + NVP / 2 + FH_MAX_POLY)) +
            sizeof(int) * (9 * NSEG + FH_MAX_POLY + 1 + TB_WORDS) + ((NSEG * FH_MAX_POLY + 15) & ~15) +
            (sizeof(fh_face) + sizeof(float)) * max_faces + 16;
   }
@@ -359,8 +400,9 @@ struct Solver {
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
   unsigned poly_ok;  // polytopes without a violated zero-normal face (such a polytope can never hold a segment)
 #ifdef FH_PROFILE
-  unsigned long long prof[16];
-  unsigned int cnt[16];
+  unsigned long long prof[24];   // 0-15: see scripts/phase_profile.py; 16 look-around + donations, 17 result write, 18 hand-off of the pair (charged to
+  unsigned int cnt[24];          // its safe problem), 19 ticket + launch order fetch (charged to the problem drawn), 20 child order + bounds, 21 leaf bookkeeping
+  unsigned long long pre_cycles, glue_cycles;  // measured in the kernel loop, charged to the next problem
 #endif
   unsigned allowed_first, allowed_last;  // polytopes not excluded for segment 0 / N-1 by jerk-independent rows
   double h, tol, dep2;
@@ -376,9 +418,10 @@ struct Solver {
     double* p = reinterpret_cast<double*>(base);
     Q = p; p += NVP * S;
     R = p; p += RPSZ;
-    x = p; p += NVP;  u = p; p += NVP;  rinv = p; p += NVP;
+    x = p; p += NVP;  u = p; p += NVP;
     act = reinterpret_cast<int*>(p); p += NVP / 2;
-    // ---- end of the snapshot block ----
+    // ---- end of the snapshot block (1 / diag(R) is not part of it: recomputed from R when a snapshot is restored) ----
+    rinv = p; p += NVP;
     g = p; p += NVP;  d = p; p += NVP;  r = d;
     xs = p; p += NXP;
     z = xs;  // the remainder kept for the re-orthogonalisation pass lives where the x-space scratch does: xs is dead between the
@@ -389,6 +432,8 @@ struct Solver {
     viol = g;  // [NSEG][FH_MAX_POLY] aliases g,d,xs: only live between two active-set runs (analyze)
     static_assert(NSEG * FH_MAX_POLY <= 2 * NVP + NXP && 9 <= NVP, "scratch must fit in g,d,xs");
     xfl = p; p += 12;
+    tcache = p; p += TC * SNAP_TAIL;
+    tbnd = p; p += TC * FH_MAX_POLY;
     int* ip = reinterpret_cast<int*>(p);
     assign = ip; ip += NSEG;  bestassign = ip; ip += NSEG;  fullassign = ip; ip += NSEG;
     stk_seg = ip; ip += NSEG;  stk_next = ip; ip += NSEG;  stk_cnt = ip; ip += NSEG;  stk_q = ip; ip += NSEG;  stk_mask = ip; ip += NSEG;  stk_keep = ip; ip += NSEG;
@@ -404,16 +449,12 @@ struct Solver {
   // A snapshot holds only what is live: the first q columns of Q1 (contiguous: column major), the first q columns of the
   // packed R, and the fixed tail (x, u, 1/diag, active masks).  Workspace slot: [tail | Q | R], each padded for the
   // 16-B-per-lane copy granularity.
-  static constexpr int SNAP_TAIL = 3 * NVP + NVP / 2;  // x, u, 1/diag, active row ids
+  static constexpr int SNAP_TAIL = 2 * NVP + NVP / 2;  // x, u, active row ids
   static constexpr int SNAP_QOFF = (SNAP_TAIL + 127) & ~127;
-#ifdef FH_PARENT_BOUND
-  // experimental (not in the default build): the lower bounds of a frame's children, by rank, in the padding behind the tail of the
-  // frame's workspace slot (they travel with a frame that is given away)
+  // the lower bounds of a frame's children (child bound, search()), by rank, live in the padding behind the tail of the frame's
+  // workspace slot: they travel with a frame that is given away
   static constexpr int SNAP_BOUNDS = SNAP_TAIL, SNAP_TAIL_COPY = SNAP_TAIL + FH_MAX_POLY;
   static_assert(SNAP_TAIL + FH_MAX_POLY <= ((SNAP_TAIL + 127) & ~127), "the child bounds live in the padding behind the tail");
-#else
-  static constexpr int SNAP_TAIL_COPY = SNAP_TAIL;
-#endif
   static constexpr int SNAP_ROFF = SNAP_QOFF + ((NVP * S + 127) & ~127) + 128;
   static constexpr int SNAP_PADDED = SNAP_ROFF + ((RPSZ + 127) & ~127) + 128;  // doubles per workspace slot
   __device__ __forceinline__ void copy_out(double* __restrict__ dst, const double* src, int count) const {
@@ -445,7 +486,12 @@ struct Solver {
   __device__ void snapshot_save(double* __restrict__ ws_level, int level) {
     const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
     FH_SYNC();
-    copy_out(ws_level, x, SNAP_TAIL);
+    if (level < TC) {  // the tail stays in LDS
+      double* tc = tcache + level * SNAP_TAIL;
+      for (int i = lane; i < SNAP_TAIL; i += 64) tc[i] = x[i];
+    } else {
+      copy_out(ws_level, x, SNAP_TAIL);
+    }
     copy_out(ws_level + SNAP_QOFF, Q, q * S);
     copy_out(ws_level + SNAP_ROFF, R, (q * (q + 1)) / 2);
     if (lane == 0) stk_keep[level] = q;
@@ -453,38 +499,54 @@ struct Solver {
   // q_saved: number of active rows in the snapshot; the current q may be larger (columns to clear) or smaller
   __device__ void snapshot_restore(const double* __restrict__ ws_level, int q_saved, int level) {
     const int lane = opaque(this->lane);  // (lane-derived constants are recomputed here, not kept in registers across the whole solve)
-    int keep = uniform_i32(stk_keep[level]);
-    keep = keep < 0 ? 0 : (keep > q_saved ? q_saved : keep);
+    const int keep0 = uniform_i32(stk_keep[level]);
+    const bool intact = keep0 >= q_saved;  // no row below q_saved was dropped since the snapshot: its factor columns are still in LDS
+    const bool cached = level < TC;
+    int keep = keep0 < 0 ? 0 : (keep0 > q_saved ? q_saved : keep0);
     keep &= ~1;  // (the copies move 16 bytes per lane: an even number of doubles from an even offset; S is odd)
     // the workspace was written by this same wavefront (snapshot_save of an ancestor node): drain its outstanding stores
-    // before reading them back
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // before reading them back — only when something IS read back (a drain is a full memory round trip)
+    if (!cached || !intact) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if (lane < NVP)
       for (int c = q_saved; c < q; c++) Q[c * S + lane] = 0.0;  // keep the zero padding beyond the active columns
     FH_SYNC();
-    // the tail and the first 2 KiB of R are requested before the Q copy starts, so that the three round trips overlap
-    const int r0 = ((keep * (keep + 1)) / 2) & ~1;  // first double of R that is fetched (columns >= keep)
-    const int nr = (q_saved * (q_saved + 1)) / 2 - r0, nr2 = (nr + 1) >> 1;
-    const double2* st2 = reinterpret_cast<const double2*>(ws_level);
-    const double2* sr2 = reinterpret_cast<const double2*>(ws_level + SNAP_ROFF + r0);
     constexpr int TAIL2 = SNAP_TAIL / 2, TAIL_TRIPS = (TAIL2 + 63) / 64;
     static_assert(SNAP_TAIL % 2 == 0, "the tail is copied 16 B at a time");
-    double2 tail[TAIL_TRIPS];
+    if (!intact) {
+      // the tail and the first 2 KiB of R are requested before the Q copy starts, so that the three round trips overlap
+      const int r0 = ((keep * (keep + 1)) / 2) & ~1;  // first double of R that is fetched (columns >= keep)
+      const int nr = (q_saved * (q_saved + 1)) / 2 - r0, nr2 = (nr + 1) >> 1;
+      const double2* st2 = reinterpret_cast<const double2*>(ws_level);
+      const double2* sr2 = reinterpret_cast<const double2*>(ws_level + SNAP_ROFF + r0);
+      double2 tail[TAIL_TRIPS];
+      if (!cached) {
 #pragma unroll
-    for (int j = 0; j < TAIL_TRIPS; j++) tail[j] = st2[(j * 64 + lane) < TAIL2 ? j * 64 + lane : 0];
-    double2 rr[2];
+        for (int j = 0; j < TAIL_TRIPS; j++) tail[j] = st2[(j * 64 + lane) < TAIL2 ? j * 64 + lane : 0];
+      }
+      double2 rr[2];
 #pragma unroll
-    for (int j = 0; j < 2; j++) rr[j] = sr2[(j * 64 + lane) < nr2 ? j * 64 + lane : 0];
-    copy_in(Q + keep * S, ws_level + SNAP_QOFF + keep * S, (q_saved - keep) * S);
+      for (int j = 0; j < 2; j++) rr[j] = sr2[(j * 64 + lane) < nr2 ? j * 64 + lane : 0];
+      copy_in(Q + keep * S, ws_level + SNAP_QOFF + keep * S, (q_saved - keep) * S);
+      if (!cached) {
 #pragma unroll
-    for (int j = 0; j < TAIL_TRIPS; j++)
-      if (j * 64 + lane < TAIL2) reinterpret_cast<double2*>(x)[j * 64 + lane] = tail[j];
+        for (int j = 0; j < TAIL_TRIPS; j++)
+          if (j * 64 + lane < TAIL2) reinterpret_cast<double2*>(x)[j * 64 + lane] = tail[j];
+      }
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-      if (j * 64 + lane < nr2) reinterpret_cast<double2*>(R + r0)[j * 64 + lane] = rr[j];
-    if (nr2 > 128) copy_in(R + r0 + 256, ws_level + SNAP_ROFF + r0 + 256, nr - 256);  // more than 22 active rows to fetch
+      for (int j = 0; j < 2; j++)
+        if (j * 64 + lane < nr2) reinterpret_cast<double2*>(R + r0)[j * 64 + lane] = rr[j];
+      if (nr2 > 128) copy_in(R + r0 + 256, ws_level + SNAP_ROFF + r0 + 256, nr - 256);  // more than 22 active rows to fetch
+    } else if (!cached) {
+      copy_in(x, ws_level, SNAP_TAIL);
+    }
+    if (cached) {
+      const double* tc = tcache + level * SNAP_TAIL;
+      for (int i = lane; i < SNAP_TAIL; i += 64) x[i] = tc[i];
+    }
     q = q_saved;
     if (lane == 0) stk_keep[level] = q_saved;
+    FH_SYNC();
+    if (lane < q_saved) rinv[lane] = 1.0 / R[rp(lane, lane)];  // (the same division that produced the value when the row was added)
     FH_SYNC();
   }
 
@@ -1536,7 +1598,12 @@ struct Solver {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const double* src = ws + (size_t)d * SNAP_PADDED;
     double* snap = slot_snap(sa, pos);
-    copy_out_shared(snap, src, SNAP_TAIL_COPY);
+    if (d < TC) {  // (tail and child bounds of the first levels live in LDS)
+      copy_out_shared(snap, tcache + d * SNAP_TAIL, SNAP_TAIL);
+      copy_out_shared(snap + SNAP_BOUNDS, tbnd + d * FH_MAX_POLY, FH_MAX_POLY);
+    } else {
+      copy_out_shared(snap, src, SNAP_TAIL_COPY);
+    }
     copy_out_shared(snap + SNAP_QOFF, src + SNAP_QOFF, qs * S);
     copy_out_shared(snap + SNAP_ROFF, src + SNAP_ROFF, (qs * (qs + 1)) / 2);
     drain_stores();
@@ -1693,7 +1760,12 @@ struct Solver {
     }
     const int qs = uniform_i32((int)(unsigned)w_q_qe);
     const double* snap = slot_snap(sa, pos);
-    copy_in_shared(ws, snap, SNAP_TAIL_COPY);
+    if (TC > 0) {  // the frame becomes stack level 0 of this worker: its tail and child bounds go where level 0 keeps them
+      for (int i = lane; i < SNAP_TAIL; i += 64) tcache[i] = cc_load(snap + i);
+      if (lane < FH_MAX_POLY) tbnd[lane] = cc_load(snap + SNAP_BOUNDS + lane);
+    } else {
+      copy_in_shared(ws, snap, SNAP_TAIL_COPY);
+    }
     copy_in_shared(ws + SNAP_QOFF, snap + SNAP_QOFF, qs * S);
     copy_in_shared(ws + SNAP_ROFF, snap + SNAP_ROFF, (qs * (qs + 1)) / 2);
     drain_stores();  // (the loads have returned: their values were stored)
@@ -1866,10 +1938,15 @@ struct Solver {
           carry_inf = false;
           const int nx = stk_next[d_];
           if (nx < stk_cnt[d_]) {
-#ifdef FH_PARENT_BOUND
-            if (best_cost < INFINITY) {  // the child's lower bound (written when the frame was made) against the incumbent: qp_loop's test, before the visit
-              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-              const double lb = uniform_f64(ws[(size_t)d_ * SNAP_PADDED + SNAP_BOUNDS + uniform_i32(nx)]);
+            if (sa.child_bound && best_cost < INFINITY) {  // the child's lower bound (written when the frame was made) against the incumbent: qp_loop's test, before the visit
+              double lb;
+              if (d_ < TC) {
+                FH_SYNC();
+                lb = uniform_f64(tbnd[d_ * FH_MAX_POLY + uniform_i32(nx)]);
+              } else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                lb = uniform_f64(ws[(size_t)d_ * SNAP_PADDED + SNAP_BOUNDS + uniform_i32(nx)]);
+              }
               const int shp = 3 * (15 - (depth0 + d_));
               const unsigned long long ckey = ((cur_key >> (shp + 3)) << (shp + 3)) | ((unsigned long long)(unsigned)uniform_i32(nx) << shp);
               const double ubp = best_cost * (1.0 - par.mip_gap);
@@ -1880,7 +1957,6 @@ struct Solver {
                 continue;  // (not infeasible: the next pass clears this level's all-infeasible bit)
               }
             }
-#endif
             FH_SYNC();
             if (lane == 0) { stk_next[d_] = nx + 1; assign[seg] = stk_order[d_ * FH_MAX_POLY + nx]; }
             { FH_T0(); snapshot_restore(ws + (size_t)d_ * SNAP_PADDED, stk_q[d_], d_); FH_T1(11); }  // restart from the parent's optimum, not from scratch
@@ -1907,6 +1983,7 @@ struct Solver {
       // a problem that is already shared looks around twice as often; a taker looks before its first node (it hands the other
       // children of its frame, or the following trials, on at once if more takers are waiting)
       if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (rec >= 0 && local_nodes == 1 && (entry == 1 || trial + 1 < trial_end))) {
+        FH_T0();
         int fl = look_around(sa, local_nodes, iters);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }
         // somebody is out of work: a problem that has proved hard (it already has a share record, or sa.min_nodes nodes so far)
@@ -1914,15 +1991,23 @@ struct Solver {
         // (sa.enabled is 0 with a work cap or a MIP gap.)
         // (idle takers: nothing to lose by sharing early; no idle taker but room in the backlog: only the giants publish ahead)
         if ((fl & 2) && ((fl & 4) ? (rec >= 0 || nodes + local_nodes >= sa.min_nodes) : (nodes + local_nodes >= sa.giant_nodes || (fl & 8)))) {
-          if (depth > 0) donate(sa, ws, depth, best_cost);
-          // ... and the factor trials after this one (a narrow tree may never have an open frame to give, but its trials are
-          // independent), or, when it has none left to give, a second frame
-          const int fl2 = look_around(sa, 1);
-          if (fl2 & 2) {
-            if (trial + 1 < trial_end) donate_trials(sa, pr, best_cost, (fl2 >> 8) & 63);
-            else if (rec >= 0 && depth > 0) donate(sa, ws, depth, best_cost);
+          // the shallowest open frame first; then the factor trials after this one (a narrow tree may never have an open frame to
+          // give, but its trials are independent), or, when it has none left to give, a second frame.  (ONE call site of donate():
+          // a second one makes the compiler outline it, and a call puts the whole solver state into scratch memory.)
+          for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+              const int fl2 = look_around(sa, 1);
+              if (!(fl2 & 2)) break;
+              if (trial + 1 < trial_end) {
+                donate_trials(sa, pr, best_cost, (fl2 >> 8) & 63);
+                break;
+              }
+              if (rec < 0) break;
+            }
+            if (depth > 0) donate(sa, ws, depth, best_cost);
           }
         }
+        FH_T1(16);
       }
       if (rec >= 0) {  // shared problem: other workers' leaves prune here too
         const unsigned long long r = uniform_u64(ald(&(sa.recs + rec)->inc_rank));
@@ -1949,6 +2034,7 @@ struct Solver {
         int bseg;
         { FH_T0(); bseg = analyze(pr, entry == 0 && local_nodes == 1); FH_T1(9); }
         if (bseg < 0) {  // leaf: feasible for the MIQP.  The optimum is the lexicographic minimum of (cost, DFS key)
+          FH_T0();
           if (cost < best_cost || (cost == best_cost && cur_key < best_key)) {
             best_cost = cost;
             best_key = cur_key;
@@ -1957,11 +2043,11 @@ struct Solver {
             FH_SYNC();
             if (rec >= 0) publish_incumbent(sa, cost);
           }
+          FH_T1(21);
         } else {  // branch on bseg, most promising polytope first (stable insertion sort)
-#ifdef FH_PARENT_BOUND
-          double lb_first = 0.0;  // lower bound of the first child
-#endif
+          double lb_first = 0.0;  // lower bound of the first child (child bound)
           { FH_T0(); snapshot_save(ws + (size_t)depth * SNAP_PADDED, depth); FH_T1(10); }  // the children inherit this node's factorisation
+          FH_T0();
           {  // child order: candidates sorted by how far the segment is outside each (ascending, ties by polytope index — the order
              // a stable insertion sort gives), by counting: lane p ranks polytope p among the candidates, no serial loop over LDS
             const unsigned am = allowed_mask(bseg) & (P ? ((1u << P) - 1u) : 0u);
@@ -1976,8 +2062,8 @@ struct Solver {
               stk_order[depth * FH_MAX_POLY + rank] = (signed char)lane;
               if (rank == 0) assign[bseg] = lane;
             }
-#ifdef FH_PARENT_BOUND
-            {  // A lower bound of every child without visiting it.  The multipliers of this node's optimum y* together with ONE
+            if (sa.child_bound) {
+               // A lower bound of every child without visiting it.  The multipliers of this node's optimum y* together with ONE
                // multiplier on a row n of the child (violation v > 0 at y*) are dual feasible for the child's QP, and the best such
                // multiplier gives cost* + v^2 / |n|^2 (objective |y|^2): the largest of these over the rows of polytope p and the four
                // control points of the segment bounds child p from below.  |n| in the reduced space is 1 / wcp of lane (segment,
@@ -2012,11 +2098,13 @@ struct Solver {
                 bmax = (lane == p2) ? b4 : bmax;
               }
               const double lbv = cost + bmax * (1.0 - 1e-9);
-              if (cand) ws[(size_t)depth * SNAP_PADDED + SNAP_BOUNDS + rank] = lbv;
+              if (cand) {
+                if (depth < TC) tbnd[depth * FH_MAX_POLY + rank] = lbv;
+                else ws[(size_t)depth * SNAP_PADDED + SNAP_BOUNDS + rank] = lbv;
+              }
               const int l0 = first_lane(cand && rank == 0);
               lb_first = readlane_f64(lbv, l0 < 0 ? 0 : l0);
             }
-#endif
             if (lane == 0) {
               stk_cnt[depth] = __builtin_popcount(am);
               stk_seg[depth] = bseg;
@@ -2028,13 +2116,12 @@ struct Solver {
           allinf |= 1u << depth;
           depth++;
           FH_SYNC();
+          FH_T1(20);
           backtrack = false;  // first child (rank 0: the key does not change): continue from the parent's factorisation
-#ifdef FH_PARENT_BOUND
-          if (best_cost < INFINITY) {  // ... unless its lower bound already loses against the incumbent
+          if (sa.child_bound && best_cost < INFINITY) {  // ... unless its lower bound already loses against the incumbent
             const double ubp = best_cost * (1.0 - par.mip_gap);
             backtrack = lb_first > ubp || (cur_key > best_key && lb_first == ubp);
           }
-#endif
         }
       }
     }
@@ -2072,13 +2159,15 @@ __device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
 template <int NSEG, class PR>
 __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
                             const fh_params& par, const ShareArgs& sa, const double* __restrict__ basis, double* __restrict__ ws, int entry,
-                            bool interrupted, fh_result& res) {
+                            bool interrupted, fh_result& res, const double* dt0_ready) {
   const int lane = sv.lane;
 #ifdef FH_SHARE_PROFILE
   const unsigned long long sp_tp__ = wall_ticks();
 #endif
 #ifdef FH_PROFILE
-  for (int i = 0; i < 16; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
+  for (int i = 0; i < 24; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
+  sv.prof[18] = sv.glue_cycles; sv.cnt[18] = sv.glue_cycles ? 1 : 0; sv.glue_cycles = 0;
+  sv.prof[19] = sv.pre_cycles; sv.cnt[19] = sv.pre_cycles ? 1 : 0; sv.pre_cycles = 0;
   const unsigned long long tstart__ = __builtin_readcyclecounter();
 #endif
   if (entry == 0 && (interrupted || bad_input(pr, NSEG, max_faces))) {
@@ -2164,7 +2253,9 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
 #ifdef FH_PROFILE
   sv.prof[0] = __builtin_readcyclecounter() - tstart__;
 #endif
-  const double dt0 = dt_initial(pr, lane);
+  // (a big batch comes with its dt_initial values: prepare_kernel wrote them before this launch started — a scalar load)
+  typedef const __attribute__((address_space(4))) double cdouble_t;
+  const double dt0 = dt0_ready ? *(cdouble_t*)sv.uniform_u64((unsigned long long)dt0_ready) : dt_initial(pr, lane);
   const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
 #ifdef FH_PROFILE
   sv.prof[14] = __builtin_readcyclecounter() - tstart__ - sv.prof[0]; sv.cnt[14] = 1;
@@ -2271,6 +2362,9 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     }
   }
 
+#ifdef FH_PROFILE
+  const unsigned long long tres__ = __builtin_readcyclecounter();
+#endif
   if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
     FH_SYNC();
     if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
@@ -2298,21 +2392,16 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
   }
 #ifdef FH_PROFILE
   sv.prof[12] = __builtin_readcyclecounter() - tstart__;
-  sv.prof[1] += 0;
-  if (lane < 12 && sv.N < FH_MAX_SEG) {
-    unsigned long long pv = 0;
-    for (int i = 0; i < 12; i++) pv = (i == lane) ? sv.prof[i] : pv;
+  sv.prof[17] = __builtin_readcyclecounter() - tres__; sv.cnt[17] = 1;
+  if (lane < 12 && sv.N <= FH_MAX_SEG - 4) {  // rows 15 / 14: cycles / calls of slots 0..11, rows 13 / 12: of slots 12..23
+    unsigned long long pv = 0, pw = 0;
+    unsigned int cv = 0, cw = 0;
+    for (int i = 0; i < 12; i++) { pv = (i == lane) ? sv.prof[i] : pv; cv = (i == lane) ? sv.cnt[i] : cv; }
+    for (int i = 0; i < 12; i++) { pw = (i == lane) ? sv.prof[12 + i] : pw; cw = (i == lane) ? sv.cnt[12 + i] : cw; }
     res.coeff[FH_MAX_SEG - 1][lane] = (double)pv;
-    unsigned int cv = 0;
-    for (int i = 0; i < 12; i++) cv = (i == lane) ? sv.cnt[i] : cv;
     res.coeff[FH_MAX_SEG - 2][lane] = (double)cv;
-    if (lane < 4) {  // slots 12..15 (12: the whole problem, 13: screening, 14: dt_initial)
-      unsigned long long pw = 0;
-      unsigned int cw = 0;
-      for (int i = 0; i < 4; i++) { pw = (i == lane) ? sv.prof[12 + i] : pw; cw = (i == lane) ? sv.cnt[12 + i] : cw; }
-      res.coeff[FH_MAX_SEG - 3][lane] = (double)pw;
-      res.coeff[FH_MAX_SEG - 3][4 + lane] = (double)cw;
-    }
+    res.coeff[FH_MAX_SEG - 3][lane] = (double)pw;
+    res.coeff[FH_MAX_SEG - 4][lane] = (double)cw;
   }
 #endif
 #ifdef FH_SHARE_PROFILE
@@ -2356,6 +2445,9 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
   // launch order: ticket t works on unit order[t] (null: t).  Results do not depend on it; the hardest corridors go first so that
   // their trees are not what the launch ends on (order_kernel)
   const int* order;
+  // dt_initial of problem i (getDTInitial), written by prepare_kernel before the launch; null: the solve kernel computes it (small
+  // batches, and always for the safe problem of a pair, whose initial state is only known once its whole problem is solved)
+  const double* dt0;
 };
 
 // Persistent workgroups (one wavefront each).  Every workgroup pulls fresh units from a device-scope ticket counter
@@ -2387,9 +2479,15 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
 #ifdef FH_SHARE_PROFILE
   unsigned long long sp_dry__ = 0;
 #endif
+#ifdef FH_PROFILE
+  sv.pre_cycles = 0; sv.glue_cycles = 0;
+#endif
   for (;;) {
     int entry = 0, unit = 0, phase = 0;
     bool interrupted = false;
+#ifdef FH_PROFILE
+    const unsigned long long tpre__ = __builtin_readcyclecounter();
+#endif
     // a frame of a hard problem comes before a fresh problem; without fresh problems the workgroup waits for frames
     if (sa.enabled && (sa.backlog > 0 || !tickets_left)) entry = sv.take_task(sa, ws, !tickets_left);
     if (entry) {
@@ -2431,6 +2529,9 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
     unit = uniform_i32(unit);
     phase = uniform_i32(phase);
     interrupted = uniform_i32(interrupted ? 1 : 0) != 0;
+#ifdef FH_PROFILE
+    if (!entry) sv.pre_cycles = __builtin_readcyclecounter() - tpre__;
+#endif
     for (;;) {  // the problems of the unit (a pair has two)
       bool finished;
       if constexpr (PAIRS) {
@@ -2443,7 +2544,8 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(phase ? &ka.safe[unit] : &problems[unit]));
         const fh_face* fcs = reinterpret_cast<const fh_face*>(sv.uniform_u64((unsigned long long)(phase ? ka.sfaces : faces)));
         fh_result* out = reinterpret_cast<fh_result*>(sv.uniform_u64((unsigned long long)(phase ? &ka.sres[unit] : &results[unit])));
-        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out);
+        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out,
+                                                    (phase == 0 && ka.dt0) ? ka.dt0 + unit : nullptr);
       }
       else {
         // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
@@ -2452,12 +2554,15 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
         typedef const __attribute__((address_space(4))) fh_problem const_problem;
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(problems + unit));  // (provably wave-uniform)
         finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
-                                                    results[unit]);
+                                                    results[unit], ka.dt0 ? ka.dt0 + unit : nullptr);
       }
       if (!finished) break;  // the unit continues in another workgroup
       if constexpr (PAIRS) {
         if (phase == 0) {
           // the whole result was written by this wavefront (plain stores): drained, then read back by the hand-off
+#ifdef FH_PROFILE
+          const unsigned long long tglue__ = __builtin_readcyclecounter();
+#endif
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           pair_glue_one<true>(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit],
                               ka.sfaces, opaque((int)threadIdx.x));
@@ -2465,6 +2570,9 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
           // that CU's stores; no agent-scope acquire here — it made every pair drop the CU's L1 and, measured, 0.5 GB of dirty
           // snapshot lines per launch leave L2); a workgroup that takes a frame of it later acquires in take_task
           drain_stores();
+#ifdef FH_PROFILE
+          sv.glue_cycles = __builtin_readcyclecounter() - tglue__;
+#endif
           phase = 1;
           entry = 0;
           if (threadIdx.x == 0) sv.tb[sv.TB_PHASE] = 1;
@@ -2507,14 +2615,18 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
 // number of polytopes (C4: 52 active-set iterations per pair with 2, 320 with 6; 34 of the 41 hardest pairs in 4096 have 6), and a
 // hard tree that is started late is what a launch ends on.  The order inside a class is whatever the atomics give: no result
 // depends on it.
-__global__ void __launch_bounds__(256) order_hist_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters) {
+// The same launch prepares the batch: thread i also computes dt_initial of problem i (dt0 != null), so that no wavefront of the
+// solve kernel has to (prepare: the histogram is skipped when counters == null — batches that are not reordered).
+__global__ void __launch_bounds__(256) prepare_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters,
+                                                      double* __restrict__ dt0) {
   __shared__ int cnt[FH_MAX_POLY + 1];
   if (threadIdx.x <= FH_MAX_POLY) cnt[threadIdx.x] = 0;
   __syncthreads();
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i < n) atomicAdd(&cnt[min(max(problems[i].n_poly, 0), FH_MAX_POLY)], 1);
+  if (i < n && counters) atomicAdd(&cnt[min(max(problems[i].n_poly, 0), FH_MAX_POLY)], 1);
+  if (i < n && dt0) dt0[i] = dt_initial_serial(problems[i]);
   __syncthreads();
-  if (threadIdx.x <= FH_MAX_POLY && cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]);
+  if (counters && threadIdx.x <= FH_MAX_POLY && cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]);
 }
 __global__ void __launch_bounds__(256) order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters,
                                                             int* __restrict__ order) {

@@ -170,7 +170,10 @@ typedef struct fh_sched {
   int32_t cloud_blocks;       /* 1 (default): the decomposition skips blocks of 64 cloud points whose bounding box misses the
                                  local box of a segment                                                                         */
   int32_t workgroups_per_cu;  /* resident solves per CU (0 = default: as many as LDS and registers admit, 11 for the C4 kernel)    */
-  int32_t reserved;
+  int32_t child_bound;        /* 1 (default): a child of a branch-and-bound node is not visited when a lower bound of its QP that is
+                                 known at the parent — the parent's multipliers plus one multiplier on the child's most violated
+                                 row: cost* + v^2 / |n|^2 — already loses against the incumbent (it holds no better leaf: the result
+                                 is unchanged, the trees are half as large).  0: every child is visited, the tree of the CPU oracle   */
 } fh_sched;
 void fh_default_sched(fh_sched* s);
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s);

@@ -1,29 +1,65 @@
 """Per-phase cycle breakdown of fh::solve_kernel (diagnostic build with -DFH_PROFILE; not part of the product).
-   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DFH_PROFILE -o /tmp/libfasterhip_prof.so faster_amd/csrc/fh_capi.hip
-   FASTERHIP_SO=/tmp/libfasterhip_prof.so python scripts/phase_profile.py"""
+   FASTERHIP_EXTRA_FLAGS=-DFH_PROFILE python -c "from faster_amd import build; build.build_device(force=True)"   (or an -o elsewhere + FASTERHIP_SO)
+   python scripts/phase_profile.py [pairs] [plain|pairs]
+The C4 batch of bench.py (seed 3) through the fused pair kernel (default) or the whole problems alone; every problem record of the
+launch carries its own cycle counters in the unused coefficient rows 12..15 (N <= 12)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from faster_amd import abi, capi, corridor
 
-names = ["staging (faces, LDS init)", "setup_trial", "states+CP", "scan", "build_g", "project", "backsolve+ratio+update", "add_row",
-         "drop_row", "analyze", "snap save", "snap restore", "(whole problem)", "screen_constant_rows", "dt_initial", "search() in total"]
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+names = ["staging (record, faces, LDS init)", "setup_trial", "states+CP", "scan", "build_g", "project", "backsolve+ratio+update", "add_row",
+         "drop_row", "analyze", "snap save", "snap restore", "(whole problem)", "screen_constant_rows", "dt_initial", "(search() in total)",
+         "look-around + donations", "result write", "hand-off of the pair (glue)", "ticket + order fetch", "child order + bounds", "leaf bookkeeping",
+         "-", "-"]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+mode = sys.argv[2] if len(sys.argv) > 2 else "pairs"
 ctx = capi.Context(0)
 whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=10, p_choices=(2, 3, 4, 5, 6))
-res = ctx.solve_batch(whole, faces)
+
+
 def report(tag, res):
-    prof = np.concatenate([res["coeff"][:, abi.FH_MAX_SEG - 1, :12], res["coeff"][:, abi.FH_MAX_SEG - 3, :4]], axis=1)
+    res = res[res["trials"] > 0]
+    M = abi.FH_MAX_SEG
+    prof = np.concatenate([res["coeff"][:, M - 1, :12], res["coeff"][:, M - 3, :12]], axis=1)
+    cnt = np.concatenate([res["coeff"][:, M - 2, :12], res["coeff"][:, M - 4, :12]], axis=1).sum(axis=0)
     whole_problem = prof[:, 12].copy()
-    prof[:, 12] = 0
     search_total = prof[:, 15].copy()
+    prof[:, 12] = 0
     prof[:, 15] = 0
     tot = prof.sum(axis=0)
-    print(tag, "cycles per problem (mean): in the slots %.0f, whole problem %.0f; iters %.1f nodes %.1f trials %.2f" % (prof.sum(axis=1).mean(), whole_problem.mean(), res["qp_iters"].mean(), res["nodes"].mean(), res["trials"].mean()))
-    cnt = np.concatenate([res["coeff"][:, abi.FH_MAX_SEG - 2, :12], res["coeff"][:, abi.FH_MAX_SEG - 3, 4:8]], axis=1).sum(axis=0)
-    for n, v, c in zip(names, tot, cnt):
-        print("   %-26s %6.1f%%  %9.0f cyc/problem  %7.1f calls/problem  %7.0f cyc/call" % (n, 100 * v / tot.sum(), v / len(res), c / len(res), v / max(c, 1)))
-    inner = prof[:, 2:12].sum(axis=1) + prof[:, 13]
-    print("   search() %.0f cyc/problem, of which outside the slots (bookkeeping, look-around, sharing) %.0f; run_problem outside search/setup/staging/dt (result write, epilogue) %.0f"
-          % (search_total.mean(), (search_total - inner).mean(), (whole_problem - search_total - prof[:, 0] - prof[:, 1] - prof[:, 14]).mean()))
-report("whole", res)
+    n = len(res)
+    print("%s: %d problems; cycles per problem (mean): run_problem %.0f (+ ticket %.0f + glue %.0f outside it); iters %.1f nodes %.1f trials %.2f solved %.3f"
+          % (tag, n, whole_problem.mean(), prof[:, 19].mean(), prof[:, 18].mean(), res["qp_iters"].mean(), res["nodes"].mean(), res["trials"].mean(), res["solved"].mean()))
+    denom = whole_problem.sum() + prof[:, 18].sum() + prof[:, 19].sum()
+    for k, (nm, v, c) in enumerate(zip(names, tot, cnt)):
+        if nm.startswith("(") or nm == "-":
+            continue
+        print("   %-36s %6.1f%%  %9.0f cyc/problem  %7.2f calls/problem  %7.0f cyc/call" % (nm, 100 * v / denom, v / n, c / n, v / max(c, 1)))
+    inner = prof[:, 2:12].sum(axis=1) + prof[:, 13] + prof[:, 16] + prof[:, 20] + prof[:, 21]
+    outside = whole_problem - search_total - prof[:, 0] - prof[:, 1] - prof[:, 14] - prof[:, 17]
+    print("   search() %.0f cyc/problem, of which outside its slots (stack bookkeeping, incumbent polls) %.0f; run_problem outside search / staging / dt / set-up / result write %.0f"
+          % (search_total.mean(), (search_total - inner).mean(), outside.mean()))
+    return denom / n
+
+
+if mode == "plain":
+    report("whole problems (plain launch)", ctx.solve_batch(whole, faces))
+else:
+    import torch
+    dev = "cuda:0"
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    safe_t = corridor.safe_templates(whole)
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    d_whole, d_faces, d_safe = to_dev(whole), to_dev(faces), to_dev(safe_t)
+    d_sf = torch.zeros_like(d_faces)
+    d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+    d_sr = torch.zeros_like(d_wr)
+    ctx.set_pair_margin(0.05)
+    for _ in range(2):
+        ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, 10, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(), d_sf.data_ptr(), d_sr.data_ptr())
+        ctx.sync()
+    ms = ctx.timing_read()
+    a = report("whole problems of the pairs", d_wr.cpu().numpy().view(abi.result_dtype).copy())
+    b = report("safe problems of the pairs", d_sr.cpu().numpy().view(abi.result_dtype).copy())
+    print("per pair: %.0f cycles in the slots; launches %s ms" % (a + b, [round(float(x), 3) for x in ms[-2:]]))

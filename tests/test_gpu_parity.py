@@ -196,15 +196,21 @@ def test_maximum_sizes(ctx, oracle):
     # (conflict-directed backjumping) while the oracle enumerates them: never more nodes, and most trees node for node (a
     # regression check on the node-state snapshots of the NVP = 48 instantiation; with sharing, pruning depends on when another
     # wavefront's incumbent arrives, so only the results are compared there)
+    # The child bound (fh_sched.child_bound, on by default) skips children that cannot hold a better leaf: switched off, the trees are
+    # the oracle's; switched on, never larger — and the results are the same bit for bit in all three runs.
     solo = capi.Context(0)
     par = abi.default_params()
     par["share"] = 0
     solo.set_params(par)
+    bounded = solo.solve_batch(pr, faces)
+    solo.set_sched(child_bound=0)
     alone = solo.solve_batch(pr, faces)
     solo.close()
     assert alone["nodes"].max() > 50 and np.all(alone["nodes"] <= ref["nodes"]) and (alone["nodes"] == ref["nodes"]).mean() > 0.5
+    assert np.all(bounded["nodes"] <= alone["nodes"]) and bounded["nodes"].sum() < 0.8 * alone["nodes"].sum()
     for f in ("solved", "trials", "status", "factor", "dt", "cost", "coeff", "assign"):
         assert np.array_equal(alone[f], got[f]), f
+        assert np.array_equal(bounded[f], got[f]), f
 
 
 def test_mixed_sizes_in_one_batch(ctx, oracle):

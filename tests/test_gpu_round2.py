@@ -454,7 +454,9 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
 
     ref = run(ctx)
     assert (ref[1]["solved"] == 1).mean() > 0.7
-    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0, "workgroups_per_cu": 5}   # (fh_set_sched: explicit fields, no environment)
+    # (fh_set_sched: explicit fields, no environment.  min_nodes 64: almost nothing is given to idle workgroups; child_bound 0: every
+    # child of a node is visited — the tree of the CPU oracle, about twice the nodes)
+    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0, "workgroups_per_cu": 5, "min_nodes": 64, "child_bound": 0}
     for k, v in variants.items():
         ctx.set_sched(**{k: v})
         try:
@@ -464,6 +466,8 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
         for a, b in zip(ref, got):
             for f in RESULT_FIELDS:
                 assert np.array_equal(a[f], b[f]), (k, f)
+        if k == "child_bound":  # the bound only removes nodes
+            assert got[0]["nodes"].sum() > 1.3 * ref[0]["nodes"].sum() and got[1]["nodes"].sum() > ref[1]["nodes"].sum()
     solo = capi.Context(0)
     par = abi.default_params()
     par["share"] = 0

@@ -765,11 +765,15 @@ def test_fast_safe_problems_follow_the_oracle_tree(oracle, n_seg, p_choices):
         shared.set_params(par)
         par["share"] = 0
         solo.set_params(par)
-        got, alone = shared.solve_batch(pr, faces), solo.solve_batch(pr, faces)
+        got, bounded = shared.solve_batch(pr, faces), solo.solve_batch(pr, faces)
+        solo.set_sched(child_bound=0)  # every child visited: the oracle's tree (the default skips children that cannot hold a better leaf)
+        alone = solo.solve_batch(pr, faces)
     finally:
         shared.close()
         solo.close()
     compare(alone, ref)
     assert np.all(alone["nodes"] <= ref["nodes"]) and (alone["nodes"] == ref["nodes"]).mean() > 0.5
+    assert np.all(bounded["nodes"] <= alone["nodes"]) and bounded["nodes"].sum() < alone["nodes"].sum()
     for f in ("solved", "trials", "status", "factor", "dt", "cost", "coeff", "assign"):
         assert np.array_equal(alone[f], got[f]), f
+        assert np.array_equal(bounded[f], got[f]), f
