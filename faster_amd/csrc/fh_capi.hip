@@ -98,11 +98,6 @@ __global__ void share_init_kernel(fh::ShareCtl* ctl, unsigned long long* seqs) {
   if (i < sizeof(fh::ShareCtl) / 4) reinterpret_cast<unsigned int*>(ctl)[i] = 0u;
 }
 
-// Batches of at least this many problems get their dt_initial values from prepare_kernel (one thread per problem) before the solve
-// kernel starts; smaller ones — a single genNewTraj() — compute them inside the solve kernel and save the extra launch.
-#ifndef FH_PREPARE_MIN
-#define FH_PREPARE_MIN 256
-#endif
 // One solve launch: NSEG selects the kernel instantiation, PAIRS the whole -> hand-off -> safe unit.
 template <int NSEG, bool PAIRS>
 static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face* d_faces, fh_result* d_results, fh::SolveArgs ka) {
@@ -184,12 +179,6 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   ctx->ctl_ready = false;  // (true again once the launch below has been issued: it resets the block when it ends)
   // big batches are started hardest corridors first (order_kernel); results do not depend on the order
   ka.order = nullptr;
-  ka.dt0 = nullptr;
-  const bool prepare = n >= FH_PREPARE_MIN;  // big batches: dt_initial of every problem by one thread each, before the solve kernel
-  if (prepare) {
-    if ((rc = ensure(ctx, 18, sizeof(double) * (size_t)n)) != FH_OK) return rc;
-    ka.dt0 = (const double*)ctx->d_buf[18];
-  }
   if (n >= 2048 && ctx->sched.launch_order) {
     const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 64) || !ctx->order_ready;
     ctx->order_ready = false;  // (true again once all three launches below have been issued: a failed launch must not leave dirty counters behind)
@@ -198,14 +187,10 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     int* order = counters + 64;
     if (fresh) FH_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 64, ctx->stream));  // afterwards the scatter kernel leaves them zeroed
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(fh::prepare_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters, (double*)ctx->d_buf[18]);
+    hipLaunchKernelGGL(fh::order_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters);
     hipLaunchKernelGGL(fh::order_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters, order);
     FH_HIP(hipGetLastError());
     ka.order = order;
-  } else if (prepare) {
-    hipLaunchKernelGGL(fh::prepare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_problems, n, (int*)nullptr,
-                       (double*)ctx->d_buf[18]);
-    FH_HIP(hipGetLastError());
   }
   hipEvent_t e0 = ctx->ev[ctx->ev_used], e1 = ctx->ev[ctx->ev_used + 1];
   FH_HIP(hipEventRecord(e0, ctx->stream));

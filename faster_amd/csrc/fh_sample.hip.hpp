@@ -18,7 +18,10 @@
 
 namespace fh {
 
-__device__ __forceinline__ int sample_count(const fh_problem& pr, const fh_result& rs) {
+// (PW / RW: anything with the members of fh_problem / fh_result that are used — the records in memory, or the views the fused pair
+// kernel builds from what its wavefront still holds in registers and LDS: ProblemView, ResultView)
+template <class PW, class RW>
+__device__ __forceinline__ int sample_count(const PW& pr, const RW& rs) {
   int size = (int)((double)((int)pr.n_seg) * rs.dt / pr.dc);  // :384
   return size < 2 ? 2 : size;                                  // :385
 }
@@ -119,11 +122,45 @@ __device__ __forceinline__ void glue_store(int32_t* p, int32_t v) {
 // sample i of fillX (solverGurobi.cpp:122-168) without running the clock: t = (i + 1) DC, segment = boundaries crossed (the
 // reference's `if (t > dt (interval + 1)) interval++` once per sample, DC <= dt / 2).  Used by the search for R only — where two
 // pieces meet they agree to rounding; the state that becomes x0 of the safe problem is evaluated with the reference's own clock.
-__device__ __forceinline__ void state_at(const fh_result& rw, int N, double DC, int i, int size, fh_state& s) {
+template <class RW>
+__device__ __forceinline__ void state_at(const RW& rw, int N, double DC, int i, int size, fh_state& s) {
   const double t = (double)(i + 1) * DC;
   int interval = (int)ceil(t / rw.dt) - 1;
   interval = interval < 0 ? 0 : (interval > N - 1 ? N - 1 : interval);
   eval_state(rw.coeff[interval], t - interval * rw.dt, i == size - 1, s);
+}
+// What the hand-off reads of a problem / a result, for a caller that holds them in registers and LDS (the fused pair kernel: the whole
+// problem has just been solved by this wavefront; reading its record and its result back from memory costs two dependent round trips)
+struct ProblemView {
+  int n_seg, n_poly, face_begin;
+  double dc, a_max;
+  double x0[3];
+  const int* face_off;  // [n_poly + 1]
+};
+struct ResultView {
+  int solved;
+  double dt;
+  const double (*coeff)[12];  // [n_seg][12], createVars order
+};
+// max over the wavefront (DPP row_shr 1/2/4/8, row_bcast 15/31; total in lane 63), any sign
+__device__ __forceinline__ double glue_wave_max(double v) {
+  auto step = [](double x, int ctrl_sel) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    const int nlo = __double2loint(-INFINITY), nhi = __double2hiint(-INFINITY);
+    switch (ctrl_sel) {
+      case 0: lo = __builtin_amdgcn_update_dpp(nlo, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(nhi, hi, 0x111, 0xf, 0xf, false); break;
+      case 1: lo = __builtin_amdgcn_update_dpp(nlo, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(nhi, hi, 0x112, 0xf, 0xf, false); break;
+      case 2: lo = __builtin_amdgcn_update_dpp(nlo, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(nhi, hi, 0x114, 0xf, 0xf, false); break;
+      case 3: lo = __builtin_amdgcn_update_dpp(nlo, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(nhi, hi, 0x118, 0xf, 0xf, false); break;
+      case 4: lo = __builtin_amdgcn_update_dpp(nlo, lo, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(nhi, hi, 0x142, 0xa, 0xf, false); break;
+      default: lo = __builtin_amdgcn_update_dpp(nlo, lo, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(nhi, hi, 0x143, 0xc, 0xf, false); break;
+    }
+    return __hiloint2double(hi, lo);
+  };
+#pragma unroll
+  for (int k = 0; k < 6; k++) v = fmax(v, step(v, k));
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
@@ -134,7 +171,8 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // Which sample of the whole trajectory is R (k_safe of Faster::replan): mode 0 sample (int)(r_frac * size); mode 1 FASTER's own rule —
 // findIndexH (faster.cpp:218-251) against the modelled unknown space, then findIndexR (:173-216).  Returns false when no safe
 // trajectory is needed (needToComputeSafePath == false, :462-466): k is then indexH = the last sample (:231).
-__device__ inline bool choose_r_index(const fh_problem& pw, const fh_result& rw, double r_frac, const fh_pair_rule& rule, int lane, int& k) {
+template <class PW, class RW>
+__device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac, const fh_pair_rule& rule, int lane, int& k) {
   const int N = pw.n_seg;
   const double DC = pw.dc;
   const int size = sample_count(pw, rw);
@@ -189,8 +227,8 @@ __device__ inline bool choose_r_index(const fh_problem& pw, const fh_result& rw,
   return true;
 }
 
-template <bool WT = false>
-__device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, const fh_face* wfaces, double r_frac, double shrink,
+template <bool WT = false, class PW = fh_problem, class RW = fh_result>
+__device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* wfaces, double r_frac, double shrink,
                                      int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane) {
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
     if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
@@ -220,23 +258,38 @@ __device__ inline void pair_glue_one(const fh_problem& pw, const fh_result& rw, 
   const bool keep_r = r_margin >= 0.0;
   const double test_shrink = keep_r ? 0.0 : shrink;  // which polytope holds R: the original one / the shrunk one
   const double slack_ok = keep_r ? 1e-7 : 0.0;       // R is a point of the whole trajectory: inside its polytope up to the solver tolerance
-  // first polytope that contains R, else the least violated one
+  // first polytope that contains R, else the least violated one.  Every face of the whole corridor is tested at once, lane = face
+  // (one memory round trip; a polytope after the other cost one each), then one maximum per polytope.
   const int P = pw.n_poly;
   const int fb = pw.face_begin;
+  const int nf = P ? pw.face_off[P] : 0;
+  double worst_p[FH_MAX_POLY];
+#pragma unroll
+  for (int p = 0; p < FH_MAX_POLY; p++) worst_p[p] = -INFINITY;
+  for (int f0 = 0; f0 < nf; f0 += 64) {
+    const int f = f0 + lane;
+    double v = -INFINITY;
+    int pf = -1;
+    if (f < nf) {
+      const fh_face fc = wfaces[fb + f];
+      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+      v = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - test_shrink * nr);
+      pf = 0;
+      for (int p = 1; p < P; p++) pf += (f >= pw.face_off[p]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int p = 0; p < FH_MAX_POLY; p++)
+      if (p < P) worst_p[p] = fmax(worst_p[p], glue_wave_max(pf == p ? v : -INFINITY));
+  }
   int start = 0;
   double best = INFINITY;
   bool found = false;
-  for (int p = 0; p < P && !found; p++) {
-    double worst = -INFINITY;
-    for (int f = pw.face_off[p] + lane; f < pw.face_off[p + 1]; f += 64) {
-      const fh_face fc = wfaces[fb + f];
-      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      worst = fmax(worst, fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - test_shrink * nr));
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
-    if (worst <= slack_ok) { start = p; found = true; }
-    else if (worst < best) { best = worst; start = p; }
+  for (int p = 0; p < FH_MAX_POLY; p++) {
+    if (p < P && !found) {
+      if (worst_p[p] <= slack_ok) { start = p; found = true; }
+      else if (worst_p[p] < best) { best = worst_p[p]; start = p; }
+    }
   }
   int cnt = P - start;
   if (cnt > max_safe_poly) cnt = max_safe_poly;

@@ -70,9 +70,22 @@ namespace fh {
 #endif
 // Tree levels (of a worker's own stack) whose snapshot tail — the parent's optimum, its multipliers and active row ids — and child
 // bounds stay in LDS instead of the HBM workspace: going back to a parent whose factor columns are still intact in LDS then costs two
-// LDS copies and no memory round trip.  N <= 10: two levels (almost every tree); the N = 15 / 16 carves have no LDS to spare.
+// LDS copies and no memory round trip.  N <= 6 only, where LDS does not limit the resident workgroups: at N = 10 two levels cost a
+// workgroup per CU (11 -> 10) and, measured, 3 % of the throughput — with the child bound a tree goes back to a parent 0.6 times per
+// problem and a restore is 4 k cycles; the N = 15 / 16 carves have no LDS to spare.
 #ifndef FH_TAIL_LEVELS
-#define FH_TAIL_LEVELS 2
+#define FH_TAIL_LEVELS 0
+#endif
+// Tickets are drawn FH_TICKET_CHUNK at a time while every workgroup still has that many ahead of it (then 2, then 1), and finished
+// units are reported FH_DONE_BATCH at a time: the ticket counter and the `done` counter are single words that every workgroup of the
+// launch hits with a device-scope atomic — once per unit each, that is 65 000 same-address atomics per 3.5 ms launch, one every
+// 50 ns, which is about what one address sustains: the wavefronts queued behind each other for ~15 us per unit (measured as a
+// 35 k-cycle "ticket" phase with nothing in it but one atomic and one load).
+#ifndef FH_TICKET_CHUNK
+#define FH_TICKET_CHUNK 4
+#endif
+#ifndef FH_DONE_BATCH
+#define FH_DONE_BATCH 4
 #endif
 #ifndef FH_TAIL_LEVELS_BIG
 #define FH_TAIL_LEVELS_BIG 0
@@ -243,9 +256,7 @@ __device__ inline double polish3(double c3, double c2, double c1, double c0, dou
 // the CPU oracle's sequential loops; the minimum over the positive roots and the maximum over the axes do not depend on the
 // order).  The double-precision cbrt / acos / cos behind a cubic are hundreds of instructions each: done once per wavefront
 // instead of once per axis and root, they are ~4 % instead of ~25 % of a typical problem.  0: no positive root.
-// (noinline: the solve kernels evaluate the candidates one per lane, the preparation kernel of a big batch — prepare_kernel — nine per
-// thread; both call THIS code, so a root is the same double wherever it was computed)
-__device__ __noinline__ double cubic_root_of_lane(double c3, double c2, double c1, double c0, int j) {
+__device__ inline double cubic_root_of_lane(double c3, double c2, double c1, double c0, int j) {
   const double B = c2 / c3, C = c1 / c3, D = c0 / c3;
   const double p = C - B * B / 3.0;
   const double q = 2.0 * B * B * B / 27.0 - B * C / 3.0 + D;
@@ -267,7 +278,7 @@ __device__ __noinline__ double cubic_root_of_lane(double c3, double c2, double c
   }
   return cand;
 }
-__device__ __noinline__ double quad_root_of_lane(double c2, double c1, double c0, int j) {
+__device__ inline double quad_root_of_lane(double c2, double c1, double c0, int j) {
   const double disc = c1 * c1 - 4.0 * c2 * c0;
   if (disc < 0) return (j == 0 && sqrt(-disc) / fabs(2.0 * c2) < 1e-12) ? -c1 / (2.0 * c2) : 0.0;
   const double s = sqrt(disc);
@@ -306,34 +317,6 @@ __device__ inline double dt_initial(const PR& pr, int lane) {
   return dt0;
 }
 
-// The same, all nine candidates by one thread (prepare_kernel: one thread per problem of a big batch, so that the solve kernel's
-// wavefronts — nine useful lanes of 64 in dt_initial — do not spend ~1500 instructions per problem on it).  Same candidate
-// functions, same casts, exact minima / maxima: the same double as dt_initial.
-template <class PR>
-__device__ inline double dt_initial_serial(const PR& pr) {
-  float mx = 0.f;
-  for (int i = 0; i < 3; i++) {
-    const double x0p = pr.x0[i], x0v = pr.x0[3 + i], x0a = pr.x0[6 + i], xfp = pr.xf[i];
-    const double dx = xfp - x0p;
-    const float tv = (float)(fabs(dx) / pr.v_max);
-    const float jerk = (float)(copysign(1.0, dx) * pr.j_max);
-    const float a0 = (float)x0a, v0 = (float)x0v;
-    const float acc = (float)(copysign(1.0, dx) * pr.a_max);
-    double bj = INFINITY, ba = INFINITY;
-    for (int j = 0; j < 3; j++) {
-      const double rj = cubic_root_of_lane((double)jerk / 6.0, (double)a0 / 2.0, (double)v0, -dx, j);
-      const double ra = quad_root_of_lane(0.5 * (double)acc, (double)v0, -dx, j);
-      bj = (rj > 0 && rj < bj) ? rj : bj;
-      ba = (ra > 0 && ra < ba) ? ra : ba;
-    }
-    const float tj = (float)(bj < INFINITY ? bj : 0.0), ta = (float)(ba < INFINITY ? ba : 0.0);
-    mx = fmaxf(mx, fmaxf(tv, fmaxf(ta, tj)));
-  }
-  double dt0 = (double)(mx / (float)pr.n_seg);
-  if (dt0 > 10000) dt0 = 0;
-  return dt0;
-}
-
 // -----------------------------------------------------------------------------------------------------------------
 template <int NSEG>
 struct Solver {
@@ -353,7 +336,7 @@ struct Solver {
   double *Q, *R;                                      // Q1 column major [NVP cols][S] (column c = active slot); R packed upper triangular [RPSZ]
   double *x, *z, *g, *d, *r, *u, *rinv;               // [NVP] x = the reduced unknowns y (r aliases d: only live inside the re-orthogonalisation pass)
   double *tcache, *tbnd;                              // [TC][SNAP_TAIL] snapshot tails and [TC][FH_MAX_POLY] child bounds of the first TC tree levels
-  static constexpr int TC = NSEG <= 10 ? FH_TAIL_LEVELS : FH_TAIL_LEVELS_BIG;
+  static constexpr int TC = NSEG <= 6 ? 2 : (NSEG <= 10 ? FH_TAIL_LEVELS : FH_TAIL_LEVELS_BIG);
   double* xs;                                         // [NXP] x-space scratch: Z y (compute_states), a row normal in x space (build_g)
   double* Zm;                                         // [NSEG][ZS] orthogonal basis of this N (fh_basis.hip.hpp), kept across problems
   double *Pc, *Vc, *Ac;                               // [NT*3] current states at segment starts
@@ -366,7 +349,9 @@ struct Solver {
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *stk_keep, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
-         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_WORDS = 18 };  // TB_WORK: active-set iterations of the unit in hand (reported with `done`);
+         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_WORDS = 26 };
+                                                                 // TB_NEXT / TB_NEXT + 1: this workgroup's own pool of tickets [next, end), drawn a chunk at a time (and ahead,
+                                                                 // during a hand-off, with the control words TB_NEXT_EI / TB_NEXT_WT read at the same time); TB_DONE_LOCAL lives in tb[TB_ZN + ...]  // TB_WORK: active-set iterations of the unit in hand (reported with `done`);
                                                                  // TB_ZN: the N whose basis is in Zm (0: none yet)
   signed char* stk_order;                             // [NSEG][FH_MAX_POLY] child order per tree level
 
@@ -1396,6 +1381,8 @@ struct Solver {
   int trace_src, trace_id, trace_it;
   double trace_v;
 #endif
+  int fin_solved;                      // of the problem run_problem finished last (the fused pair kernel's hand-off reads them and the
+  double fin_dt;                       //   coefficient table left in the LDS of Q instead of the result record in memory)
   unsigned conflict;                   // of the node just found infeasible
   unsigned allinf;                     // bit d: every child of stack frame d tried so far was infeasible (and none was given away)
 
@@ -1659,6 +1646,34 @@ struct Solver {
       remaining -= end - k0;
       end = k0;
       trial_end = k0;
+    }
+  }
+
+  // How many tickets the next draw takes: FH_TICKET_CHUNK while every workgroup of the launch still has that many units ahead of it,
+  // then 2, then 1 (the units a workgroup holds but has not started cannot be given away: the tail of a launch stays one unit deep)
+  static __device__ __forceinline__ int ticket_chunk(int n, int grid, int last_ticket) {
+    const long long left = (long long)n - (long long)last_ticket;
+    if (FH_TICKET_CHUNK >= 4 && left >= 4ll * FH_TICKET_CHUNK * (long long)grid / 4) return FH_TICKET_CHUNK;
+    if (FH_TICKET_CHUNK >= 2 && left >= 2ll * (long long)grid) return 2;
+    return 1;
+  }
+  // Units finished here are reported FH_DONE_BATCH at a time (one 8-byte add: count | iterations << 32); flush_done before waiting / leaving
+  __device__ __forceinline__ void unit_done(const ShareArgs& sa) {
+    if (lane == 0) {
+      const int nd = tb[TB_DONE_N] + 1;
+      const unsigned int it = (unsigned int)tb[TB_DONE_IT] + (unsigned int)min(tb[TB_WORK], 0xfffff);
+      if (nd >= FH_DONE_BATCH) {
+        aadd(reinterpret_cast<unsigned long long*>(&sa.ctl->done), (unsigned long long)(unsigned)nd | ((unsigned long long)min(it, 0xfffffffu) << 32));
+        tb[TB_DONE_N] = 0; tb[TB_DONE_IT] = 0;
+      } else {
+        tb[TB_DONE_N] = nd; tb[TB_DONE_IT] = (int)it;
+      }
+    }
+  }
+  __device__ __forceinline__ void flush_done(const ShareArgs& sa) {
+    if (lane == 0 && tb[TB_DONE_N] > 0) {
+      aadd(reinterpret_cast<unsigned long long*>(&sa.ctl->done), (unsigned long long)(unsigned)tb[TB_DONE_N] | ((unsigned long long)(unsigned)tb[TB_DONE_IT] << 32));
+      tb[TB_DONE_N] = 0; tb[TB_DONE_IT] = 0;
     }
   }
 
@@ -2159,8 +2174,9 @@ __device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
 template <int NSEG, class PR>
 __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
                             const fh_params& par, const ShareArgs& sa, const double* __restrict__ basis, double* __restrict__ ws, int entry,
-                            bool interrupted, fh_result& res, const double* dt0_ready) {
+                            bool interrupted, fh_result& res) {
   const int lane = sv.lane;
+  sv.fin_solved = 0;
 #ifdef FH_SHARE_PROFILE
   const unsigned long long sp_tp__ = wall_ticks();
 #endif
@@ -2253,12 +2269,18 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
 #ifdef FH_PROFILE
   sv.prof[0] = __builtin_readcyclecounter() - tstart__;
 #endif
-  // (a big batch comes with its dt_initial values: prepare_kernel wrote them before this launch started — a scalar load)
-  typedef const __attribute__((address_space(4))) double cdouble_t;
-  const double dt0 = dt0_ready ? *(cdouble_t*)sv.uniform_u64((unsigned long long)dt0_ready) : dt_initial(pr, lane);
+  const double dt0 = dt_initial(pr, lane);
   const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
 #ifdef FH_PROFILE
   sv.prof[14] = __builtin_readcyclecounter() - tstart__ - sv.prof[0]; sv.cnt[14] = 1;
+#ifdef FH_PROFILE_ICACHE  // the same code again, now warm in the instruction cache: how much of the first call was instruction fetch?
+  {
+    const unsigned long long t2__ = __builtin_readcyclecounter();
+    const double again = dt_initial(pr, opaque(lane));
+    if (again != dt0) sv.cnt[22] += 1000;
+    sv.prof[22] = __builtin_readcyclecounter() - t2__; sv.cnt[22] += 1;
+  }
+#endif
 #endif
   // entry 0: a fresh problem, from its first factor.  entry 1: a stack frame of the tree of trial tb[TB_TRIALS] - 1 taken from the
   // queue.  entry 2: the trials of the problem from number tb[TB_TRIALS] - 1 (factor tb[TB_F]) on, taken from the queue.
@@ -2389,7 +2411,10 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     if (!solved) continue;
 #endif
     res.coeff[t][rem] = v;
+    if (t < NSEG) sv.Q[idx] = v;  // (Q is free now; the hand-off of a pair evaluates R from this table: fin_solved, fin_dt)
   }
+  sv.fin_solved = solved ? 1 : 0;
+  sv.fin_dt = dt;
 #ifdef FH_PROFILE
   sv.prof[12] = __builtin_readcyclecounter() - tstart__;
   sv.prof[17] = __builtin_readcyclecounter() - tres__; sv.cnt[17] = 1;
@@ -2445,9 +2470,6 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
   // launch order: ticket t works on unit order[t] (null: t).  Results do not depend on it; the hardest corridors go first so that
   // their trees are not what the launch ends on (order_kernel)
   const int* order;
-  // dt_initial of problem i (getDTInitial), written by prepare_kernel before the launch; null: the solve kernel computes it (small
-  // batches, and always for the safe problem of a pair, whose initial state is only known once its whole problem is solved)
-  const double* dt0;
 };
 
 // Persistent workgroups (one wavefront each).  Every workgroup pulls fresh units from a device-scope ticket counter
@@ -2468,7 +2490,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
   sv.lane = threadIdx.x;
   sv.q = 0;
   sv.qe = 0;
-  if (threadIdx.x == 0) sv.tb[sv.TB_ZN] = 0;
+  if (threadIdx.x == 0) { sv.tb[sv.TB_ZN] = 0; sv.tb_put64(sv.TB_NEXT, 0ull); sv.tb[sv.TB_DONE_N] = 0; sv.tb[sv.TB_DONE_IT] = 0; }
   const ShareArgs& sa = ka.sa;
   double* ws = ka.workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   if (threadIdx.x == 0) {
@@ -2488,38 +2510,69 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
 #ifdef FH_PROFILE
     const unsigned long long tpre__ = __builtin_readcyclecounter();
 #endif
+    // Tickets come from the workgroup's own pool [TB_NEXT, TB_NEXT + 1): chunks of FH_TICKET_CHUNK drawn with ONE atomic, and — in a pair
+    // launch — drawn AHEAD, during the hand-off of the pair in hand, together with the control words of the block, so that those
+    // memory round trips overlap the hand-off's own instead of standing between two pairs.  The control words are up to a chunk
+    // old when they are used: a pending frame that is gone fails its compare-and-swap in take_task, a stop request is seen a few
+    // units later (the trees poll it themselves).
+    int pool_next = uniform_i32(sv.tb[sv.TB_NEXT]), pool_end = uniform_i32(sv.tb[sv.TB_NEXT + 1]);
+    bool frame_pending = true, fresh_words = false;
+    if (tickets_left && pool_next < pool_end) {
+      const unsigned long long wt = sv.tb_get64(sv.TB_NEXT_WT);
+      frame_pending = (int)((unsigned int)(wt >> 32) - (unsigned int)wt) > 0;
+    }
     // a frame of a hard problem comes before a fresh problem; without fresh problems the workgroup waits for frames
-    if (sa.enabled && (sa.backlog > 0 || !tickets_left)) entry = sv.take_task(sa, ws, !tickets_left);
+    if (sa.enabled && (sa.backlog > 0 || !tickets_left) && (frame_pending || !tickets_left)) {
+      if (!tickets_left) sv.flush_done(sa);  // (units this workgroup has finished but not yet reported: the waiting ends when all are)
+      entry = sv.take_task(sa, ws, !tickets_left);
+    }
     if (entry) {
       unit = uniform_i32(sv.tb[sv.TB_B]);
       phase = uniform_i32(sv.tb[sv.TB_PHASE]);
     } else if (!tickets_left) {
       break;  // every unit is done (or enough others are waiting, or sharing is off)
     } else {
-      unsigned int b = 0, intr = 0;
-      if (threadIdx.x == 0) {
-        b = (unsigned int)min(aadd(&sa.ctl->ticket, 1ull), (unsigned long long)ka.n);
-        {
-          const unsigned long long ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
-          intr = (unsigned int)ei | (unsigned int)(ei >> 32);
+      unsigned int intr = 0;
+      if (pool_next >= pool_end) {  // the pool is empty: draw a chunk now
+        unsigned long long b0 = 0ull, ei = 0ull, wt = 0ull;
+        const int ch = sv.ticket_chunk(ka.n, (int)gridDim.x, pool_end);
+        if (threadIdx.x == 0) {
+          b0 = aadd(&sa.ctl->ticket, (unsigned long long)ch);
+          ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
+          wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
+          sv.tb_put64(sv.TB_NEXT_EI, ei);
+          sv.tb_put64(sv.TB_NEXT_WT, wt);
         }
-        if (!intr && b < (unsigned)ka.n) {  // the host's stop word costs a PCIe read: one workgroup in 32 polls it, with every draw
+        b0 = sv.uniform_u64(b0);
+        pool_next = (int)min(b0, (unsigned long long)ka.n);
+        pool_end = (int)min(b0 + (unsigned long long)ch, (unsigned long long)ka.n);
+        fresh_words = true;
+      }
+      unsigned int b = (unsigned int)pool_next;
+      if (threadIdx.x == 0) {
+        sv.tb[sv.TB_NEXT] = pool_next + (pool_next < pool_end ? 1 : 0);
+        sv.tb[sv.TB_NEXT + 1] = pool_end;
+        const unsigned long long ei = ((unsigned long long)(unsigned)sv.tb[sv.TB_NEXT_EI + 1] << 32) | (unsigned)sv.tb[sv.TB_NEXT_EI];
+        intr = (unsigned int)ei | (unsigned int)(ei >> 32);
+        if (!intr && pool_next < pool_end) {  // the host's stop word costs a PCIe read: one workgroup in 32 polls it, with every draw
           const unsigned long long t_start = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
           if (sa.deadline_ticks && wall_ticks() - t_start > sa.deadline_ticks) intr = 2u;
           else if (sa.host_abort && (blockIdx.x & 31u) == 0u && __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) intr = 1u;
           if (intr) ast(&sa.ctl->interrupted, intr);
         }
       }
-      b = (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+      (void)fresh_words;
       interrupted = __builtin_amdgcn_readfirstlane((int)intr) != 0;
-      if (b >= (unsigned int)ka.n) {
+      if (pool_next >= pool_end) {  // (the chunk lay beyond the batch)
         tickets_left = false;
 #ifdef FH_SHARE_PROFILE
         sp_dry__ = wall_ticks();
 #endif
         continue;
       } else {
-        unit = ka.order ? ka.order[b] : (int)b;
+        // (the launch order was written by order_scatter_kernel before this launch began: a scalar load through the constant address space)
+        typedef const __attribute__((address_space(4))) int cint_t;
+        unit = ka.order ? *(cint_t*)sv.uniform_u64((unsigned long long)(ka.order + b)) : (int)b;
         if (threadIdx.x == 0) { sv.tb[sv.TB_B] = unit; sv.tb[sv.TB_PHASE] = 0; sv.tb[sv.TB_WORK] = 0; }
       }
     }
@@ -2544,8 +2597,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(phase ? &ka.safe[unit] : &problems[unit]));
         const fh_face* fcs = reinterpret_cast<const fh_face*>(sv.uniform_u64((unsigned long long)(phase ? ka.sfaces : faces)));
         fh_result* out = reinterpret_cast<fh_result*>(sv.uniform_u64((unsigned long long)(phase ? &ka.sres[unit] : &results[unit])));
-        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out,
-                                                    (phase == 0 && ka.dt0) ? ka.dt0 + unit : nullptr);
+        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out);
       }
       else {
         // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
@@ -2554,22 +2606,60 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
         typedef const __attribute__((address_space(4))) fh_problem const_problem;
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(problems + unit));  // (provably wave-uniform)
         finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
-                                                    results[unit], ka.dt0 ? ka.dt0 + unit : nullptr);
+                                                    results[unit]);
       }
       if (!finished) break;  // the unit continues in another workgroup
       if constexpr (PAIRS) {
         if (phase == 0) {
-          // the whole result was written by this wavefront (plain stores): drained, then read back by the hand-off
+          // The hand-off reads what this wavefront still holds — sizes and face offsets in registers / LDS, the coefficient table left
+          // in Q's LDS by run_problem, the scalars of the problem record through the scalar cache — not the result record it has just
+          // written (a drain of the stores and a read-back: two dependent memory round trips per pair).
 #ifdef FH_PROFILE
           const unsigned long long tglue__ = __builtin_readcyclecounter();
 #endif
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-          pair_glue_one<true>(problems[unit], results[unit], faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit],
-                              ka.sfaces, opaque((int)threadIdx.x));
+          unsigned long long ahead_b = 0ull, ahead_ei = 0ull, ahead_wt = 0ull;
+          const int pool_end_now = uniform_i32(sv.tb[sv.TB_NEXT + 1]);
+#ifdef FH_NO_AHEAD  // (A/B builds)
+          const bool draw_ahead = false;
+#else
+          const bool draw_ahead = tickets_left && uniform_i32(sv.tb[sv.TB_NEXT]) >= pool_end_now;
+#endif
+          const int ahead_ch = sv.ticket_chunk(ka.n, (int)gridDim.x, pool_end_now);
+          if (draw_ahead && threadIdx.x == 0) {  // issued here, stored after the hand-off's own drain below
+            ahead_b = aadd(&sa.ctl->ticket, (unsigned long long)ahead_ch);
+            ahead_ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
+            ahead_wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
+          }
+          {
+            typedef const __attribute__((address_space(4))) fh_problem const_problem;
+            const const_problem& pw = *(const_problem*)sv.uniform_u64((unsigned long long)&problems[unit]);
+            ProblemView pv;
+            pv.n_seg = sv.N; pv.n_poly = sv.P; pv.face_begin = pw.face_begin; pv.dc = pw.dc; pv.a_max = pw.a_max;
+            pv.x0[0] = pw.x0[0]; pv.x0[1] = pw.x0[1]; pv.x0[2] = pw.x0[2];
+            pv.face_off = sv.face_off;
+            ResultView rv;
+            rv.solved = sv.fin_solved; rv.dt = sv.fin_dt;
+            rv.coeff = reinterpret_cast<const double (*)[12]>(sv.Q);
+            FH_SYNC();
+            pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
+                                opaque((int)threadIdx.x));
+          }
           // the safe problem went out write-through and is drained: this wavefront reads its own stores back (a CU's L1 follows
           // that CU's stores; no agent-scope acquire here — it made every pair drop the CU's L1 and, measured, 0.5 GB of dirty
           // snapshot lines per launch leave L2); a workgroup that takes a frame of it later acquires in take_task
           drain_stores();
+          if (draw_ahead && threadIdx.x == 0) {
+            const unsigned long long nn = (unsigned long long)ka.n;
+            if (ahead_b < nn) {
+              sv.tb[sv.TB_NEXT] = (int)ahead_b;
+              sv.tb[sv.TB_NEXT + 1] = (int)min(ahead_b + (unsigned long long)ahead_ch, nn);
+            } else {  // beyond the batch: an empty pool at the end of the batch (the next draw finds the same and ends the tickets)
+              sv.tb[sv.TB_NEXT] = ka.n;
+              sv.tb[sv.TB_NEXT + 1] = ka.n;
+            }
+            sv.tb_put64(sv.TB_NEXT_EI, ahead_ei);
+            sv.tb_put64(sv.TB_NEXT_WT, ahead_wt);
+          }
 #ifdef FH_PROFILE
           sv.glue_cycles = __builtin_readcyclecounter() - tglue__;
 #endif
@@ -2579,10 +2669,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
           continue;
         }
       }
-      if (threadIdx.x == 0) {  // one more unit done, and what it cost (both words of one 8-byte add)
-        const unsigned long long it = (unsigned long long)(unsigned)sv.tb[sv.TB_WORK];
-        aadd(reinterpret_cast<unsigned long long*>(&sa.ctl->done), 1ull | (min(it, 0xfffffull) << 32));
-      }
+      sv.unit_done(sa);  // one more unit done, and what it cost
       break;
     }
   }
@@ -2593,6 +2680,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
   // ring sequence numbers i), after copying what the host wants to read.  No separate initialisation kernel per launch: on a
   // chip whose vector registers are all held by persistent workgroups of other launches, such a tiny kernel waited milliseconds
   // for a slot (rocprofv3: 12 ms average with 8 launches in flight), and a single genNewTraj() paid a second launch.
+  sv.flush_done(sa);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int last = 0;
   if (threadIdx.x == 0) last = aadd(&sa.ctl->exited, 1u) == gridDim.x - 1u ? 1 : 0;
@@ -2615,19 +2703,18 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
 // number of polytopes (C4: 52 active-set iterations per pair with 2, 320 with 6; 34 of the 41 hardest pairs in 4096 have 6), and a
 // hard tree that is started late is what a launch ends on.  The order inside a class is whatever the atomics give: no result
 // depends on it.
-// The same launch prepares the batch: thread i also computes dt_initial of problem i (dt0 != null), so that no wavefront of the
-// solve kernel has to (prepare: the histogram is skipped when counters == null — batches that are not reordered).
-__global__ void __launch_bounds__(256) prepare_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters,
-                                                      double* __restrict__ dt0) {
+__global__ void __launch_bounds__(256) order_hist_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters) {
   __shared__ int cnt[FH_MAX_POLY + 1];
   if (threadIdx.x <= FH_MAX_POLY) cnt[threadIdx.x] = 0;
   __syncthreads();
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i < n && counters) atomicAdd(&cnt[min(max(problems[i].n_poly, 0), FH_MAX_POLY)], 1);
-  if (i < n && dt0) dt0[i] = dt_initial_serial(problems[i]);
+  if (i < n) atomicAdd(&cnt[min(max(problems[i].n_poly, 0), FH_MAX_POLY)], 1);
   __syncthreads();
-  if (counters && threadIdx.x <= FH_MAX_POLY && cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]);
+  if (threadIdx.x <= FH_MAX_POLY && cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]);
 }
+// (Both order kernels fit into 8 vector registers: with three 168-register solve wavefronts on a SIMD that is exactly what is left, so
+// they slip in beside the persistent solve kernels of the other streams.  A version of the first one that also computed dt_initial of
+// every problem — 87 registers — had to wait for a solve wavefront to leave: the timed region of bench.py lost 12 %.)
 __global__ void __launch_bounds__(256) order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters,
                                                             int* __restrict__ order) {
   __shared__ int cnt[FH_MAX_POLY + 1], base[FH_MAX_POLY + 1];

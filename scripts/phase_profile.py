@@ -5,13 +5,15 @@ The C4 batch of bench.py (seed 3) through the fused pair kernel (default) or the
 launch carries its own cycle counters in the unused coefficient rows 12..15 (N <= 12)."""
 import os, sys
 import numpy as np
+import torch
+torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from faster_amd import abi, capi, corridor
 
 names = ["staging (record, faces, LDS init)", "setup_trial", "states+CP", "scan", "build_g", "project", "backsolve+ratio+update", "add_row",
          "drop_row", "analyze", "snap save", "snap restore", "(whole problem)", "screen_constant_rows", "dt_initial", "(search() in total)",
          "look-around + donations", "result write", "hand-off of the pair (glue)", "ticket + order fetch", "child order + bounds", "leaf bookkeeping",
-         "-", "-"]
+         "dt_initial again (warm I-cache)", "-"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 mode = sys.argv[2] if len(sys.argv) > 2 else "pairs"
 ctx = capi.Context(0)
