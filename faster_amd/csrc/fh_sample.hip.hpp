@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/fasterhip.h"
+#include "fh_clock.hpp"
 
 namespace fh {
 
@@ -229,7 +230,8 @@ __device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac,
 
 template <bool WT = false, class PW = fh_problem, class RW = fh_result>
 __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* wfaces, double r_frac, double shrink,
-                                     int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane) {
+                                     int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane,
+                                     unsigned long long* probe = nullptr) {  // probe: cycle stamps of a diagnostic build (null otherwise)
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
     if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
     return;
@@ -242,12 +244,11 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
     if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
     return;
   }
+  if (probe) probe[0] = __builtin_readcyclecounter();
   double t = 0;
   int interval = 0;
-  for (int i = 0; i <= k; i++) {  // the reference's clock (solverGurobi.cpp:131-135), wave-uniform
-    t = t + DC;
-    if (t > dt * (interval + 1)) interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
-  }
+  clock_at(k, DC, dt, N, t, interval);  // the reference's clock at sample k (solverGurobi.cpp:131-135) — its own double, not (k + 1) DC: fh_clock.hpp
+  if (probe) probe[1] = __builtin_readcyclecounter();
   fh_state R;
   eval_state(rw.coeff[interval], t - interval * dt, k == size - 1, R);
   if (lane < 3) {  // (selected, not indexed: an array indexed by the lane would live in scratch memory)
@@ -281,6 +282,7 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
     for (int p = 0; p < FH_MAX_POLY; p++)
       if (p < P) worst_p[p] = fmax(worst_p[p], glue_wave_max(pf == p ? v : -INFINITY));
   }
+  if (probe) probe[2] = __builtin_readcyclecounter();
   int start = 0;
   double best = INFINITY;
   bool found = false;
@@ -325,6 +327,7 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
       sfaces[fb + f] = fc;
     }
   }
+  if (probe) probe[3] = __builtin_readcyclecounter();
   if (lane <= FH_MAX_POLY) {
     const int p = lane < cnt ? lane : cnt;
     glue_store<WT>(&ps.face_off[lane], pw.face_off[start + p] - src0);

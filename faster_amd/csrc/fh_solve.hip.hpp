@@ -51,6 +51,12 @@ namespace fh {
 #endif
 // -DFH_PROFILE: per-phase cycle counters (s_memtime) accumulated per problem and written into the unused last
 // coefficient row of the result (diagnostic builds only; scripts/phase_profile.py).
+// a cycle stamp that the compiler does not move memory operations across (the kernel-loop probes of the diagnostic builds)
+__device__ __forceinline__ unsigned long long pinned_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
 #ifdef FH_PROFILE
 #define FH_T0() const unsigned long long t0__ = __builtin_readcyclecounter()
 #define FH_T1(slot) do { prof[slot] += __builtin_readcyclecounter() - t0__; cnt[slot] += 1; } while (0)
@@ -387,7 +393,9 @@ struct Solver {
 #ifdef FH_PROFILE
   unsigned long long prof[24];   // 0-15: see scripts/phase_profile.py; 16 look-around + donations, 17 result write, 18 hand-off of the pair (charged to
   unsigned int cnt[24];          // its safe problem), 19 ticket + launch order fetch (charged to the problem drawn), 20 child order + bounds, 21 leaf bookkeeping
-  unsigned long long pre_cycles, glue_cycles;  // measured in the kernel loop, charged to the next problem
+  unsigned long long take_cycles; unsigned int take_calls;  // take_task of a workgroup that still has tickets (is a frame pending?)
+  unsigned long long glue_parts[4];  // of the hand-off: before the clock, the clock loop, R + the polytope test (first memory wait), the face copy
+  unsigned long long pre_cycles, glue_cycles, drain_cycles;  // measured in the kernel loop, charged to the next problem
 #endif
   unsigned allowed_first, allowed_last;  // polytopes not excluded for segment 0 / N-1 by jerk-independent rows
   double h, tol, dep2;
@@ -2181,10 +2189,14 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
   const unsigned long long sp_tp__ = wall_ticks();
 #endif
 #ifdef FH_PROFILE
+  const unsigned long long tstart__ = pinned_clock();
   for (int i = 0; i < 24; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
   sv.prof[18] = sv.glue_cycles; sv.cnt[18] = sv.glue_cycles ? 1 : 0; sv.glue_cycles = 0;
   sv.prof[19] = sv.pre_cycles; sv.cnt[19] = sv.pre_cycles ? 1 : 0; sv.pre_cycles = 0;
-  const unsigned long long tstart__ = __builtin_readcyclecounter();
+  sv.prof[23] = sv.drain_cycles; sv.cnt[23] = sv.drain_cycles ? 1 : 0; sv.drain_cycles = 0;
+  sv.prof[22] = sv.take_cycles; sv.cnt[22] = sv.take_calls; sv.take_cycles = 0; sv.take_calls = 0;
+  const unsigned long long gp0__ = sv.glue_parts[0], gp1__ = sv.glue_parts[1], gp2__ = sv.glue_parts[2], gp3__ = sv.glue_parts[3];
+  sv.glue_parts[0] = sv.glue_parts[1] = sv.glue_parts[2] = sv.glue_parts[3] = 0;
 #endif
   if (entry == 0 && (interrupted || bad_input(pr, NSEG, max_faces))) {
     if (lane == 0) {
@@ -2267,12 +2279,12 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
   FH_SYNC();
 
 #ifdef FH_PROFILE
-  sv.prof[0] = __builtin_readcyclecounter() - tstart__;
+  sv.prof[0] = pinned_clock() - tstart__;
 #endif
   const double dt0 = dt_initial(pr, lane);
   const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
 #ifdef FH_PROFILE
-  sv.prof[14] = __builtin_readcyclecounter() - tstart__ - sv.prof[0]; sv.cnt[14] = 1;
+  sv.prof[14] = pinned_clock() - tstart__ - sv.prof[0]; sv.cnt[14] = 1;
 #ifdef FH_PROFILE_ICACHE  // the same code again, now warm in the instruction cache: how much of the first call was instruction fetch?
   {
     const unsigned long long t2__ = __builtin_readcyclecounter();
@@ -2385,7 +2397,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
   }
 
 #ifdef FH_PROFILE
-  const unsigned long long tres__ = __builtin_readcyclecounter();
+  const unsigned long long tres__ = pinned_clock();
 #endif
   if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
     FH_SYNC();
@@ -2410,14 +2422,25 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
 #ifdef FH_TRACE
     if (!solved) continue;
 #endif
+#ifdef FH_NT_RESULTS  // the record is written once and not read again by this launch (the hand-off of a pair reads the LDS copy below):
+    __builtin_nontemporal_store(v, &res.coeff[t][rem]);  // streamed past the L2 instead of evicting the lines the solves come back to
+#else
     res.coeff[t][rem] = v;
+#endif
     if (t < NSEG) sv.Q[idx] = v;  // (Q is free now; the hand-off of a pair evaluates R from this table: fin_solved, fin_dt)
   }
   sv.fin_solved = solved ? 1 : 0;
   sv.fin_dt = dt;
 #ifdef FH_PROFILE
-  sv.prof[12] = __builtin_readcyclecounter() - tstart__;
-  sv.prof[17] = __builtin_readcyclecounter() - tres__; sv.cnt[17] = 1;
+  sv.prof[17] = pinned_clock() - tres__; sv.cnt[17] = 1;
+#ifdef FH_PROFILE_DRAIN  // how long until the result stores of this problem are acknowledged (changes the timing of what follows)
+  {
+    const unsigned long long td__ = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sv.prof[22] = __builtin_readcyclecounter() - td__; sv.cnt[22] = 1;
+  }
+#endif
+  sv.prof[12] = pinned_clock() - tstart__;
   if (lane < 12 && sv.N <= FH_MAX_SEG - 4) {  // rows 15 / 14: cycles / calls of slots 0..11, rows 13 / 12: of slots 12..23
     unsigned long long pv = 0, pw = 0;
     unsigned int cv = 0, cw = 0;
@@ -2427,6 +2450,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     res.coeff[FH_MAX_SEG - 2][lane] = (double)cv;
     res.coeff[FH_MAX_SEG - 3][lane] = (double)pw;
     res.coeff[FH_MAX_SEG - 4][lane] = (double)cw;
+    if (lane < 4) res.coeff[FH_MAX_SEG - 5][lane] = (double)(lane == 0 ? gp0__ : (lane == 1 ? gp1__ : (lane == 2 ? gp2__ : gp3__)));
   }
 #endif
 #ifdef FH_SHARE_PROFILE
@@ -2502,13 +2526,14 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
   unsigned long long sp_dry__ = 0;
 #endif
 #ifdef FH_PROFILE
-  sv.pre_cycles = 0; sv.glue_cycles = 0;
+  sv.pre_cycles = 0; sv.glue_cycles = 0; sv.drain_cycles = 0; sv.take_cycles = 0; sv.take_calls = 0;
+  sv.glue_parts[0] = sv.glue_parts[1] = sv.glue_parts[2] = sv.glue_parts[3] = 0;
 #endif
   for (;;) {
     int entry = 0, unit = 0, phase = 0;
     bool interrupted = false;
 #ifdef FH_PROFILE
-    const unsigned long long tpre__ = __builtin_readcyclecounter();
+    const unsigned long long tpre__ = pinned_clock();
 #endif
     // Tickets come from the workgroup's own pool [TB_NEXT, TB_NEXT + 1): chunks of FH_TICKET_CHUNK drawn with ONE atomic, and — in a pair
     // launch — drawn AHEAD, during the hand-off of the pair in hand, together with the control words of the block, so that those
@@ -2524,7 +2549,13 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
     // a frame of a hard problem comes before a fresh problem; without fresh problems the workgroup waits for frames
     if (sa.enabled && (sa.backlog > 0 || !tickets_left) && (frame_pending || !tickets_left)) {
       if (!tickets_left) sv.flush_done(sa);  // (units this workgroup has finished but not yet reported: the waiting ends when all are)
+#ifdef FH_PROFILE
+      const unsigned long long ttake__ = pinned_clock();
+#endif
       entry = sv.take_task(sa, ws, !tickets_left);
+#ifdef FH_PROFILE
+      if (tickets_left) { sv.take_cycles += pinned_clock() - ttake__; sv.take_calls += 1; }
+#endif
     }
     if (entry) {
       unit = uniform_i32(sv.tb[sv.TB_B]);
@@ -2583,7 +2614,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
     phase = uniform_i32(phase);
     interrupted = uniform_i32(interrupted ? 1 : 0) != 0;
 #ifdef FH_PROFILE
-    if (!entry) sv.pre_cycles = __builtin_readcyclecounter() - tpre__;
+    if (!entry) sv.pre_cycles = pinned_clock() - tpre__;
 #endif
     for (;;) {  // the problems of the unit (a pair has two)
       bool finished;
@@ -2615,7 +2646,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
           // in Q's LDS by run_problem, the scalars of the problem record through the scalar cache — not the result record it has just
           // written (a drain of the stores and a read-back: two dependent memory round trips per pair).
 #ifdef FH_PROFILE
-          const unsigned long long tglue__ = __builtin_readcyclecounter();
+          const unsigned long long tglue__ = pinned_clock();
 #endif
           unsigned long long ahead_b = 0ull, ahead_ei = 0ull, ahead_wt = 0ull;
           const int pool_end_now = uniform_i32(sv.tb[sv.TB_NEXT + 1]);
@@ -2641,13 +2672,29 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
             rv.solved = sv.fin_solved; rv.dt = sv.fin_dt;
             rv.coeff = reinterpret_cast<const double (*)[12]>(sv.Q);
             FH_SYNC();
+#ifdef FH_PROFILE
+            unsigned long long probe[4] = {0ull, 0ull, 0ull, 0ull};
+            pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
+                                opaque((int)threadIdx.x), probe);
+            if (probe[0]) {
+              sv.glue_parts[0] = probe[0] - tglue__; sv.glue_parts[1] = probe[1] - probe[0]; sv.glue_parts[2] = probe[2] - probe[1];
+              sv.glue_parts[3] = probe[3] - probe[2];
+            }
+#else
             pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
                                 opaque((int)threadIdx.x));
+#endif
           }
           // the safe problem went out write-through and is drained: this wavefront reads its own stores back (a CU's L1 follows
           // that CU's stores; no agent-scope acquire here — it made every pair drop the CU's L1 and, measured, 0.5 GB of dirty
           // snapshot lines per launch leave L2); a workgroup that takes a frame of it later acquires in take_task
+#ifdef FH_PROFILE
+          const unsigned long long tdrain__ = __builtin_readcyclecounter();
+#endif
           drain_stores();
+#ifdef FH_PROFILE
+          sv.drain_cycles = __builtin_readcyclecounter() - tdrain__;
+#endif
           if (draw_ahead && threadIdx.x == 0) {
             const unsigned long long nn = (unsigned long long)ka.n;
             if (ahead_b < nn) {
@@ -2661,7 +2708,7 @@ __global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_p
             sv.tb_put64(sv.TB_NEXT_WT, ahead_wt);
           }
 #ifdef FH_PROFILE
-          sv.glue_cycles = __builtin_readcyclecounter() - tglue__;
+          sv.glue_cycles = pinned_clock() - tglue__;
 #endif
           phase = 1;
           entry = 0;

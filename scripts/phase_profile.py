@@ -13,7 +13,7 @@ from faster_amd import abi, capi, corridor
 names = ["staging (record, faces, LDS init)", "setup_trial", "states+CP", "scan", "build_g", "project", "backsolve+ratio+update", "add_row",
          "drop_row", "analyze", "snap save", "snap restore", "(whole problem)", "screen_constant_rows", "dt_initial", "(search() in total)",
          "look-around + donations", "result write", "hand-off of the pair (glue)", "ticket + order fetch", "child order + bounds", "leaf bookkeeping",
-         "dt_initial again (warm I-cache)", "-"]
+         "  of ticket: take_task (a frame pending?)", "  of the hand-off: drain of its stores"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 mode = sys.argv[2] if len(sys.argv) > 2 else "pairs"
 ctx = capi.Context(0)
@@ -38,6 +38,9 @@ def report(tag, res):
         if nm.startswith("(") or nm == "-":
             continue
         print("   %-36s %6.1f%%  %9.0f cyc/problem  %7.2f calls/problem  %7.0f cyc/call" % (nm, 100 * v / denom, v / n, c / n, v / max(c, 1)))
+    gp = res["coeff"][:, M - 5, :4].mean(axis=0)
+    if gp.sum() > 0:
+        print("   hand-off parts (cycles per pair): up to the clock %.0f | the clock loop %.0f | R, face load + polytope test %.0f | face copy %.0f" % tuple(gp))
     inner = prof[:, 2:12].sum(axis=1) + prof[:, 13] + prof[:, 16] + prof[:, 20] + prof[:, 21]
     outside = whole_problem - search_total - prof[:, 0] - prof[:, 1] - prof[:, 14] - prof[:, 17]
     print("   search() %.0f cyc/problem, of which outside its slots (stack bookkeeping, incumbent polls) %.0f; run_problem outside search / staging / dt / set-up / result write %.0f"

@@ -17,3 +17,18 @@ def test_basis_tables():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:]
     assert int(r.stdout.split()[1]) > 10000
+
+
+def test_sample_clock_short_cut_equals_the_loop():
+    """faster_amd/csrc/fh_clock.hpp: the reference's sample clock `t = t + DC` (fillX, solverGurobi.cpp:131-135) evaluated a binade at a
+    time — the same double and the same interval as the loop, for the reference's DC and for step sizes with every mantissa length
+    (tests/cpp/test_clock.cpp; with and without fused multiply-adds: every intermediate is an exact integer, so contraction cannot matter)."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_clock.cpp")
+    hdr = os.path.join(ROOT, "faster_amd", "csrc", "fh_clock.hpp")
+    for flags in (["-ffp-contract=off"], ["-ffp-contract=fast", "-mfma"]):
+        exe = os.path.join(ROOT, "tests", "cpp", "test_clock")
+        subprocess.check_call(["g++", "-O2", "-std=c++14"] + flags + [src, "-o", exe])
+        r = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+        assert int(r.stdout.split()[0]) > 500000
+    assert os.path.getsize(hdr) > 0
