@@ -7,12 +7,21 @@
 //   state:              pos, vel, accel, jerk (3-vectors with x()/y()/z()), yaw, dyaw, setPos/setVel/setAccel/
 //                       setJerk/setZero                                   (faster_types.hpp:79-149)
 //   LinearConstraint3D: A() (F x 3), b() (F), inside(pt)                  (DecompUtil polyhedron.h:115-185)
-// When FASTER is built with its real dependencies, define FASTER_HIP_USE_REFERENCE_TYPES and include the
-// reference headers before solver_hip.hpp instead.
+// When FASTER is built with its real dependencies, define FASTER_HIP_USE_REFERENCE_TYPES: this header then
+// includes the reference's own headers — faster_types.hpp (which expects Eigen and the standard containers to be included before it)
+// and DecompUtil's polyhedron.h — instead of defining the stand-ins, so that solver_hip.cpp compiles as a translation unit of its
+// own against FASTER's types (tests/test_host_class.py::test_reference_types_build_round_trip does exactly that).
 #pragma once
 #include <cmath>
 #include <cstddef>
 #include <vector>
+#ifdef FASTER_HIP_USE_REFERENCE_TYPES
+#include <Eigen/Dense>
+#include <iostream>
+#include <string>
+#include <decomp_geometry/polyhedron.h>
+#include "faster_types.hpp"
+#endif
 
 namespace fhstub {
 

@@ -209,3 +209,45 @@ def test_jps_hip_equals_host_search(tmp_path):
     r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "JPS_OK 256" in r.stdout and int(r.stdout.split()[-1]) > 240
+
+
+def test_reference_types_build_round_trip(tmp_path, oracle, fixture_corridor):
+    """INTEGRATION.md §1 prescribes -DFASTER_HIP_USE_REFERENCE_TYPES: SolverHip against FASTER's own `state`
+    (faster/include/faster_types.hpp:79-165) and DecompUtil's LinearConstraint3D (decomp_geometry/polyhedron.h:115-185), included where
+    they lie under /root/reference (Eigen through the test-only shim).  Compiles solver_hip.cpp that way and drives one replan's calls
+    — setX0 / setXf / setPolytopes / genNewTraj / fillX — with the C-ABI calls answered by the CPU oracle: known answer KA-1.
+    Skipped where /root/reference is absent (the GPU box)."""
+    ref = os.environ.get("FASTER_REFERENCE", "/root/reference")
+    inc_types = os.path.join(ref, "faster", "include")
+    inc_decomp = os.path.join(ref, "thirdparty", "DecompROS", "DecompUtil", "include")
+    if not (os.path.exists(os.path.join(inc_types, "faster_types.hpp")) and os.path.isdir(inc_decomp)):
+        pytest.skip("the reference sources are not present")
+    from oracle import oracle as orc
+
+    exe = str(tmp_path / "test_reference_types")
+    host = os.path.join(ROOT, "faster_amd", "host")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-DFASTER_HIP_USE_REFERENCE_TYPES",
+                           "-I", os.path.join(ROOT, "oracle", "ref_frontend", "shim"), "-I", inc_types, "-I", inc_decomp,
+                           "-I", os.path.join(ROOT, "include"), "-I", host, "-I", os.path.join(ROOT, "tests", "cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "test_reference_types.cpp"), os.path.join(host, "solver_hip.cpp"),
+                           "-o", exe, "-L", os.path.join(ROOT, "faster_amd"), "-lfasterhip", "-ldl",
+                           "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
+    fx = fixture_corridor
+    sc = tmp_path / "fixture.txt"
+    lines = [" ".join(repr(float(v)) for v in list(fx["x0"][:3]) + list(fx["xf"][:3])), str(len(fx["polytopes"]))]
+    for p in fx["polytopes"]:
+        lines.append(str(len(p["b"])))
+        for a, b in zip(p["A"], p["b"]):
+            lines.append("%r %r %r %r" % (float(a[0]), float(a[1]), float(a[2]), float(b)))
+    sc.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, orc.build(), str(sc)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["geometry"] == 1
+    assert out["solved"] == 1 and out["trials"] == 3 and out["factor"] == 3.0
+    assert out["dt"] == 0.7348469495773315
+    assert out["cost"] == pytest.approx(23.869158339522752, rel=1e-9)
+    assert out["n"] == int(10 * out["dt"] / 0.01)
+    np.testing.assert_allclose(out["first"], [p + 0.0 for p in fx["x0"][:3]], atol=1e-4)
+    np.testing.assert_allclose(out["last"], fx["xf"][:3], atol=1e-6)
+    assert out["last_vel_norm"] == 0.0
