@@ -467,7 +467,10 @@ def main():
                                                      out["roofline"]["solo"]["step_ms_median"], elapsed / args.steps, to_dev)
             out["e2e_with_copies"] = e2e_leg(torch, dev, pipes[0], whole, faces, safe_t, B, N, max_faces)
             if args.workload == "c4":
-                out["config"]["safe_solved_frac_literal_8d"] = literal_leg(make_pipe, run_step, fused, abi, B)
+                lit_frac, lit_rate = literal_leg(torch, make_pipe, run_step, fused, abi, B, inflight=len(pipes))
+                out["config"]["safe_solved_frac_literal_8d"] = lit_frac
+                out["config"]["pairs_per_s_literal_8d"] = lit_rate
+                out["single_replan_latency_ms"] = latency_leg(whole, faces)
                 out["c5"] = c5_leg(torch, dev, local_rank, par, args.r_margin)
                 out["replan_faithful"] = replan_leg(torch, dev, local_rank, par)
         if not args.no_cpu and world == 1:  # the CPU baseline is a property of the host: reported at N=1 only
@@ -831,14 +834,54 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
                                                     "infeasible for every factor — problems FASTER never poses"}}
 
 
-def literal_leg(make_pipe, run_step, fused, abi, B):
-    """The same step with the hand-off of SURVEY.md 8(d) taken to the letter (R may lie outside its shrunk corridor)."""
-    pp = make_pipe(-1.0)
-    run_step(pp, fused)
-    pp.ctx.sync()
-    frac = float(pp.d_sres.cpu().numpy().view(abi.result_dtype)[:B]["solved"].mean())
-    pp.ctx.close()
-    return frac
+def literal_leg(torch, make_pipe, run_step, fused, abi, B, inflight=8, steps=32):
+    """The same step with the hand-off of SURVEY.md 8(d) taken to the letter (R may lie outside its shrunk corridor): the solved
+    fraction of the safe problems, and the throughput of that variant measured like the timed region (`inflight` pipelines, `steps`
+    steps; more of its safe problems are infeasible for every factor, i.e. run all ten trials)."""
+    pipes = [make_pipe(-1.0) for _ in range(inflight)]
+    for pp in pipes:
+        run_step(pp, fused)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for k in range(steps):
+        run_step(pipes[k % inflight], fused)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    frac = float(pipes[0].d_sres.cpu().numpy().view(abi.result_dtype)[:B]["solved"].mean())
+    for pp in pipes:
+        pp.ctx.close()
+    return frac, B * steps / dt
+
+
+def latency_leg(whole, faces, reps=200):
+    """One replan at a time through the C++ class of the boundary is what FASTER itself does (SolverHip::genNewTraj, batch of 1:
+    tests/cpp/test_solver_hip.cpp); here the same single-problem launch through the C ABI's host-pointer entry point — H2D of one
+    problem record and its faces, one launch, D2H of one result — for `reps` different whole problems of the batch, one after the
+    other.  The reference's replan period is 10 ms (faster.yaml:5)."""
+    import numpy as np
+
+    from faster_amd import capi
+
+    ctx = capi.Context(0)
+    ms, solved = [], 0
+    try:
+        for i in range(reps + 8):
+            pr = whole[i: i + 1].copy()
+            nf = int(pr["face_off"][0][pr["n_poly"][0]])
+            fc = faces[int(pr["face_begin"][0]): int(pr["face_begin"][0]) + nf].copy()
+            pr["face_begin"] = 0
+            t = time.perf_counter()
+            r = ctx.solve_batch(pr, fc)
+            if i >= 8:
+                ms.append(1e3 * (time.perf_counter() - t))
+                solved += int(r["solved"][0])
+    finally:
+        ctx.close()
+    ms = np.array(ms)
+    return {"median_ms": float(np.median(ms)), "p95_ms": float(np.percentile(ms, 95)), "max_ms": float(ms.max()), "replans": int(len(ms)),
+            "solved": solved, "replan_period_of_the_reference_ms": 10.0,
+            "note": "fh_solve_batch with ONE whole problem (N=10, <=6 polytopes) per call, host pointers: copies, launch and synchronisation "
+                    "included; the batch entry points exist for throughput, this is the latency a single SolverHip::genNewTraj() sees"}
 
 
 def cpu_baseline(whole, faces, safe, sfaces, target_s):

@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
-    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule",
+    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule", "fh_set_unknown_grid_device",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_corridor_problems_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
@@ -102,6 +102,8 @@ def lib():
         L.fh_set_pair_margin.argtypes = [vp, f64]
         L.fh_set_pair_rule.restype = i32
         L.fh_set_pair_rule.argtypes = [vp, vp]
+        L.fh_set_unknown_grid_device.restype = i32
+        L.fh_set_unknown_grid_device.argtypes = [vp, vp, vp]
         L.fh_packed_result_size.restype = ctypes.c_size_t
         L.fh_packed_result_size.argtypes = [i32]
         L.fh_pack_results_device.restype = i32
@@ -399,10 +401,23 @@ class Context:
         self._check(lib().fh_set_pair_margin(self._h, float(r_margin)), "fh_set_pair_margin")
 
     def set_pair_rule(self, mode=0, r_known=0.0, drone_radius=0.0, delta_h=1.0, delta_a=0.5):
-        """fh_set_pair_rule: mode 0 = R at the fraction r_frac of the whole trajectory; 1 = FASTER's findIndexH / findIndexR."""
+        """fh_set_pair_rule: mode 0 = R at the fraction r_frac of the whole trajectory; 1 = FASTER's findIndexH / findIndexR against
+        modelled unknown space (farther than r_known from the start); 2 = the same against the unknown voxels given with
+        set_unknown_grid_device (unknown space as an input)."""
         r = np.zeros(1, dtype=abi.pair_rule_dtype)
         r["mode"], r["r_known"], r["drone_radius"], r["delta_h"], r["delta_a"] = mode, r_known, drone_radius, delta_h, delta_a
         self._check(lib().fh_set_pair_rule(self._h, abi.ptr(r)), "fh_set_pair_rule")
+
+    def set_unknown_grid_device(self, d_flags, origin=None, res=None, dims=None):
+        """fh_set_unknown_grid_device: the mapper's unknown voxels (rule mode 2): device pointer to dims[0] * dims[1] * dims[2] bytes, x
+        fastest, non-zero = unknown; cell centres (i + 0.5) res + origin.  d_flags = None: no unknown grid."""
+        if d_flags is None:
+            self._check(lib().fh_set_unknown_grid_device(self._h, None, None), "fh_set_unknown_grid_device")
+            return
+        g = np.zeros((), dtype=abi.voxel_grid_dtype)
+        g["origin"], g["res"], g["dims"] = origin, res, dims
+        g = np.ascontiguousarray(g).reshape(1)
+        self._check(lib().fh_set_unknown_grid_device(self._h, abi.ptr(g), d_flags), "fh_set_unknown_grid_device")
 
     def pack_results_device(self, d_results, n, n_seg, d_packed):
         """fh_pack_results_device: n fh_result records -> n packed records of packed_result_size(n_seg) bytes (device pointers)."""

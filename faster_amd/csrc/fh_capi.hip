@@ -45,6 +45,7 @@ struct fh_ctx {
   unsigned int* h_report = nullptr;         // pinned: the control block's report words of the last launch (copied with the results)
   double pair_margin = -1.0;                // fh_set_pair_margin
   fh_pair_rule pair_rule = {0, 0, 0.0, 0.0, 1.0, 0.5};  // fh_set_pair_rule
+  fh::UnknownGrid unknown = {nullptr, 0.0, 0.0, 0.0, 1.0, 0, 0, 0, 0};  // fh_set_unknown_grid_device (rule mode 2); the flags belong to the caller
   bool ctl_ready = false;                   // the device-side control block is in its initial state (left so by the previous launch)
   bool launched = false;                    // a solve launch has been issued since the control block was last checked
   int last_grid = 0;
@@ -398,9 +399,24 @@ int fh_set_pair_margin(fh_ctx* ctx, double r_margin) {
 
 int fh_set_pair_rule(fh_ctx* ctx, const fh_pair_rule* rule) {
   if (!ctx || !rule) return FH_ERR_ARG;
-  if (rule->mode != 0 && rule->mode != 1) return FH_ERR_ARG;
+  if (rule->mode != 0 && rule->mode != 1 && rule->mode != 2) return FH_ERR_ARG;
   if (rule->mode == 1 && (!(rule->r_known > 0) || !(rule->drone_radius >= 0) || !(rule->delta_h > 0) || !(rule->delta_a > 0))) return FH_ERR_ARG;
+  if (rule->mode == 2 && (!(rule->drone_radius > 0) || !(rule->delta_h > 0) || !(rule->delta_a > 0))) return FH_ERR_ARG;
   ctx->pair_rule = *rule;
+  return FH_OK;
+}
+
+int fh_set_unknown_grid_device(fh_ctx* ctx, const fh_voxel_grid* grid, const unsigned char* d_flags) {
+  if (!ctx) return FH_ERR_ARG;
+  if (!d_flags) {  // none: rule mode 2 is refused until a grid is set again
+    ctx->unknown.flags = nullptr;
+    return FH_OK;
+  }
+  if (!grid || !(grid->res > 0) || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1) return FH_ERR_ARG;
+  if ((long long)grid->dims[0] * grid->dims[1] * grid->dims[2] > (1ll << 30)) return FH_ERR_ARG;
+  ctx->unknown.flags = d_flags;
+  ctx->unknown.ox = grid->origin[0]; ctx->unknown.oy = grid->origin[1]; ctx->unknown.oz = grid->origin[2]; ctx->unknown.res = grid->res;
+  ctx->unknown.nx = grid->dims[0]; ctx->unknown.ny = grid->dims[1]; ctx->unknown.nz = grid->dims[2];
   return FH_OK;
 }
 
@@ -709,8 +725,12 @@ int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result*
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
+  if (ctx->pair_rule.mode == 2 && !ctx->unknown.flags) {
+    ctx->err = "fh_pair_rule mode 2 needs the unknown voxels: fh_set_unknown_grid_device";
+    return FH_ERR_ARG;
+  }
   hipLaunchKernelGGL(fh::pair_glue_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole,
-                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, ctx->pair_margin, ctx->pair_rule, d_safe, d_safe_faces);
+                     d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, ctx->pair_margin, ctx->pair_rule, d_safe, d_safe_faces, ctx->unknown);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
@@ -723,8 +743,12 @@ int fh_append_plans_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_resu
   DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe || !d_safe_results || !d_counts || (max_states > 0 && !d_plans)) return FH_ERR_ARG;
+  if (ctx->pair_rule.mode == 2 && !ctx->unknown.flags) {
+    ctx->err = "fh_pair_rule mode 2 needs the unknown voxels: fh_set_unknown_grid_device";
+    return FH_ERR_ARG;
+  }
   hipLaunchKernelGGL(fh::plan_append_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole, d_whole_results, d_safe, d_safe_results, n,
-                     r_frac, ctx->pair_rule, max_states, d_plans, d_counts, d_k_safe);
+                     r_frac, ctx->pair_rule, max_states, d_plans, d_counts, d_k_safe, ctx->unknown);
   FH_HIP(hipGetLastError());
   return FH_OK;
 }
@@ -738,6 +762,11 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe || !d_safe_results) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
+  if (ctx->pair_rule.mode == 2) {  // the fused kernel's hand-off knows the modelled unknown space only (rule modes 0 and 1)
+    ctx->err = "fh_solve_pairs_device: fh_pair_rule mode 2 (unknown voxels as an input) runs as stages: fh_solve_batch_device, "
+               "fh_safe_corridor_batch_device or fh_pair_glue_device, fh_solve_batch_device, fh_append_plans_device";
+    return FH_ERR_ARG;
+  }
   if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
   if (max_faces <= 0 || max_faces > FH_MAX_FACES) max_faces = FH_MAX_FACES;
   max_faces = (max_faces + 7) & ~7;
@@ -953,6 +982,10 @@ int fh_safe_corridor_batch_device(fh_ctx* ctx, const fh_problem* d_whole, const 
   DeviceScope device_scope(ctx);
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_paths || !d_n_points || !d_goals || !d_safe || !d_safe_faces || (n_cloud > 0 && !d_cloud_xyz)) return FH_ERR_ARG;
+  if (ctx->pair_rule.mode == 2 && !ctx->unknown.flags) {
+    ctx->err = "fh_pair_rule mode 2 needs the unknown voxels: fh_set_unknown_grid_device";
+    return FH_ERR_ARG;
+  }
   if ((size_t)n * (size_t)faces_per_problem > (size_t)0x7fffffff) return FH_ERR_ARG;
   const int mp = max_poly_safe + 1;
   const size_t nseg = (size_t)n * max_poly_safe;
@@ -971,7 +1004,7 @@ int fh_safe_corridor_batch_device(fh_ctx* ctx, const fh_problem* d_whole, const 
   int32_t* w_npoly = (int32_t*)(base + o_np);
   int32_t* w_np = d_safe_n_points ? d_safe_n_points : (int32_t*)(base + o_cnt);
   hipLaunchKernelGGL(fh::safe_path_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, d_whole, d_whole_results, d_paths, d_n_points, n, max_points,
-                     r_frac, ctx->pair_rule, max_poly_safe, d_safe, w_paths, w_np, w_sph);
+                     r_frac, ctx->pair_rule, max_poly_safe, d_safe, w_paths, w_np, w_sph, ctx->unknown);
   hipLaunchKernelGGL(fh::safe_spheres_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, ctx->stream, w_sph, n, max_poly_safe,
                      (double*)ctx->d_buf[17]);
   FH_HIP(hipGetLastError());
@@ -985,6 +1018,12 @@ int fh_safe_corridor_batch_device(fh_ctx* ctx, const fh_problem* d_whole, const 
   fh::UnknownLattice lat;
   lat.ox = grid->origin[0]; lat.oy = grid->origin[1]; lat.oz = grid->origin[2]; lat.res = grid->res;
   lat.nx = grid->dims[0]; lat.ny = grid->dims[1]; lat.nz = grid->dims[2]; lat.on = 1;
+  lat.flags = nullptr;
+  if (ctx->pair_rule.mode == 2) {  // the caller's unknown voxels (the lattice of THAT grid), not the sphere model
+    lat.ox = ctx->unknown.ox; lat.oy = ctx->unknown.oy; lat.oz = ctx->unknown.oz; lat.res = ctx->unknown.res;
+    lat.nx = ctx->unknown.nx; lat.ny = ctx->unknown.ny; lat.nz = ctx->unknown.nz;
+    lat.flags = ctx->unknown.flags;
+  }
   if ((rc = decompose_device(ctx, d_cloud_xyz, n_cloud, (const double*)ctx->d_buf[10], (int)nseg, local_bbox, drone_radius, z_ground, seg_cap,
                              (fh_face*)ctx->d_buf[11], (int32_t*)ctx->d_buf[12], lat, (const double*)ctx->d_buf[17])) != FH_OK)
     return rc;

@@ -111,9 +111,13 @@ __device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt,
 // problems: the voxels of a grid (cell centres) that lie farther than a radius from a point (the vehicle: it has seen what its
 // sensor reaches and nothing else).  Nothing is stored: a segment enumerates the cells of the grid inside the bounding box of its
 // local box, z-major, x fastest — the order in which a cloud holding ALL such voxels would list them.
+// With `flags` (fh_set_unknown_grid_device, rule mode 2) the unknown voxels are the caller's: cell (ix, iy, iz) is unknown iff
+// flags[(iz ny + iy) nx + ix] != 0 — the mapper's unknown cloud as FASTER feeds it to cvxEllipsoidDecomp together with the occupied
+// points (jps_manager.cpp:91-98); the sphere is not used then.
 struct UnknownLattice {
   double ox, oy, oz, res;
   int nx, ny, nz, on;
+  const unsigned char* flags;
 };
 struct LatticeRange {
   int x0, cx, y0, cy, z0, cz, total;  // sub-block of the grid: first cell and count per axis
@@ -123,7 +127,7 @@ __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat,
   LatticeRange g;
   g.total = 0; g.x0 = g.y0 = g.z0 = g.cx = g.cy = g.cz = 0;
   g.ax = g.ay = g.az = g.r2 = 0;
-  if (!lat.on || !sphere) return g;
+  if (!lat.on || (!sphere && !lat.flags)) return g;
   auto first = [](double v, double o, double res, int n) { int i = (int)floor((v - o) / res) - 1; return i < 0 ? 0 : (i > n ? n : i); };
   auto last = [](double v, double o, double res, int n) { int i = (int)floor((v - o) / res) + 1; return i > n - 1 ? n - 1 : i; };
   g.x0 = first(lo[0], lat.ox, lat.res, lat.nx); g.cx = last(hi[0], lat.ox, lat.res, lat.nx) - g.x0 + 1;
@@ -132,7 +136,7 @@ __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat,
   if (g.cx <= 0 || g.cy <= 0 || g.cz <= 0) return g;
   const long long cells = (long long)g.cx * g.cy * g.cz;
   g.total = cells > (1ll << 28) ? -1 : (int)cells;  // -1: a grid far too fine for the local box — the segment reports failure (count -1)
-  g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3];
+  if (sphere) { g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3]; }
   return g;
 }
 // cell number idx of the sub-block: its centre, and whether it is an unknown voxel
@@ -140,6 +144,7 @@ __device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const L
   if (idx >= g.total) return false;
   const int iz = idx / (g.cx * g.cy), rem = idx - iz * (g.cx * g.cy), iy = rem / g.cx, ix = rem - iy * g.cx;
   q = d3(((double)(g.x0 + ix) + 0.5) * lat.res + lat.ox, ((double)(g.y0 + iy) + 0.5) * lat.res + lat.oy, ((double)(g.z0 + iz) + 0.5) * lat.res + lat.oz);
+  if (lat.flags) return lat.flags[((size_t)(g.z0 + iz) * lat.ny + (g.y0 + iy)) * lat.nx + (g.x0 + ix)] != 0;
   const double dx = q.x - g.ax, dy = q.y - g.ay, dz = q.z - g.az;
   return dx * dx + dy * dy + dz * dz > g.r2;
 }

@@ -51,6 +51,42 @@ __device__ inline P3 sphere_crossing(P3 a_in, P3 b_in, double r, P3 c) {
 
 constexpr int SAFE_PATH_CAP = 40;
 
+// Distance from p to the nearest unknown voxel centre of the caller's grid (rule mode 2) — what `kdtree_unk_.nearestKSearch(p, 1, ...)`
+// returns in getFirstCollisionJPS (faster.cpp:806-812), exactly: the minimum of dx^2 + dy^2 + dz^2 over the unknown voxels, then the
+// square root.  The whole wavefront searches cubes of cells around p's cell, lane = cell; a cube of half-width w has seen every voxel
+// closer than (w + 1/2) res, so the search ends when the best distance found is inside that bound (or the cube covers the grid).
+// INFINITY: the grid has no unknown voxel (the reference's kd-tree is empty: the path is returned as it was).
+__device__ inline double nearest_unknown(const UnknownGrid& ug, P3 p, int lane) {
+  if (!ug.flags) return INFINITY;
+  const int cx = (int)floor((p.x - ug.ox) / ug.res), cy = (int)floor((p.y - ug.oy) / ug.res), cz = (int)floor((p.z - ug.oz) / ug.res);
+  const int wmax = max(max(max(cx, ug.nx - 1 - cx), max(cy, ug.ny - 1 - cy)), max(max(cz, ug.nz - 1 - cz), 0));  // covers the grid
+  int w = 1;
+  for (;;) {
+    const int x0 = max(cx - w, 0), x1 = min(cx + w, ug.nx - 1), y0 = max(cy - w, 0), y1 = min(cy + w, ug.ny - 1);
+    const int z0 = max(cz - w, 0), z1 = min(cz + w, ug.nz - 1);
+    double best = INFINITY;
+    if (x1 >= x0 && y1 >= y0 && z1 >= z0) {
+      const int sx = x1 - x0 + 1, sy = y1 - y0 + 1, total = sx * sy * (z1 - z0 + 1);
+      for (int idx = lane; idx < total; idx += 64) {
+        const int iz = idx / (sx * sy), rem = idx - iz * (sx * sy), iy = rem / sx, ix = rem - iy * sx;
+        if (ug.flags[((size_t)(z0 + iz) * ug.ny + (y0 + iy)) * ug.nx + (x0 + ix)]) {
+          const double dx = ((double)(x0 + ix) + 0.5) * ug.res + ug.ox - p.x, dy = ((double)(y0 + iy) + 0.5) * ug.res + ug.oy - p.y,
+                       dz = ((double)(z0 + iz) + 0.5) * ug.res + ug.oz - p.z;
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          best = d2 < best ? d2 : best;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmin(best, __shfl_xor(best, o));
+    const double d = sqrt(best);
+    if (w >= wmax || d <= ((double)w + 0.5) * ug.res) return d;
+    // next cube: wide enough to prove the candidate (or twice as wide when there is none yet)
+    const int need = best < INFINITY ? (int)ceil(d / ug.res) : 2 * w + 1;
+    w = min(max(need, w + 1), wmax);
+  }
+}
+
 // first point of path[lo .. n) on the sphere around `center` (utils.cpp:782-870); last_inside is relative to lo
 __device__ inline P3 sphere_exit(const P3* path, int n, double r, P3 center, int& last_inside, bool& none_outside) {
   none_outside = false;
@@ -94,7 +130,7 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
                                                        const double* __restrict__ paths, const int32_t* __restrict__ n_points, int n,
                                                        int max_points, double r_frac, fh_pair_rule rule, int max_poly_safe,
                                                        fh_problem* __restrict__ safe, double* __restrict__ safe_paths,
-                                                       int32_t* __restrict__ safe_np, double* __restrict__ spheres) {
+                                                       int32_t* __restrict__ safe_np, double* __restrict__ spheres, UnknownGrid ug) {
   __shared__ P3 s_orig[SAFE_PATH_CAP + 2], s_cur[SAFE_PATH_CAP + 2];  // (LDS, not per-lane arrays: those would be 2 KB of scratch per lane)
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n) return;
@@ -105,16 +141,13 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
   const int np_in = n_points[b];
   if (rw.solved && pw.n_seg >= 1 && pw.n_seg <= FH_MAX_SEG && np_in >= 2 && np_in <= SAFE_PATH_CAP) {
     int k;
-    if (choose_r_index(pw, rw, r_frac, rule, lane, k)) {
+    if (choose_r_index(pw, rw, r_frac, rule, lane, k, &ug)) {
       const int N = pw.n_seg;
       const double dt = rw.dt, DC = pw.dc;
       const int size = sample_count(pw, rw);
       double t = 0;
       int interval = 0;
-      for (int i = 0; i <= k; i++) {  // the reference's clock (solverGurobi.cpp:131-135)
-        t = t + DC;
-        if (t > dt * (interval + 1)) interval = (interval + 1 < N - 1) ? interval + 1 : N - 1;
-      }
+      clock_at(k, DC, dt, N, t, interval);  // the reference's clock at sample k (solverGurobi.cpp:131-135): fh_clock.hpp
       fh_state R;
       eval_state(rw.coeff[interval], t - interval * dt, k == size - 1, R);
       if (lane < 3) {
@@ -122,32 +155,44 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
         safe[b].x0[3 + lane] = lane == 0 ? R.vel[0] : (lane == 1 ? R.vel[1] : R.vel[2]);
         safe[b].x0[6 + lane] = lane == 0 ? R.accel[0] : (lane == 1 ? R.accel[1] : R.accel[2]);
       }
-      if (lane == 0) {  // a handful of vertices: one lane walks them
+      {  // a handful of vertices: every lane walks them (wave-uniform), lane 0 writes; the distance query of mode 2 needs the wavefront
         const P3 A = p3(pw.x0[0], pw.x0[1], pw.x0[2]);
         P3* orig = s_orig;
         P3* cur = s_cur;
         int no = np_in, nc = np_in;
-        for (int i = 0; i < np_in; i++) {
-          const double* v = paths + 3 * ((size_t)b * max_points + i);
-          orig[i] = cur[i] = p3(v[0], v[1], v[2]);
-        }
-        // getFirstCollisionJPS against unknown space (distance to it: r_known - |p - A|, not below 0)
+        __syncthreads();
+        if (lane == 0)
+          for (int i = 0; i < np_in; i++) {
+            const double* v = paths + 3 * ((size_t)b * max_points + i);
+            orig[i] = cur[i] = p3(v[0], v[1], v[2]);
+          }
+        __syncthreads();
+        // getFirstCollisionJPS against unknown space.  Distance to it — mode 2: to the nearest unknown voxel of the caller's grid (no
+        // unknown voxel at all: the reference returns the path as it was, :806-812); otherwise modelled: r_known - |p - A|, not below 0
         int iteration = 0;
-        bool done = false;
-        while (nc > 0 && !done) {
-          double r = rule.r_known - dist3(cur[0], A);
-          r = r > 0 ? r : 0;
+        while (nc > 0) {
+          double r;
+          if (rule.mode == 2) {
+            r = nearest_unknown(ug, cur[0], lane);
+            if (!(r < INFINITY)) break;
+          } else {
+            r = rule.r_known - dist3(cur[0], A);
+            r = r > 0 ? r : 0;
+          }
+          __syncthreads();
           if (r < rule.drone_radius) {
-            if (iteration == 0) {  // already there at the first vertex: the reference returns a 1 cm stub
-              orig[1] = p3(orig[0].x + 0.01, orig[0].y, orig[0].z);
-              no = 2;
-            } else {
-              const int eliminated = no - nc + 1;
-              no = eliminated;
-              orig[no++] = cur[0];
-              shorten_by(orig, no, rule.drone_radius);
+            if (lane == 0) {
+              if (iteration == 0) {  // already there at the first vertex: the reference returns a 1 cm stub
+                orig[1] = p3(orig[0].x + 0.01, orig[0].y, orig[0].z);
+                no = 2;
+              } else {
+                const int eliminated = no - nc + 1;
+                no = eliminated;
+                orig[no++] = cur[0];
+                shorten_by(orig, no, rule.drone_radius);
+              }
             }
-            done = true;
+            no = __shfl(no, 0);
             break;
           }
           bool none_outside;
@@ -155,17 +200,24 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
           const P3 inters = sphere_exit(cur, nc, r, cur[0], last_id, none_outside);
           if (none_outside) break;  // the rest of the path is known to be clear: the path as it was
           const int drop = last_id + 1;  // erase [0, last_id], insert the intersection in front
-          for (int i = drop; i < nc; i++) cur[i - drop + 1] = cur[i];
+          __syncthreads();
+          if (lane == 0) {
+            for (int i = drop; i < nc; i++) cur[i - drop + 1] = cur[i];
+            cur[0] = inters;
+          }
           nc = nc - drop + 1;
-          cur[0] = inters;
+          __syncthreads();
           iteration++;
         }
+        __syncthreads();
         // JPS_safe: R first, at most max_poly_safe legs (:478-490)
-        orig[0] = p3(R.pos[0], R.pos[1], R.pos[2]);
         np_out = no < mp ? no : mp;
-        for (int i = 0; i < np_out; i++) {
-          double* o = safe_paths + 3 * ((size_t)b * mp + i);
-          o[0] = orig[i].x; o[1] = orig[i].y; o[2] = orig[i].z;
+        if (lane == 0) {
+          orig[0] = p3(R.pos[0], R.pos[1], R.pos[2]);
+          for (int i = 0; i < np_out; i++) {
+            double* o = safe_paths + 3 * ((size_t)b * mp + i);
+            o[0] = orig[i].x; o[1] = orig[i].y; o[2] = orig[i].z;
+          }
         }
       }
     }

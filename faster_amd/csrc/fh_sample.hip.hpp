@@ -130,6 +130,38 @@ __device__ __forceinline__ void state_at(const RW& rw, int N, double DC, int i, 
   interval = interval < 0 ? 0 : (interval > N - 1 ? N - 1 : interval);
   eval_state(rw.coeff[interval], t - interval * rw.dt, i == size - 1, s);
 }
+// Unknown space as an INPUT (fh_set_unknown_grid_device; fh_pair_rule mode 2): the mapper's unknown voxels on a lattice — cell (ix, iy,
+// iz) with flags[(iz ny + iy) nx + ix] != 0 is unknown and stands for its centre ((i + 0.5) res + origin), the point a cloud of the
+// mapper's unknown voxels (pclptr_unk_ / vec_uo_ of FASTER: faster.cpp:99-137, jps_manager.cpp:91-98) would hold.  flags == null: none.
+struct UnknownGrid {
+  const unsigned char* flags;
+  double ox, oy, oz, res;
+  int nx, ny, nz, pad;
+};
+// Is an unknown voxel centre closer than `radius` to p?  What `kdtree_unk_.nearestKSearch(p, 1, ...)` followed by `sqrt(d2) < radius`
+// decides in findIndexH (faster.cpp:236-240).  One lane, the cells around p's own.
+__device__ inline bool unknown_within(const UnknownGrid& ug, double px, double py, double pz, double radius) {
+#pragma clang fp contract(off)
+  if (!ug.flags || !(radius > 0)) return false;
+  const int k = (int)floor(radius / ug.res + 0.5) + 1;
+  const int cx = (int)floor((px - ug.ox) / ug.res), cy = (int)floor((py - ug.oy) / ug.res), cz = (int)floor((pz - ug.oz) / ug.res);
+  const int x0 = max(cx - k, 0), x1 = min(cx + k, ug.nx - 1), y0 = max(cy - k, 0), y1 = min(cy + k, ug.ny - 1);
+  const int z0 = max(cz - k, 0), z1 = min(cz + k, ug.nz - 1);
+  bool hit = false;
+  for (int iz = z0; iz <= z1; iz++)
+    for (int iy = y0; iy <= y1; iy++) {
+      const unsigned char* row = ug.flags + ((size_t)iz * ug.ny + iy) * ug.nx;
+      const double qy = ((double)iy + 0.5) * ug.res + ug.oy, qz = ((double)iz + 0.5) * ug.res + ug.oz;
+      const double dy = qy - py, dz = qz - pz;
+      for (int ix = x0; ix <= x1; ix++) {
+        if (!row[ix]) continue;
+        const double qx = ((double)ix + 0.5) * ug.res + ug.ox, dx = qx - px;
+        hit = hit || sqrt(dx * dx + dy * dy + dz * dz) < radius;
+      }
+    }
+  return hit;
+}
+
 // What the hand-off reads of a problem / a result, for a caller that holds them in registers and LDS (the fused pair kernel: the whole
 // problem has just been solved by this wavefront; reading its record and its result back from memory costs two dependent round trips)
 struct ProblemView {
@@ -173,13 +205,15 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // findIndexH (faster.cpp:218-251) against the modelled unknown space, then findIndexR (:173-216).  Returns false when no safe
 // trajectory is needed (needToComputeSafePath == false, :462-466): k is then indexH = the last sample (:231).
 template <class PW, class RW>
-__device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac, const fh_pair_rule& rule, int lane, int& k) {
+__device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac, const fh_pair_rule& rule, int lane, int& k,
+                                      const UnknownGrid* ug = nullptr) {
   const int N = pw.n_seg;
   const double DC = pw.dc;
   const int size = sample_count(pw, rw);
   k = (int)(r_frac * (double)size);
-  if (rule.mode == 1) {
-    // findIndexH (faster.cpp:218-251): samples 0, 10, 20, ... against unknown space (modelled: farther than r_known from x0)
+  if (rule.mode == 1 || rule.mode == 2) {
+    // findIndexH (faster.cpp:218-251): samples 0, 10, 20, ... against unknown space — mode 1: modelled (farther than r_known from x0);
+    // mode 2: the unknown voxels of the caller's grid (nearest unknown voxel centre closer than drone_radius)
     const double lim = rule.r_known - rule.drone_radius;
     int iH = 0x7fffffff;
     for (int base = 0; 10 * base < size && iH == 0x7fffffff; base += 64) {
@@ -188,8 +222,12 @@ __device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac,
       if (i < size) {
         fh_state s;
         state_at(rw, N, DC, i, size, s);
-        const double dx = s.pos[0] - pw.x0[0], dy = s.pos[1] - pw.x0[1], dz = s.pos[2] - pw.x0[2];
-        if (sqrt(dx * dx + dy * dy + dz * dz) > lim) mine = i;
+        if (rule.mode == 2) {
+          if (ug && unknown_within(*ug, s.pos[0], s.pos[1], s.pos[2], rule.drone_radius)) mine = i;
+        } else {
+          const double dx = s.pos[0] - pw.x0[0], dy = s.pos[1] - pw.x0[1], dz = s.pos[2] - pw.x0[2];
+          if (sqrt(dx * dx + dy * dy + dz * dz) > lim) mine = i;
+        }
       }
       iH = wave_min_i32(mine);
     }
@@ -231,7 +269,8 @@ __device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac,
 template <bool WT = false, class PW = fh_problem, class RW = fh_result>
 __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* wfaces, double r_frac, double shrink,
                                      int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane,
-                                     unsigned long long* probe = nullptr) {  // probe: cycle stamps of a diagnostic build (null otherwise)
+                                     unsigned long long* probe = nullptr,  // probe: cycle stamps of a diagnostic build (null otherwise)
+                                     const UnknownGrid* ug = nullptr) {    // the unknown voxels of rule mode 2
   if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
     if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
     return;
@@ -240,7 +279,7 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
   const double dt = rw.dt, DC = pw.dc;
   const int size = sample_count(pw, rw);
   int k;
-  if (!choose_r_index(pw, rw, r_frac, rule, lane, k)) {  // the pair ends with its whole trajectory
+  if (!choose_r_index(pw, rw, r_frac, rule, lane, k, ug)) {  // the pair ends with its whole trajectory
     if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
     return;
   }
@@ -341,10 +380,10 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
 __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
                                                        const fh_face* __restrict__ wfaces, int n, double r_frac, double shrink,
                                                        int max_safe_poly, double r_margin, fh_pair_rule rule, fh_problem* __restrict__ safe,
-                                                       fh_face* __restrict__ sfaces) {
+                                                       fh_face* __restrict__ sfaces, UnknownGrid ug) {
   const int b = blockIdx.x;
   if (b >= n) return;
-  pair_glue_one<false>(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, r_margin, rule, safe[b], sfaces, threadIdx.x);
+  pair_glue_one<false>(whole[b], wres[b], wfaces, r_frac, shrink, max_safe_poly, r_margin, rule, safe[b], sfaces, threadIdx.x, nullptr, &ug);
 }
 
 // Faster::appendToPlan (faster/src/faster.cpp:606-648) for a batch of independent pairs whose plan holds only the start A
@@ -355,7 +394,7 @@ __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restr
 __global__ void __launch_bounds__(64) plan_append_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,
                                                          const fh_problem* __restrict__ safe, const fh_result* __restrict__ sres, int n,
                                                          double r_frac, fh_pair_rule rule, int max_states, fh_state* __restrict__ plans,
-                                                         int32_t* __restrict__ counts, int32_t* __restrict__ k_safe_out) {
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ k_safe_out, UnknownGrid ug) {
   __shared__ __attribute__((aligned(16))) double tile[64 * 12];
   __shared__ double coef[FH_MAX_SEG * 12];
   const int b = blockIdx.x;
@@ -366,7 +405,7 @@ __global__ void __launch_bounds__(64) plan_append_kernel(const fh_problem* __res
   int count = 0, k = -1;
   if (rw.solved && pw.n_seg >= 1 && pw.n_seg <= FH_MAX_SEG) {
     const int size_w = __builtin_amdgcn_readfirstlane(sample_count(pw, rw));
-    const bool need_safe = choose_r_index(pw, rw, r_frac, rule, lane, k);
+    const bool need_safe = choose_r_index(pw, rw, r_frac, rule, lane, k, &ug);
     k = __builtin_amdgcn_readfirstlane(k);
     const fh_problem& ps = safe[b];
     const fh_result& rs = sres[b];

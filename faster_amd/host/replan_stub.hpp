@@ -43,6 +43,14 @@ struct Params {  // the planner-relevant subset of `parameters` (faster_types.hp
   int deltaT = 10;  // states between "now" and the start state A (faster.hpp:131)
   double wdx = 20, wdy = 20, wdz = 4, res = 0.15;
   double z_ground = 0.0, z_max = 3.0, inflation_jps = 0.47, factor_jps = 1.0;
+  // ---- what a test may pin down (defaults: the behaviour described above) ----
+  bool jps = false;               // true: the path search is jump point search in jps3d's own order (plan_path_jps: what FASTER runs,
+                                  //       jps_manager.cpp:166); false: the A* with a total order of its own (plan_path: the same cost)
+  double decomp_radius = -1.0;    // >= 0: the inflation handed to the decomposition (cvxEllipsoidDecomp's drone radius) when it is to differ
+                                  //       from drone_radius of the unknown-space tests; < 0: drone_radius
+  bool map_fixed = false;         // true: the occupancy grid is map_cells cells of size res centred at map_center for every replan (a
+  double map_center[3] = {0, 0, 0};  //    batch of independent pairs shares one map), not wdx x wdy x wdz around the vehicle
+  int map_cells[3] = {0, 0, 0};
 };
 
 enum class Status { TRAVELING, GOAL_SEEN, GOAL_REACHED };
@@ -239,6 +247,16 @@ public:
   }
   Status status() const { return status_; }
   const std::deque<state>& plan() const { return plan_; }
+  // A fresh vehicle for the same planner object (a batch of independent start/goal pairs through one pair of solver contexts): no
+  // state, no plan, the factor windows back to what the constructor set (faster.cpp:57, :68)
+  void reset() {
+    state_set_ = false;
+    goal_set_ = false;
+    status_ = Status::TRAVELING;
+    plan_.clear();
+    sg_whole_.setFactorInitialAndFinalAndIncrement(1, 10, par_.increment_whole);
+    sg_safe_.setFactorInitialAndFinalAndIncrement(1, 10, par_.increment_safe);
+  }
 
   bool replan(ReplanLog* log = nullptr) {
     ReplanLog local;
@@ -260,10 +278,16 @@ public:
 
     // ---- path search in the known map (:361), clipped to the sphere S of radius ra around A (:373-384)
     fhfront::VoxelGrid grid;
-    grid.build(occupied_.pts, (int)(par_.wdx / par_.res), (int)(par_.wdy / par_.res), (int)(par_.wdz / par_.res), par_.factor_jps * par_.res, here,
-               par_.z_ground, par_.z_max, par_.inflation_jps);
+    if (par_.map_fixed)
+      grid.build(occupied_.pts, par_.map_cells[0], par_.map_cells[1], par_.map_cells[2], par_.factor_jps * par_.res,
+                 V3(par_.map_center[0], par_.map_center[1], par_.map_center[2]), par_.z_ground, par_.z_max, par_.inflation_jps);
+    else
+      grid.build(occupied_.pts, (int)(par_.wdx / par_.res), (int)(par_.wdy / par_.res), (int)(par_.wdz / par_.res), par_.factor_jps * par_.res, here,
+                 par_.z_ground, par_.z_max, par_.inflation_jps);
     std::vector<V3> JPSk;
-    if (!fhfront::plan_path(grid, pos_of(A), G, par_.inflation_jps, JPSk)) { L.stage = 1; return false; }
+    const bool found = par_.jps ? fhfront::plan_path_jps(grid, pos_of(A), G, par_.inflation_jps, JPSk)
+                                : fhfront::plan_path(grid, pos_of(A), G, par_.inflation_jps, JPSk);
+    if (!found) { L.stage = 1; return false; }
     const double ra = std::min(dist_to_goal - 0.001, par_.Ra);
     int li1 = 0;
     bool none_outside = false;
@@ -276,7 +300,8 @@ public:
     std::vector<V3> JPS_whole = JPS_in;
     keep_first(JPS_whole, par_.max_poly_whole);
     Epos = JPS_whole.back();
-    l_constraints_whole_ = to_solver_constraints(decompose_(JPS_whole, occupied_.pts, par_.drone_radius, par_.z_ground));
+    const double decomp_r = par_.decomp_radius >= 0 ? par_.decomp_radius : par_.drone_radius;
+    l_constraints_whole_ = to_solver_constraints(decompose_(JPS_whole, occupied_.pts, decomp_r, par_.z_ground));
     if (l_constraints_whole_.empty()) { L.stage = 2; return false; }  // (a device decomposition that failed reports an empty corridor)
     if (l_constraints_whole_.back().inside(fhstub::Vec3(G.x, G.y, G.z))) Epos = G;
     state E;
@@ -309,7 +334,7 @@ public:
       std::vector<V3> JPS_safe = tmp;
       keep_first(JPS_safe, par_.max_poly_safe);
       Mpos = JPS_safe.back();
-      l_constraints_safe_ = to_solver_constraints(decompose_(JPS_safe, unknown_and_occupied_, par_.drone_radius, par_.z_ground));
+      l_constraints_safe_ = to_solver_constraints(decompose_(JPS_safe, unknown_and_occupied_, decomp_r, par_.z_ground));
       if (l_constraints_safe_.empty()) { L.stage = 3; return false; }  // failed (device) decomposition: no safe corridor, as for the whole one
       if (l_constraints_safe_.back().inside(fhstub::Vec3(G.x, G.y, G.z))) Mpos = G;
       state M;

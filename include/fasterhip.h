@@ -263,15 +263,27 @@ int fh_set_pair_margin(fh_ctx* ctx, double r_margin);
  *     (needToComputeSafePath == false, faster.cpp:462-466) and the pair ends with its whole trajectory (safe n_seg = 0).
  *   findIndexR (faster.cpp:173-216): the first sample i <= indexH from which the vehicle can no longer brake before H — per axis
  *     x, y: sign(v (pH - p)) v^2 / (2 delta_a a_max) > |pH - p| — is R; if there is none, R = H.
- * r_frac of the calls is ignored in mode 1.  The safe corridor is built from R as described above in both modes. */
+ * mode 2: the same two functions against unknown space AS AN INPUT — the mapper's unknown voxels, given once per context with
+ *   fh_set_unknown_grid_device: a sample is near unknown space iff an unknown voxel centre is closer than drone_radius to it, which is
+ *   what the reference's `kdtree_unk_.nearestKSearch(p, 1, ...)` + `sqrt(d2) < drone_radius` decides (faster.cpp:236-240).  r_known
+ *   is not used.  Mode 2 is for the staged entry points (fh_pair_glue_device, fh_safe_corridor_batch_device, fh_append_plans_device);
+ *   fh_solve_pairs_device refuses it.
+ * r_frac of the calls is ignored in modes 1 and 2.  The safe corridor is built from R as described above in every mode. */
 typedef struct fh_pair_rule {
   int32_t mode, reserved;
-  double r_known;       /* [m] radius of known space around x0 (mode 1)                                   */
+  double r_known;       /* [m] radius of known space around x0 (mode 1; unused in mode 2)                  */
   double drone_radius;  /* [m] par_.drone_radius (faster.yaml: 0.42)                                       */
   double delta_h;       /* par_.delta_H (faster.yaml: 1.0)                                                 */
   double delta_a;       /* par_.delta_a (faster.yaml: 0.5)                                                 */
 } fh_pair_rule;
 int fh_set_pair_rule(fh_ctx* ctx, const fh_pair_rule* rule);
+/* Unknown space as an input (rule mode 2): d_flags[(iz ny + iy) nx + ix] != 0 marks cell (ix, iy, iz) of `grid` as unknown; the voxel
+ * stands for its centre ((i + 0.5) res + origin) — the point the mapper's unknown cloud holds for it (FASTER: pclptr_unk_ feeds
+ * kdtree_unk_, faster/src/faster.cpp:99-137, and, together with the occupied points, the decomposition: vec_uo_, jps_manager.cpp:91-98).
+ * Device pointer, owned by the caller, read by every later launch of the context that uses rule mode 2 (it may be updated between
+ * launches like any other input; it need not be the lattice of an fh_map).  d_flags = NULL: no unknown grid (mode 2 is refused). */
+struct fh_voxel_grid;
+int fh_set_unknown_grid_device(fh_ctx* ctx, const struct fh_voxel_grid* grid, const unsigned char* d_flags);
 int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results,
                         const fh_face* d_faces, int n, double r_frac, double shrink, int max_safe_poly,
                         fh_problem* d_safe, fh_face* d_safe_faces);
@@ -331,7 +343,10 @@ int fh_corridor_problems_device(fh_ctx* ctx, const int32_t* d_n_points, const do
  *      voxels of `grid` (cell centres (i + 0.5) res + origin) farther than r_known from A, enumerated z-major and listed FIRST;
  *   4. d_safe[i]: x0 = R, xf = G (d_goals[i]) when G lies in the last polytope, else M (:498-499), n_poly / face_off / face_begin
  *      (= i * faces_per_problem, rows in d_safe_faces), n_seg = n_seg_safe; every other field is left as the caller prepared it.
- * Unknown space is MODELLED (a batch has no mapper): everything farther than fh_pair_rule.r_known from A.  A pair without a whole
+ * Unknown space is MODELLED in rule modes 0 and 1 (a batch has no mapper): everything farther than fh_pair_rule.r_known from A.  In
+ * rule mode 2 it is the caller's unknown voxel grid (fh_set_unknown_grid_device): step 1 marches along the path with the exact
+ * distance to the nearest unknown voxel centre (the reference's kd-tree query), step 3 lists the unknown voxels of THAT grid first,
+ * z-major, and `grid` of this call is not used.  A pair without a whole
  * trajectory, without a need for a safe one (rule mode 1) or without a corridor gets n_seg = 0.  Then solve d_safe with
  * fh_solve_batch_device and splice with fh_append_plans_device.  d_safe_paths [n][max_poly_safe + 1][3] / d_safe_n_points [n]: the
  * safe paths (may be NULL).  CPU restatement: oracle/pair_glue.py (safe_path, unknown_voxels) + the host decomposition.

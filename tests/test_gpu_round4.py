@@ -1,0 +1,205 @@
+"""GPU tests added in round 4: the device pipeline of one Faster::replan per pair END TO END against the restatement of the caller
+(faster_amd/host/replan_stub.hpp = faster/src/faster.cpp:296-595), with unknown space given as an INPUT (fh_set_unknown_grid_device,
+fh_pair_rule mode 2) — the same unknown voxels that the stub receives as a point cloud (updateMap, faster.cpp:99-137)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from faster_amd import abi, capi, corridor, frontend
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_first():
+    import torch  # noqa: F401  (torch before the HIP library: one HIP runtime in the process)
+
+
+def _build_pairs_driver():
+    from faster_amd import build as fb
+
+    fb.build_all()
+    exe = os.path.join(ROOT, "tests", "cpp", "test_replan_pairs")
+    src = exe + ".cpp"
+    host = os.path.join(ROOT, "faster_amd", "host")
+    deps = [src, fb.HOST_SO] + [os.path.join(host, f) for f in ("replan_stub.hpp", "corridor_frontend.hpp", "corridor_frontend.cpp", "solver_hip.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-I", os.path.join(ROOT, "include"), "-I", host, src, os.path.join(host, "corridor_frontend.cpp"),
+                               "-o", exe, "-L", os.path.join(ROOT, "faster_amd"), "-lsolverhip", "-lfasterhip", "-ldl", "-fopenmp",
+                               "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
+    return exe
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")
+
+
+def device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dims, P):
+    """The stages of bench.py's `replan_faithful`, unknown space as an input (rule mode 2).  Returns what the device committed."""
+    import torch
+
+    dev = "cuda:0"
+    B, N, max_poly, fpp, max_states = len(starts), P["N"], P["max_poly"], 96, 1024
+    mp = max_poly + 1
+    whole = abi.make_problems(B)
+    whole["n_seg"], whole["force_final_pos"], whole["dc"] = N, 1, P["dc"]
+    whole["v_max"], whole["a_max"], whole["j_max"] = P["v_max"], P["a_max"], P["j_max"]
+    whole["f_init"], whole["f_final"], whole["f_inc"] = 1.0, 10.0, 1.0
+    whole["x0"][:, 0:3], whole["x0"][:, 3:6] = starts, vels
+    tmpl = corridor.safe_templates(whole)
+    tmpl["n_seg"] = N
+    ctx, vmap = capi.Context(0), capi.Map(0)
+    try:
+        f64, i32 = torch.float64, torch.int32
+        d_cloud, d_starts, d_goals, d_flags = _dev(cloud), _dev(starts), _dev(goals), _dev(flags)
+        d_whole, d_safe = _dev(whole), _dev(tmpl)
+        d_paths, d_np, d_ex = torch.zeros((B, mp, 3), dtype=f64, device=dev), torch.zeros(B, dtype=i32, device=dev), torch.zeros(B, dtype=torch.int64, device=dev)
+        FB, RES = abi.face_dtype.itemsize, abi.result_dtype.itemsize
+        d_wf, d_sf = torch.zeros(B * fpp * FB, dtype=torch.uint8, device=dev), torch.zeros(B * fpp * FB, dtype=torch.uint8, device=dev)
+        d_off, d_npoly, d_last = torch.zeros((B, 9), dtype=i32, device=dev), torch.zeros(B, dtype=i32, device=dev), torch.zeros((B, 3), dtype=f64, device=dev)
+        d_wr, d_sr = torch.zeros(B * RES, dtype=torch.uint8, device=dev), torch.zeros(B * RES, dtype=torch.uint8, device=dev)
+        d_plans = torch.zeros(B * max_states * abi.state_dtype.itemsize, dtype=torch.uint8, device=dev)
+        d_counts, d_k = torch.zeros(B, dtype=i32, device=dev), torch.zeros(B, dtype=i32, device=dev)
+        d_spaths, d_snp = torch.zeros((B, mp, 3), dtype=f64, device=dev), torch.zeros(B, dtype=i32, device=dev)
+        ctx.set_pair_rule(mode=2, drone_radius=P["drone_radius"], delta_h=P["delta_h"], delta_a=P["delta_a"])
+        ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, P["res"], dims)
+        vmap.set_search("jps")
+        vmap.set_sphere(P["Ra"])
+        vmap.read_device(d_cloud.data_ptr(), len(cloud), cells, P["res"], center, 0.0, P["z_max"], P["inflation"])
+        vmap.plan_batch_device(d_starts.data_ptr(), d_goals.data_ptr(), B, mp, d_paths.data_ptr(), d_np.data_ptr(), d_ex.data_ptr(), P["dist_max_vertexes"], max_poly)
+        vmap.sync()
+        ctx.corridor_batch_device(d_cloud.data_ptr(), len(cloud), d_paths.data_ptr(), d_np.data_ptr(), B, mp, max_poly, fpp, d_wf.data_ptr(), d_off.data_ptr(),
+                                  d_npoly.data_ptr(), d_last.data_ptr(), P["decomp_radius"], 0.0)
+        ctx.corridor_problems_device(d_np.data_ptr(), d_last.data_ptr(), d_goals.data_ptr(), d_wf.data_ptr(), d_off.data_ptr(), d_npoly.data_ptr(), B, fpp, N,
+                                     d_whole.data_ptr())
+        ctx.solve_batch_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, d_wr.data_ptr())
+        ctx.safe_corridor_batch_device(d_whole.data_ptr(), d_wr.data_ptr(), d_paths.data_ptr(), d_np.data_ptr(), mp, d_goals.data_ptr(), d_cloud.data_ptr(),
+                                       len(cloud), origin, P["res"], dims, B, 0.5, max_poly, (2.0, 2.0, 1.0), P["decomp_radius"], 0.0, fpp, N,
+                                       d_safe.data_ptr(), d_sf.data_ptr(), d_spaths.data_ptr(), d_snp.data_ptr())
+        ctx.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, fpp, d_sr.data_ptr())
+        ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states, d_plans.data_ptr(),
+                                d_counts.data_ptr(), d_k.data_ptr())
+        ctx.sync()
+        out = {"np": d_np.cpu().numpy(), "wres": d_wr.cpu().numpy().view(abi.result_dtype).copy(), "sres": d_sr.cpu().numpy().view(abi.result_dtype).copy(),
+               "safe": d_safe.cpu().numpy().view(abi.problem_dtype).copy(), "whole": d_whole.cpu().numpy().view(abi.problem_dtype).copy(),
+               "counts": d_counts.cpu().numpy(), "k": d_k.cpu().numpy(),
+               "plans": d_plans.cpu().numpy().view(abi.state_dtype).reshape(B, max_states).copy(), "snp": d_snp.cpu().numpy(),
+               "spaths": d_spaths.cpu().numpy()}
+        # rule mode 2 without a grid, and in the fused kernel, is refused loudly
+        ctx.set_unknown_grid_device(None)
+        with pytest.raises(capi.FasterHipError):
+            ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states, d_plans.data_ptr(),
+                                    d_counts.data_ptr(), d_k.data_ptr())
+        ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, P["res"], dims)
+        with pytest.raises(capi.FasterHipError):
+            ctx.solve_pairs_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, 0.5, 0.0, 3, d_wr.data_ptr(), d_safe.data_ptr(), d_sf.data_ptr(), d_sr.data_ptr())
+        dm, og = vmap.dims()
+    finally:
+        vmap.close()
+        ctx.close()
+    return out
+
+
+def stub_replans(tmp_path, cloud, cells, center, starts, vels, goals, unknown_pts, P):
+    """The same pairs, one at a time, through replan_stub.hpp driving SolverHip (tests/cpp/test_replan_pairs.cpp)."""
+    exe = _build_pairs_driver()
+    B = len(starts)
+    hi = np.zeros(16, dtype=np.int32)
+    hi[:10] = [P["N"], P["N"], P["max_poly"], P["max_poly"], cells[0], cells[1], cells[2], B, len(cloud), len(unknown_pts)]
+    hd = np.zeros(32, dtype=np.float64)
+    hd[:17] = [P["dc"], P["v_max"], P["a_max"], P["j_max"], P["Ra"], P["drone_radius"], P["decomp_radius"], P["dist_max_vertexes"], P["delta_a"],
+               P["delta_h"], P["res"], P["inflation"], 0.0, P["z_max"], center[0], center[1], center[2]]
+    sc, outp = tmp_path / "pairs.bin", tmp_path / "pairs.out"
+    with open(sc, "wb") as f:
+        f.write(hi.tobytes())
+        f.write(hd.tobytes())
+        f.write(np.ascontiguousarray(cloud, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(unknown_pts, dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(np.concatenate([starts, vels, goals], axis=1), dtype=np.float64).tobytes())
+    r = subprocess.run([exe, str(sc), str(outp)], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raw = open(outp, "rb").read()
+    recs, pos = [], 0
+    for _ in range(B):
+        rec = np.frombuffer(raw, dtype=np.int32, count=8, offset=pos)
+        fac = np.frombuffer(raw, dtype=np.float64, count=2, offset=pos + 32)
+        pos += 48
+        cnt = int(rec[7])
+        plan = np.frombuffer(raw, dtype=np.float64, count=12 * cnt, offset=pos).reshape(cnt, 12)
+        pos += 96 * cnt
+        recs.append({"ok": int(rec[0]), "stage": int(rec[1]), "needed_safe": int(rec[2]), "index_H": int(rec[3]), "k_safe": int(rec[4]),
+                     "n_whole": int(rec[5]), "n_safe": int(rec[6]), "plan": plan, "whole_factor": fac[0], "safe_factor": fac[1]})
+    assert pos == len(raw)
+    return recs
+
+
+def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_path):
+    """1024 independent start/goal pairs in a random forest of which only some regions have been seen.  Device: map -> jump point search
+    (JPS_in) -> whole corridor -> whole solve -> H, R and the safe corridor against the UNKNOWN VOXELS GIVEN AS AN INPUT -> safe solve ->
+    appendToPlan, every stage a batch launch.  Caller: replan_stub.hpp, one pair at a time, the unknown voxels as the point cloud a
+    mapper would hand over (z-major), brute-force nearest-neighbour queries where the reference asks its kd-tree.  Per pair: the same
+    decision at every stage (path found, whole trajectory, safe trajectory needed, safe trajectory found), the same sample k_safe, the
+    same number of committed states, the committed states themselves to 1e-9."""
+    B = 1024
+    P = {"N": 6, "max_poly": 3, "dc": 0.01, "v_max": 5.0, "a_max": 5.0, "j_max": 8.0, "Ra": 4.0, "drone_radius": 0.3, "decomp_radius": 0.05,
+         "dist_max_vertexes": 1.5, "delta_a": 0.5, "delta_h": 1.0, "res": 0.2, "inflation": 0.3, "z_max": 3.0}
+    cloud, cells, center, starts, goals, rng = frontend.forest_queries(B, 11, return_rng=True)
+    u = goals - starts
+    u /= np.maximum(np.linalg.norm(u, axis=1, keepdims=True), 1e-9)
+    vels = u * rng.uniform(0, 1.5, size=(B, 1))
+    # the lattice of the device map (MapUtil::readMap: dims include the inflation margin) carries the unknown flags
+    probe = capi.Map(0)
+    probe.read(cloud, cells, P["res"], center, 0.0, P["z_max"], P["inflation"])
+    dims, origin = probe.dims()
+    probe.close()
+    dims, origin = [int(d) for d in dims], np.array(origin, dtype=np.float64)
+    iz, iy, ix = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+    centres = np.stack([(ix + 0.5) * P["res"] + origin[0], (iy + 0.5) * P["res"] + origin[1], (iz + 0.5) * P["res"] + origin[2]], axis=-1)
+    seen = np.zeros(iz.shape, dtype=bool)
+    for c in rng.uniform([1, 1, 1.5], [19, 19, 1.5], size=(14, 3)):      # what the vehicle has explored: a few overlapping spheres
+        seen |= np.linalg.norm(centres - c, axis=-1) < rng.uniform(3.0, 5.5)
+    flags = (~seen).astype(np.uint8)                                      # [nz][ny][nx], x fastest
+    unknown_pts = centres[~seen]                                          # z-major, x fastest: the order the device enumerates
+    assert 0.2 < flags.mean() < 0.8
+
+    dv = device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dims, P)
+    st = stub_replans(tmp_path, cloud, cells, center, starts, vels, goals, unknown_pts, P)
+
+    whole_ok = (dv["np"] >= 2) & (dv["wres"]["solved"] == 1) & (dv["whole"]["n_seg"] > 0)
+    need_safe = dv["safe"]["n_seg"] > 0
+    safe_ok = dv["sres"]["solved"] == 1
+    stages = {1: 0, 2: 0, 3: 0, 5: 0}
+    worst = 0.0
+    for i, s in enumerate(st):
+        stages[s["stage"]] = stages.get(s["stage"], 0) + 1
+        if s["stage"] == 1:                       # no path
+            assert dv["np"][i] < 2 and dv["counts"][i] == 0, i
+            continue
+        if s["stage"] == 2:                       # no whole trajectory
+            assert not whole_ok[i] and dv["counts"][i] == 0, i
+            continue
+        assert whole_ok[i], i
+        assert s["n_whole"] == max(2, int(P["N"] * dv["wres"]["dt"][i] / P["dc"])), i
+        assert s["whole_factor"] == dv["wres"]["factor"][i], i
+        assert bool(s["needed_safe"]) == bool(need_safe[i] or (dv["snp"][i] >= 2 and not need_safe[i])), i
+        if s["stage"] == 3:                       # a safe trajectory was needed and not found
+            assert not (need_safe[i] and safe_ok[i]) and dv["counts"][i] == 0, i
+            continue
+        assert s["stage"] == 5 and s["ok"] == 1, (i, s["stage"])
+        assert dv["k"][i] == s["k_safe"], (i, dv["k"][i], s["k_safe"], s["index_H"])
+        if s["needed_safe"]:
+            assert need_safe[i] and safe_ok[i] and s["safe_factor"] == dv["sres"]["factor"][i], i
+        n = len(s["plan"])
+        assert dv["counts"][i] == n, (i, dv["counts"][i], n)
+        got = dv["plans"][i, :n]
+        mine = np.concatenate([got["pos"], got["vel"], got["accel"], got["jerk"]], axis=1)
+        worst = max(worst, float(np.abs(mine - s["plan"]).max()))
+    assert worst < 1e-9, worst
+    # the batch exercises every outcome that matters
+    assert stages[5] > 0.7 * B and sum(1 for s in st if s["needed_safe"]) > 0.3 * B and sum(1 for s in st if s["stage"] == 5 and not s["needed_safe"]) > 10
+    print("replan chain == stub on %d pairs: stages %s, worst state difference %.2e" % (B, stages, worst))
