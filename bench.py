@@ -685,7 +685,8 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
         return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
 
     ctx, vmap = capi.Context(local_rank), capi.Map(local_rank)
-    mp = max_poly + 1
+    mp = 16  # vertices of JPS_in kept: the WHOLE path inside the sphere — the march towards unknown space runs along all of it
+             # (faster.cpp:446-452); the whole corridor uses its first max_poly legs (deleteVertexes, :390-392: fh_corridor_batch_device)
     d_cloud, d_starts, d_goals = to_dev(cloud), to_dev(starts), to_dev(goals)
     d_whole_t, d_tmpl = to_dev(whole), to_dev(tmpl)
     d_whole, d_safe = torch.zeros_like(d_whole_t), torch.zeros_like(d_tmpl)
@@ -718,7 +719,7 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
             d_safe.copy_(d_tmpl)
             timed("map", lambda: vmap.read_device(d_cloud.data_ptr(), len(cloud), cells, res, center, 0.0, zmax, infl), vmap.sync)
             timed("path_search", lambda: vmap.plan_batch_device(d_starts.data_ptr(), d_goals.data_ptr(), B, mp, d_paths.data_ptr(), d_np.data_ptr(),
-                                                                d_ex.data_ptr(), 1.5, max_poly), vmap.sync)
+                                                                d_ex.data_ptr(), 1.5, 0), vmap.sync)
             if dims is None:
                 dims, origin = vmap.dims()
 
@@ -736,10 +737,43 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
             timed("safe_solve", lambda: ctx.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, fpp, d_sr.data_ptr()), ctx.sync)
             timed("append_plans", lambda: ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5,
                                                                   max_states, d_plans.data_ptr(), d_counts.data_ptr(), d_k.data_ptr()), ctx.sync)
-        wres, sres = d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype)
-        wprob, safe = d_whole.cpu().numpy().view(abi.problem_dtype), d_safe.cpu().numpy().view(abi.problem_dtype)
-        counts = d_counts.cpu().numpy()
+        wres, sres = d_wr.cpu().numpy().view(abi.result_dtype).copy(), d_sr.cpu().numpy().view(abi.result_dtype).copy()
+        wprob, safe = d_whole.cpu().numpy().view(abi.problem_dtype).copy(), d_safe.cpu().numpy().view(abi.problem_dtype).copy()
+        counts = d_counts.cpu().numpy().copy()
         pops = int(d_ex.sum().item())
+        # ---- the same pairs with unknown space as an INPUT (fh_pair_rule mode 2): the voxels of the map's lattice that a vehicle which has
+        # explored a dozen spheres has not seen.  Map, paths and whole trajectories do not depend on it: the three stages that do, again.
+        iz, iy, ix = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+        cen = np.stack([(ix + 0.5) * res + origin[0], (iy + 0.5) * res + origin[1], (iz + 0.5) * res + origin[2]], axis=-1)
+        seen = np.zeros(iz.shape, dtype=bool)
+        for c in rng.uniform([1, 1, 1.5], [19, 19, 1.5], size=(16, 3)):
+            seen |= np.linalg.norm(cen - c, axis=-1) < rng.uniform(2.0, 3.5)
+        d_flags = to_dev((~seen).astype(np.uint8))
+        ctx.set_pair_rule(mode=2, drone_radius=drone_r, delta_h=1.0, delta_a=0.5)
+        ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, res, dims)
+        fpp2 = 192  # (polytopes against real unknown voxels have more rows: 3 x 64)
+        d_sf2 = torch.zeros(B * fpp2 * FB, dtype=torch.uint8, device=dev)
+        stages2 = {"safe_corridor": [], "safe_solve": [], "append_plans": []}
+        stages_sphere, stages = stages, stages2
+        for _ in range(reps + 1):
+            d_safe.copy_(d_tmpl)
+            timed("safe_corridor", lambda: ctx.safe_corridor_batch_device(d_whole.data_ptr(), d_wr.data_ptr(), d_paths.data_ptr(), d_np.data_ptr(), mp,
+                                                                          d_goals.data_ptr(), d_cloud.data_ptr(), len(cloud), origin, res, dims, B, 0.5,
+                                                                          max_poly, (2.0, 2.0, 1.0), decomp_r, 0.0, fpp2, N, d_safe.data_ptr(),
+                                                                          d_sf2.data_ptr()), ctx.sync)
+            timed("safe_solve", lambda: ctx.solve_batch_device(d_safe.data_ptr(), d_sf2.data_ptr(), B, N, fpp2, d_sr.data_ptr()), ctx.sync)
+            timed("append_plans", lambda: ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5,
+                                                                  max_states, d_plans.data_ptr(), d_counts.data_ptr(), d_k.data_ptr()), ctx.sync)
+        stages = stages_sphere
+        sres2, safe2, counts2 = d_sr.cpu().numpy().view(abi.result_dtype), d_safe.cpu().numpy().view(abi.problem_dtype), d_counts.cpu().numpy()
+        need2 = safe2["n_seg"] > 0
+        med2 = {k: float(np.median(v[1:])) for k, v in stages2.items()}
+        unknown_input = {"unknown_voxel_frac": float((~seen).mean()), "stages_ms": med2, "pairs_needing_a_safe_trajectory": int(need2.sum()),
+                         "safe_solved_frac": float(sres2["solved"][need2].mean()) if need2.any() else None,
+                         "plans_committed_frac": float((counts2 > 0).mean()),
+                         "note": "fh_set_unknown_grid_device + fh_pair_rule mode 2: findIndexH and the march of getFirstCollisionJPS ask for the "
+                                 "nearest unknown voxel of the grid (exact, as the reference's kd-tree), the safe corridor is decomposed against "
+                                 "[unknown voxels | occupied points]; map, paths and whole solves as above"}
     finally:
         vmap.close()
         ctx.close()
@@ -754,6 +788,7 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
             "whole_solved_frac": float(wres["solved"][have].mean()), "pairs_needing_a_safe_trajectory": int(need.sum()),
             "safe_solved_frac": float(sres["solved"][need].mean()) if need.any() else None,
             "plans_committed_frac": float((counts > 0).mean()), "mean_plan_states": float(counts[counts > 0].mean()) if (counts > 0).any() else 0.0,
+            "unknown_space_as_an_input": unknown_input,
             "note": "unknown space is MODELLED (a batch has no mapper): everything farther than Ra from the start — distance queries use "
                     "Ra - |p - A|, the decomposition sees the voxels of the map's grid out there; path_search includes building the jump tables "
                     "of the map; whole_corridor includes fh_corridor_problems_device (E = G or the last vertex)"}

@@ -873,7 +873,8 @@ int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const 
 
 // ---- corridors of a batch of paths: segments -> decomposition -> polytope rows in the layout fh_problem points at ---------------
 namespace {
-// segment j of pair i = (vertex j, vertex j+1) of its path, NaN where the path has no such leg; goal = the last vertex kept
+// segment j of pair i = (vertex j, vertex j+1) of its path, NaN where the path has no such leg; a path of more than max_poly legs is
+// cut to its first max_poly legs (deleteVertexes, utils.cpp:1117-1124); goal = the last vertex kept
 __global__ void corridor_segments_kernel(const double* __restrict__ paths, const int32_t* __restrict__ n_points, int n, int max_points,
                                          int max_poly, double* __restrict__ segments, double* __restrict__ goal) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -888,7 +889,8 @@ __global__ void corridor_segments_kernel(const double* __restrict__ paths, const
     for (int k = 0; k < 6; k++) sg[k] = __builtin_nan("");
   }
   if (j == 0 && goal) {
-    for (int k = 0; k < 3; k++) goal[3 * (size_t)i + k] = np >= 2 ? paths[3 * ((size_t)i * max_points + (np - 1)) + k] : __builtin_nan("");
+    const int last = np - 1 < max_poly ? np - 1 : max_poly;
+    for (int k = 0; k < 3; k++) goal[3 * (size_t)i + k] = np >= 2 ? paths[3 * ((size_t)i * max_points + last) + k] : __builtin_nan("");
   }
 }
 
@@ -900,9 +902,9 @@ __global__ void __launch_bounds__(64) corridor_assemble_kernel(const int32_t* __
   const int i = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (i >= n) return;
   const int np = n_points[i];
-  const int legs = np >= 2 ? np - 1 : 0;
+  const int legs = np >= 2 ? (np - 1 < max_poly ? np - 1 : max_poly) : 0;  // (at most max_poly legs are kept: deleteVertexes)
   int total = 0;
-  bool fits = legs > 0 && legs <= max_poly && legs <= FH_MAX_POLY;
+  bool fits = legs > 0 && legs <= FH_MAX_POLY;
   for (int p = 0; p < legs && fits; p++) {
     const int c = seg_counts[(size_t)i * max_poly + p];
     if (c <= 0 || total + c > faces_per_problem) { fits = false; break; }

@@ -199,6 +199,9 @@ struct ReplanLog {
   int k_end_whole = 0, k_safe = 0, index_H = 0;
   double whole_factor = 0, safe_factor = 0;
   size_t n_whole = 0, n_safe = 0;
+  std::vector<V3> safe_path;     // JPS_safe: R first (faster.cpp:478-490)
+  V3 safe_goal = V3(0, 0, 0);    // what sg_safe_.setXf received: M, or G when G lies in the last polytope (:498-499)
+  std::vector<int> safe_rows;    // rows per polytope of the safe corridor
 };
 
 // the decomposition policy of Planner when none is given: DecompUtil's algorithm on the host (corridor_frontend.hpp);
@@ -337,6 +340,9 @@ public:
       l_constraints_safe_ = to_solver_constraints(decompose_(JPS_safe, unknown_and_occupied_, decomp_r, par_.z_ground));
       if (l_constraints_safe_.empty()) { L.stage = 3; return false; }  // failed (device) decomposition: no safe corridor, as for the whole one
       if (l_constraints_safe_.back().inside(fhstub::Vec3(G.x, G.y, G.z))) Mpos = G;
+      L.safe_path = JPS_safe;
+      L.safe_goal = Mpos;
+      for (const auto& c : l_constraints_safe_) L.safe_rows.push_back((int)c.b().rows());
       state M;
       M.setPos(Mpos.x, Mpos.y, Mpos.z);
       sg_safe_.setX0(R);

@@ -312,8 +312,10 @@ int fh_decompose_batch(fh_ctx* ctx, const double* cloud_xyz, int n_cloud, const 
                        const double local_bbox[3], double drone_radius, double z_ground, int max_faces, fh_face* faces, int32_t* counts);
 
 /* Corridors of a batch of paths, ready for fh_problem (faster.cpp:398-399: cvxEllipsoidDecomp of the path kept by createMoreVertexes /
- * deleteVertexes, then setPolytopes).  d_paths / d_n_points are what fh_map_plan_batch_device wrote with max_vertex_dist / max_poly
- * set (at most max_poly legs per path).  Pair i gets one polytope per leg; its rows are stored back to back at
+ * deleteVertexes, then setPolytopes).  d_paths / d_n_points are what fh_map_plan_batch_device wrote with max_vertex_dist set; a path of
+ * more than max_poly legs is cut to its first max_poly legs here (deleteVertexes, utils.cpp:1117-1124), so the caller can keep the whole
+ * of JPS_in — fh_safe_corridor_batch_device marches along ALL of it, as the reference does (faster.cpp:446-452) — and still get the
+ * corridor of JPS_whole.  Pair i gets one polytope per leg kept; its rows are stored back to back at
  * d_faces[i * faces_per_problem ...] with d_face_off[i][0..8] exactly as fh_problem.face_off wants them (face_begin =
  * i * faces_per_problem) and d_n_poly[i] = number of legs — 0 when the pair has no path, or a polytope exceeds FH_MAX_FACES_POLY rows,
  * or the rows do not fit faces_per_problem.  d_goal (may be NULL): the last vertex kept, the solver's E (faster.cpp:393-394).
@@ -335,7 +337,8 @@ int fh_corridor_problems_device(fh_ctx* ctx, const int32_t* d_n_points, const do
  * trajectories are solved — the faithful alternative to the hand-off of fh_pair_glue_device / fh_solve_pairs_device, which reuses
  * polytopes of the whole corridor.  Per pair:
  *   1. the path inside the sphere, JPS_in (d_paths [n][max_points][3], d_n_points [n]: what fh_map_plan_batch_device returns, first
- *      vertex = the start A), is cut where it first comes within drone_radius of unknown space and backed off by drone_radius
+ *      vertex = the start A; the WHOLE of JPS_in: plan with max_poly = 0, i.e. without deleteVertexes — the reference cuts its copy for
+ *      the whole corridor only, faster.cpp:390-392), is cut where it first comes within drone_radius of unknown space and backed off by drone_radius
  *      (getFirstCollisionJPS(..., UNKNOWN_MAP, RETURN_INTERSECTION), :451-452);
  *   2. R = sample k_safe of the whole trajectory by the rule of the context (fh_set_pair_rule; r_frac in mode 0) becomes the first
  *      vertex and x0 of the safe problem; at most max_poly_safe legs are kept (:478-490); M = the last vertex;

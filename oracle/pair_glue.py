@@ -183,15 +183,22 @@ def _norm3(v):
     return np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
 
 
-def safe_path(jps_in, A, R_pos, r_known, drone_radius, max_poly_safe):
+def safe_path(jps_in, A, R_pos, r_known, drone_radius, max_poly_safe, unknown_pts=None):
     """JPS_safe of Faster::replan: JPS_in cut where it first comes within drone_radius of unknown space (getFirstCollisionJPS against the
-    unknown map, :451-452 -> :767-926; distance to unknown space modelled as r_known - |p - A|) and backed off by drone_radius, first vertex
-    replaced by R, at most max_poly_safe legs (:478-490)."""
+    unknown map, :451-452 -> :767-926) and backed off by drone_radius, first vertex replaced by R, at most max_poly_safe legs (:478-490).
+    Distance to unknown space: modelled as r_known - |p - A|, or — unknown_pts given (fh_pair_rule mode 2) — the distance to the nearest
+    of those points, as the reference's kd-tree returns it (no point at all: the path as it was)."""
     orig = [np.array(v, dtype=np.float64) for v in jps_in]
     cur = [v.copy() for v in orig]
     iteration = 0
     while cur:
-        r = max(r_known - _norm3(cur[0] - A), 0.0)
+        if unknown_pts is not None:
+            if len(unknown_pts) == 0:
+                break
+            d = unknown_pts - cur[0]
+            r = float(np.sqrt(np.min(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])))
+        else:
+            r = max(r_known - _norm3(cur[0] - A), 0.0)
         if r < drone_radius:
             if iteration == 0:
                 orig = [orig[0], orig[0] + np.array([0.01, 0.0, 0.0])]

@@ -46,6 +46,13 @@ static int run(const int32_t* hi, const double* hd, const std::vector<V3>& occ, 
     planner.updateMap(occ, unk);
     fhreplan::ReplanLog L;
     const bool ok = planner.replan(&L);
+    if (std::getenv("FH_DEBUG_PAIR") && std::atoi(std::getenv("FH_DEBUG_PAIR")) == i) {
+      std::fprintf(stderr, "pair %d: stage %d safe path", i, L.stage);
+      for (const V3& v : L.safe_path) std::fprintf(stderr, " (%.17g, %.17g, %.17g)", v.x, v.y, v.z);
+      std::fprintf(stderr, " | xf (%.17g, %.17g, %.17g) | rows", L.safe_goal.x, L.safe_goal.y, L.safe_goal.z);
+      for (int r : L.safe_rows) std::fprintf(stderr, " %d", r);
+      std::fprintf(stderr, " | safe factor %g dt %.17g\n", L.safe_factor, planner.sg_safe_.dt_);
+    }
     const auto& plan = planner.plan();
     const int32_t rec[8] = {ok ? 1 : 0, L.stage, L.needed_safe ? 1 : 0, L.index_H, L.k_safe, (int32_t)L.n_whole, (int32_t)L.n_safe,
                             ok ? (int32_t)plan.size() : 0};

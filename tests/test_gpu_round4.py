@@ -44,8 +44,8 @@ def device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dim
     import torch
 
     dev = "cuda:0"
-    B, N, max_poly, fpp, max_states = len(starts), P["N"], P["max_poly"], 96, 1024
-    mp = max_poly + 1
+    B, N, max_poly, fpp, max_states = len(starts), P["N"], P["max_poly"], 192, 1024  # (3 polytopes of up to 64 rows: what SolverHip accepts)
+    mp = 16   # vertices of JPS_in: the WHOLE path inside the sphere (the reference cuts a copy to max_poly legs for the whole corridor only)
     whole = abi.make_problems(B)
     whole["n_seg"], whole["force_final_pos"], whole["dc"] = N, 1, P["dc"]
     whole["v_max"], whole["a_max"], whole["j_max"] = P["v_max"], P["a_max"], P["j_max"]
@@ -65,13 +65,13 @@ def device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dim
         d_wr, d_sr = torch.zeros(B * RES, dtype=torch.uint8, device=dev), torch.zeros(B * RES, dtype=torch.uint8, device=dev)
         d_plans = torch.zeros(B * max_states * abi.state_dtype.itemsize, dtype=torch.uint8, device=dev)
         d_counts, d_k = torch.zeros(B, dtype=i32, device=dev), torch.zeros(B, dtype=i32, device=dev)
-        d_spaths, d_snp = torch.zeros((B, mp, 3), dtype=f64, device=dev), torch.zeros(B, dtype=i32, device=dev)
+        d_spaths, d_snp = torch.zeros((B, max_poly + 1, 3), dtype=f64, device=dev), torch.zeros(B, dtype=i32, device=dev)
         ctx.set_pair_rule(mode=2, drone_radius=P["drone_radius"], delta_h=P["delta_h"], delta_a=P["delta_a"])
         ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, P["res"], dims)
         vmap.set_search("jps")
         vmap.set_sphere(P["Ra"])
         vmap.read_device(d_cloud.data_ptr(), len(cloud), cells, P["res"], center, 0.0, P["z_max"], P["inflation"])
-        vmap.plan_batch_device(d_starts.data_ptr(), d_goals.data_ptr(), B, mp, d_paths.data_ptr(), d_np.data_ptr(), d_ex.data_ptr(), P["dist_max_vertexes"], max_poly)
+        vmap.plan_batch_device(d_starts.data_ptr(), d_goals.data_ptr(), B, mp, d_paths.data_ptr(), d_np.data_ptr(), d_ex.data_ptr(), P["dist_max_vertexes"], 0)
         vmap.sync()
         ctx.corridor_batch_device(d_cloud.data_ptr(), len(cloud), d_paths.data_ptr(), d_np.data_ptr(), B, mp, max_poly, fpp, d_wf.data_ptr(), d_off.data_ptr(),
                                   d_npoly.data_ptr(), d_last.data_ptr(), P["decomp_radius"], 0.0)
@@ -89,7 +89,7 @@ def device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dim
                "safe": d_safe.cpu().numpy().view(abi.problem_dtype).copy(), "whole": d_whole.cpu().numpy().view(abi.problem_dtype).copy(),
                "counts": d_counts.cpu().numpy(), "k": d_k.cpu().numpy(),
                "plans": d_plans.cpu().numpy().view(abi.state_dtype).reshape(B, max_states).copy(), "snp": d_snp.cpu().numpy(),
-               "spaths": d_spaths.cpu().numpy()}
+               "spaths": d_spaths.cpu().numpy(), "paths": d_paths.cpu().numpy(), "sfaces": d_sf.cpu().numpy().view(abi.face_dtype).reshape(B, fpp).copy()}
         # rule mode 2 without a grid, and in the fused kernel, is refused loudly
         ctx.set_unknown_grid_device(None)
         with pytest.raises(capi.FasterHipError):
@@ -123,6 +123,8 @@ def stub_replans(tmp_path, cloud, cells, center, starts, vels, goals, unknown_pt
         f.write(np.ascontiguousarray(np.concatenate([starts, vels, goals], axis=1), dtype=np.float64).tobytes())
     r = subprocess.run([exe, str(sc), str(outp)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
+    if os.environ.get("FH_DEBUG_PAIR"):
+        print(r.stderr[-3000:])
     raw = open(outp, "rb").read()
     recs, pos = [], 0
     for _ in range(B):
@@ -161,15 +163,40 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
     iz, iy, ix = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
     centres = np.stack([(ix + 0.5) * P["res"] + origin[0], (iy + 0.5) * P["res"] + origin[1], (iz + 0.5) * P["res"] + origin[2]], axis=-1)
     seen = np.zeros(iz.shape, dtype=bool)
-    for c in rng.uniform([1, 1, 1.5], [19, 19, 1.5], size=(14, 3)):      # what the vehicle has explored: a few overlapping spheres
-        seen |= np.linalg.norm(centres - c, axis=-1) < rng.uniform(3.0, 5.5)
+    for c in rng.uniform([1, 1, 1.5], [19, 19, 1.5], size=(16, 3)):      # what the vehicle has explored: a few overlapping spheres
+        seen |= np.linalg.norm(centres - c, axis=-1) < rng.uniform(2.0, 3.5)
     flags = (~seen).astype(np.uint8)                                      # [nz][ny][nx], x fastest
     unknown_pts = centres[~seen]                                          # z-major, x fastest: the order the device enumerates
-    assert 0.2 < flags.mean() < 0.8
+    assert 0.2 < flags.mean() < 0.9
 
     dv = device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dims, P)
     st = stub_replans(tmp_path, cloud, cells, center, starts, vels, goals, unknown_pts, P)
 
+    # the safe corridors of a sample of pairs: the device decomposition against the unknown voxels of the grid + the occupied points
+    # equals the host decomposition of the same path against the explicit cloud [unknown voxels | occupied], row for row
+    both = np.concatenate([unknown_pts, cloud])
+    checked = 0
+    for i in np.nonzero(dv["safe"]["n_seg"] > 0)[0][:48]:
+        k = int(dv["snp"][i])
+        polys, _ = frontend.decompose(dv["spaths"][i, :k], both, P["decomp_radius"], 0.0)
+        off = dv["safe"]["face_off"][i]
+        assert dv["safe"]["n_poly"][i] == len(polys) == k - 1, i
+        for p_, (A, b) in enumerate(polys):
+            rows = dv["sfaces"][i, off[p_]:off[p_ + 1]]
+            assert len(rows) == len(b), (i, p_, len(rows), len(b))
+            assert np.array_equal(rows["a"], A) and np.array_equal(rows["b"], b), (i, p_)
+        checked += 1
+    assert checked >= 32
+    # ... and the safe paths themselves equal the numpy restatement of the march against the same unknown points (oracle/pair_glue.py)
+    from oracle import pair_glue
+
+    for i in list(np.nonzero(dv["snp"] >= 2)[0][:64]) + ([566] if B > 566 and dv["snp"][566] >= 2 else []):
+        want = pair_glue.safe_path(dv["paths"][i, : dv["np"][i]], starts[i], dv["safe"]["x0"][i, :3], 0.0, P["drone_radius"], P["max_poly"],
+                                   unknown_pts=unknown_pts)
+        got = dv["spaths"][i, : dv["snp"][i]]
+        if len(want) != len(got) or np.abs(want - got).max() > 1e-9:
+            print("safe path of pair", i, "device", got.tolist(), "numpy", want.tolist(), "JPS_in", dv["paths"][i, : dv["np"][i]].tolist())
+        assert len(want) == len(got) and np.abs(want - got).max() <= 1e-9, i
     whole_ok = (dv["np"] >= 2) & (dv["wres"]["solved"] == 1) & (dv["whole"]["n_seg"] > 0)
     need_safe = dv["safe"]["n_seg"] > 0
     safe_ok = dv["sres"]["solved"] == 1
@@ -191,8 +218,18 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
             assert not (need_safe[i] and safe_ok[i]) and dv["counts"][i] == 0, i
             continue
         assert s["stage"] == 5 and s["ok"] == 1, (i, s["stage"])
-        assert dv["k"][i] == s["k_safe"], (i, dv["k"][i], s["k_safe"], s["index_H"])
+        assert dv["k"][i] == s["k_safe"], (i, dv["k"][i], s["k_safe"], s["index_H"], "device: safe n_seg %d n_poly %d solved %d status %d trials %d, "
+                                           "safe path %d vertices %s, x0 %s xf %s | stub: needed_safe %d n_safe %d safe_factor %g" % (
+                                               dv["safe"]["n_seg"][i], dv["safe"]["n_poly"][i], dv["sres"]["solved"][i], dv["sres"]["status"][i],
+                                               dv["sres"]["trials"][i], dv["snp"][i], dv["spaths"][i].tolist(), dv["safe"]["x0"][i].tolist(),
+                                               dv["safe"]["xf"][i].tolist(), s["needed_safe"], s["n_safe"], s["safe_factor"]))
         if s["needed_safe"]:
+            if not (need_safe[i] and safe_ok[i] and s["safe_factor"] == dv["sres"]["factor"][i]):
+                print("pair", i, "device: need_safe", bool(need_safe[i]), "solved", bool(safe_ok[i]), "factor", float(dv["sres"]["factor"][i]), "dt",
+                      repr(float(dv["sres"]["dt"][i])), "status", int(dv["sres"]["status"][i]), "trials", int(dv["sres"]["trials"][i]), "rows",
+                      np.diff(dv["safe"]["face_off"][i][: dv["safe"]["n_poly"][i] + 1]).tolist(), "safe path",
+                      [tuple(float(x) for x in v) for v in dv["spaths"][i, : dv["snp"][i]]], "x0", dv["safe"]["x0"][i].tolist(), "xf",
+                      dv["safe"]["xf"][i].tolist(), "| stub factor", s["safe_factor"], "n_safe", s["n_safe"])
             assert need_safe[i] and safe_ok[i] and s["safe_factor"] == dv["sres"]["factor"][i], i
         n = len(s["plan"])
         assert dv["counts"][i] == n, (i, dv["counts"][i], n)
@@ -201,5 +238,5 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
         worst = max(worst, float(np.abs(mine - s["plan"]).max()))
     assert worst < 1e-9, worst
     # the batch exercises every outcome that matters
-    assert stages[5] > 0.7 * B and sum(1 for s in st if s["needed_safe"]) > 0.3 * B and sum(1 for s in st if s["stage"] == 5 and not s["needed_safe"]) > 10
+    assert stages[5] > 0.5 * B and sum(1 for s in st if s["needed_safe"]) > 0.15 * B and sum(1 for s in st if s["stage"] == 5 and not s["needed_safe"]) > 10
     print("replan chain == stub on %d pairs: stages %s, worst state difference %.2e" % (B, stages, worst))
