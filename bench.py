@@ -195,6 +195,10 @@ def main():
     ap.add_argument("--front", choices=["device", "host"], default="device",
                     help="c5 only: where the corridors come from — the device front-end (fh_map_* path search + fh_corridor_batch_device, "
                          "default) or the CPU front-end (same results: tests/test_gpu_round2.py)")
+    ap.add_argument("--c5-rule", choices=["reference", "c4"], default="reference",
+                    help="c5 only: how R is chosen and what the safe corridor is — reference (default): FASTER's findIndexH / findIndexR on the "
+                         "device (fh_set_pair_rule mode 1, Ra 4 m), up to 5 polytopes from the one that holds R, not pulled in: the `c5` record "
+                         "of the default run; c4: SURVEY.md 8(d)'s synthetic pairing (R at half of the trajectory, 3 polytopes pulled in by 0.2 m)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--r-margin", type=float, default=0.05,
                     help="hand-off keeps R at least this far inside its safe corridor (FASTER decomposes the safe corridor around R); "
@@ -303,6 +307,8 @@ def main():
         pp.ctx.set_stream(pp.stream.cuda_stream)
         pp.ctx.set_params(par)
         pp.ctx.set_pair_margin(r_margin)
+        if args.workload == "c5" and args.c5_rule == "reference":
+            pp.ctx.set_pair_rule(mode=1, r_known=4.0, drone_radius=0.3, delta_h=1.0, delta_a=0.5)   # Ra, delta_H, delta_a: faster.yaml
         if args.wg_per_cu:
             pp.ctx.set_sched(workgroups_per_cu=args.wg_per_cu)
         pp.d_safe = to_dev(safe_t)
@@ -323,14 +329,18 @@ def main():
     torch.cuda.synchronize()
     step_no = [0]
 
+    # the hand-off of a pair: C4 (and --c5-rule c4): R at half of the trajectory, 3 polytopes pulled in by 0.2 m;
+    # C5 by default: the reference's rule for R (set on the contexts above), up to 5 polytopes, not pulled in
+    shrink, max_safe_poly = (0.0, 5) if (args.workload == "c5" and args.c5_rule == "reference") else (0.2, 3)
+
     def run_step(pp, fused):
         c = pp.ctx
         if fused:
-            c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, 0.5, 0.2, 3, pp.d_wres.data_ptr(),
+            c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, 0.5, shrink, max_safe_poly, pp.d_wres.data_ptr(),
                                  pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), pp.d_sres.data_ptr())
         else:
             c.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, max_faces, pp.d_wres.data_ptr())
-            c.pair_glue_device(d_whole.data_ptr(), pp.d_wres.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, pp.d_safe.data_ptr(),
+            c.pair_glue_device(d_whole.data_ptr(), pp.d_wres.data_ptr(), d_faces.data_ptr(), B, 0.5, shrink, max_safe_poly, pp.d_safe.data_ptr(),
                                pp.d_sfaces.data_ptr())
             c.solve_batch_device(pp.d_safe.data_ptr(), pp.d_sfaces.data_ptr(), B, N, max_faces, pp.d_sres.data_ptr())
 
@@ -408,7 +418,9 @@ def main():
                              "synthetic corridors (faster_amd/corridor.py seed 3), hand-off keeps R >= %.2f m inside its safe corridor"
                              % (args.pairs, "job" if strong else "GPU", N, args.max_poly, args.r_margin)) if args.workload == "c4" else
                             ("C5: %d whole+safe paired solves per %s per step in a random forest (20x20x3 m, 0.1 trees/m^2), corridors from "
-                             "the voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes" % (total_pairs, "job" if strong else "GPU")),
+                             "the voxel path search + ellipsoid decomposition front-end, N=15, <=8 polytopes; hand-off: %s"
+                             % (total_pairs, "job" if strong else "GPU", "FASTER's rule for R on the device (Ra 4 m), <=5 polytopes from the one that "
+                                "holds R" if args.c5_rule == "reference" else "SURVEY 8(d) pairing (R at half, 3 polytopes pulled in 0.2 m)")),
                 "pairs_per_gpu": B,
                 "pipeline": args.pipeline,
                 "pipelines_in_flight": len(pipes),

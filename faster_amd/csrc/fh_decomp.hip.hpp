@@ -22,8 +22,12 @@
 
 namespace fh {
 
-#define FH_DECOMP_CAP 256  // points inside the local box that fit the LDS list of a segment; more: the list lives in the workgroup's HBM workspace
+#define FH_DECOMP_CAP 256  // points inside the local box whose (inflated) COORDINATES fit the LDS list of a segment
                             // (256: 10.5 KB of LDS, 12 workgroups per CU at 165 VGPRs — with 1024 and 4 per CU the same launches took 1.6x as long)
+#define FH_DECOMP_CAP_IDS 1536  // ... longer lists are kept in the SAME LDS as 4-byte ids (a cloud index, or the packed cell of an unknown
+                            // voxel) + a flag byte, and a point is rebuilt — loaded or enumerated, inflated — whenever it is looked at: the
+                            // lists of the safe corridor (2-3 k unknown voxels per local box) used to live in the workgroup's HBM workspace
+                            // and were rewritten there after every separating plane (3-5 GB of writes per dispatch)
 #define FH_DECOMP_EPS 1e-10  // DecompUtil's epsilon_
 
 struct D3 {
@@ -77,20 +81,20 @@ __device__ __forceinline__ double ell_dist(const Rot& R, D3 ax, D3 c, D3 q) {
 __device__ __forceinline__ int sgn_i(double v) { return (0.0 < v) - (v < 0.0); }
 
 // arg-min of the ellipsoid distance over the list entries whose flag has `bit`; returns the list index (-1 if none)
-template <class PD, class PF>
-__device__ __forceinline__ int closest_in(PD px, PD py, PD pz, PF flag, int cnt, unsigned char bit, const Rot& R, D3 ax, D3 c, int lane) {
+template <class L>
+__device__ __forceinline__ int closest_in(const L& list, int cnt, unsigned char bit, const Rot& R, D3 ax, D3 c, int lane) {
   double best = INFINITY;
   int bi = -1;
   for (int i = lane; i < cnt; i += 64)
-    if (flag[i] & bit) {
-      const double dd = ell_dist(R, ax, c, d3(px[i], py[i], pz[i]));
+    if (list.flag(i) & bit) {
+      const double dd = ell_dist(R, ax, c, list.get(i));
       if (dd < best) { best = dd; bi = i; }
     }
   const double mn = wave_min(best);
   if (!(mn < INFINITY)) {  // empty set, or every distance is NaN: any member (the host version does the same)
     int anyi = -1;
     for (int i = lane; i < cnt && anyi < 0; i += 64)
-      if (flag[i] & bit) anyi = i;
+      if (list.flag(i) & bit) anyi = i;
     const int l2 = first_lane(anyi >= 0);
     return l2 >= 0 ? __builtin_amdgcn_readlane(anyi, l2) : -1;
   }
@@ -135,14 +139,20 @@ __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat,
   g.z0 = first(lo[2], lat.oz, lat.res, lat.nz); g.cz = last(hi[2], lat.oz, lat.res, lat.nz) - g.z0 + 1;
   if (g.cx <= 0 || g.cy <= 0 || g.cz <= 0) return g;
   const long long cells = (long long)g.cx * g.cy * g.cz;
-  g.total = cells > (1ll << 28) ? -1 : (int)cells;  // -1: a grid far too fine for the local box — the segment reports failure (count -1)
+  g.total = (cells > (1ll << 28) || g.cx > 1024 || g.cy > 1024 || g.cz > 1024) ? -1 : (int)cells;  // -1: a grid far too fine for the local box — the segment reports failure (count -1)
   if (sphere) { g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3]; }
   return g;
 }
-// cell number idx of the sub-block: its centre, and whether it is an unknown voxel
-__device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const LatticeRange& g, int idx, D3& q) {
+// centre of the cell (ix, iy, iz) of the sub-block; `packed` = iz << 20 | iy << 10 | ix (a sub-block has at most 1024 cells per axis)
+__device__ __forceinline__ D3 lattice_centre(const UnknownLattice& lat, const LatticeRange& g, int packed) {
+  const int ix = packed & 1023, iy = (packed >> 10) & 1023, iz = (packed >> 20) & 1023;
+  return d3(((double)(g.x0 + ix) + 0.5) * lat.res + lat.ox, ((double)(g.y0 + iy) + 0.5) * lat.res + lat.oy, ((double)(g.z0 + iz) + 0.5) * lat.res + lat.oz);
+}
+// cell number idx of the sub-block: its centre, its packed coordinates, and whether it is an unknown voxel
+__device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const LatticeRange& g, int idx, D3& q, int* packed = nullptr) {
   if (idx >= g.total) return false;
   const int iz = idx / (g.cx * g.cy), rem = idx - iz * (g.cx * g.cy), iy = rem / g.cx, ix = rem - iy * g.cx;
+  if (packed) *packed = (iz << 20) | (iy << 10) | ix;
   q = d3(((double)(g.x0 + ix) + 0.5) * lat.res + lat.ox, ((double)(g.y0 + iy) + 0.5) * lat.res + lat.oy, ((double)(g.z0 + iz) + 0.5) * lat.res + lat.oz);
   if (lat.flags) return lat.flags[((size_t)(g.z0 + iz) * lat.ny + (g.y0 + iy)) * lat.nx + (g.x0 + ix)] != 0;
   const double dx = q.x - g.ax, dy = q.y - g.ay, dz = q.z - g.az;
@@ -150,12 +160,53 @@ __device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const L
 }
 
 #define FH_DECOMP_BLIST 1024  // candidate blocks per segment (more: full sweep)
-#define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the list lives in the HBM workspace (dense clouds); more => count = -1
+#define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the (id) list lives in the HBM workspace (dense clouds); more => count = -1
 
-// The decomposition of one segment with its list of box points at px/py/pz/flag (LDS for <= FH_DECOMP_CAP points, else the
-// per-workgroup HBM workspace).  `store`: compaction pass of the cloud sweep into the list.
-template <class PD, class PF>
-__device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
+// ---- what a segment's list of box points is made of ----
+// CoordList: the inflated coordinates themselves (short lists: a look is three LDS loads).
+struct CoordList {
+  double *px, *py, *pz;
+  unsigned char* fl;
+  typedef D3 Entry;
+  __device__ __forceinline__ D3 get(int i) const { return d3(px[i], py[i], pz[i]); }
+  __device__ __forceinline__ Entry entry(int i) const { return d3(px[i], py[i], pz[i]); }
+  __device__ __forceinline__ D3 point(const Entry& e) const { return e; }
+  __device__ __forceinline__ unsigned char flag(int i) const { return fl[i]; }
+  __device__ __forceinline__ void set_flag(int i, unsigned char f) const { fl[i] = f; }
+  __device__ __forceinline__ void store(int pos, const Entry& e, unsigned char f) const { px[pos] = e.x; py[pos] = e.y; pz[pos] = e.z; fl[pos] = f; }
+  __device__ __forceinline__ void put(int pos, D3 inflated, int) const { px[pos] = inflated.x; py[pos] = inflated.y; pz[pos] = inflated.z; }
+  static constexpr bool kNeedsPoint = true;  // put() wants the inflated point
+};
+// IdList: which point it is — cloud index (>= 0) or 0x80000000 | packed cell of the unknown lattice — rebuilt at every look with the
+// arithmetic that CoordList applied once (the same doubles).
+struct IdList {
+  int* id;
+  unsigned char* fl;
+  const double* cloud;
+  const UnknownLattice* lat;
+  const LatticeRange* lr;
+  Rot Ri;
+  D3 c;
+  double inflate;
+  typedef int Entry;
+  __device__ __forceinline__ D3 point(const Entry& e) const {
+    const D3 q = e < 0 ? lattice_centre(*lat, *lr, e & 0x7fffffff) : d3(cloud[3 * (size_t)e], cloud[3 * (size_t)e + 1], cloud[3 * (size_t)e + 2]);
+    const D3 l = mulT(Ri, q - c);
+    return mul(Ri, d3(l.x - sgn_i(l.x) * inflate, l.y - sgn_i(l.y) * inflate, l.z - sgn_i(l.z) * inflate)) + c;
+  }
+  __device__ __forceinline__ D3 get(int i) const { return point(id[i]); }
+  __device__ __forceinline__ Entry entry(int i) const { return id[i]; }
+  __device__ __forceinline__ unsigned char flag(int i) const { return fl[i]; }
+  __device__ __forceinline__ void set_flag(int i, unsigned char f) const { fl[i] = f; }
+  __device__ __forceinline__ void store(int pos, const Entry& e, unsigned char f) const { id[pos] = e; fl[pos] = f; }
+  __device__ __forceinline__ void put(int pos, D3, int ident) const { id[pos] = ident; }
+  static constexpr bool kNeedsPoint = false;
+};
+
+// The decomposition of one segment with its list of box points in `list` (CoordList / IdList in LDS, IdList in the per-workgroup HBM
+// workspace for the densest clouds).  The first pass of the cloud sweep (the count) has been made by the caller; this is the second.
+template <class L>
+__device__ void decomp_segment(const L& list, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
                                const D3* bn, double inflate, double z_ground, int max_faces, fh_face* __restrict__ out,
                                int32_t* __restrict__ count_out, int lane, const int* blist, int nb, const UnknownLattice& lat,
                                const LatticeRange& lrange) {
@@ -165,24 +216,28 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
   const D3 c = (p1 + p2) * 0.5;
   // ---- sweep the points: keep those inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
   int cnt = 0;
-  auto keep = [&](bool in, D3 q) {
+  auto keep = [&](bool in, D3 q, int ident) {
 #pragma unroll
     for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
     const unsigned long long m = __ballot(in);
     if (m) {
       if (in) {
         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        const D3 l = mulT(Ri, q - c);
-        const D3 qi = mul(Ri, d3(l.x - sgn_i(l.x) * inflate, l.y - sgn_i(l.y) * inflate, l.z - sgn_i(l.z) * inflate)) + c;
-        px[pos] = qi.x; py[pos] = qi.y; pz[pos] = qi.z;
+        D3 qi = q;
+        if (L::kNeedsPoint) {
+          const D3 l = mulT(Ri, q - c);
+          qi = mul(Ri, d3(l.x - sgn_i(l.x) * inflate, l.y - sgn_i(l.y) * inflate, l.z - sgn_i(l.z) * inflate)) + c;
+        }
+        list.put(pos, qi, ident);
       }
       cnt += __popcll(m);
     }
   };
   for (int base = 0; base < lrange.total; base += 64) {  // the unknown voxels first (a cloud of unknown + occupied points lists them first)
     D3 q = d3(0, 0, 0);
-    const bool in = lattice_point(lat, lrange, base + lane, q);
-    keep(in, q);
+    int packed = 0;
+    const bool in = lattice_point(lat, lrange, base + lane, q, &packed);
+    keep(in, q, (int)(0x80000000u | (unsigned)packed));
   }
   const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;  // (the blocks of 64 cloud points that can touch the box, in cloud order)
   for (int j = 0; j < n_sweep; j++) {
@@ -194,45 +249,50 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
       q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
       in = true;
     }
-    keep(in, q);
+    keep(in, q, i);
   }
   __syncthreads();
 
   // ---- ellipsoid fit (line_segment.h:156-252)
   D3 axes = d3(f, f, f);
   for (int i = lane; i < cnt; i += 64) {
-    const bool fi = ell_dist(Ri, axes, c, d3(px[i], py[i], pz[i])) <= 1.0;
-    flag[i] = (unsigned char)((fi ? 3 : 0) | 4);  // first, inside; remain
+    const bool fi = ell_dist(Ri, axes, c, list.get(i)) <= 1.0;
+    list.set_flag(i, (unsigned char)((fi ? 3 : 0) | 4));  // first, inside; remain
   }
   __syncthreads();
   Rot Rf = Ri;
   D3 cur = axes;
   for (int guard = 0; guard <= cnt; guard++) {  // second axis
-    const int ic = closest_in(px, py, pz, flag, cnt, 2, Rf, cur, c, lane);
+    const int ic = closest_in(list, cnt, 2, Rf, cur, c, lane);
     if (ic < 0) break;
-    const D3 pw = d3(px[ic], py[ic], pz[ic]);
+    const D3 pw = list.get(ic);
     D3 l = mulT(Ri, pw - c);
     Rf = rot_roll(Ri, l.z, l.y);
     l = mulT(Rf, pw - c);
     if (l.x < axes.x) axes.y = fabs(l.y) / sqrt(1 - (l.x / axes.x) * (l.x / axes.x));
     cur = d3(axes.x, axes.y, axes.y);
-    for (int i = lane; i < cnt; i += 64)
-      if ((flag[i] & 2) && !(1 - ell_dist(Rf, cur, c, d3(px[i], py[i], pz[i])) > FH_DECOMP_EPS)) flag[i] &= (unsigned char)~2;
+    for (int i = lane; i < cnt; i += 64) {
+      const unsigned char fl = list.flag(i);
+      if ((fl & 2) && !(1 - ell_dist(Rf, cur, c, list.get(i)) > FH_DECOMP_EPS)) list.set_flag(i, (unsigned char)(fl & ~2));
+    }
     __syncthreads();
   }
   for (int i = lane; i < cnt; i += 64) {  // third axis back to its initial length; restart from the first set
-    const bool in2 = (flag[i] & 1) && ell_dist(Rf, axes, c, d3(px[i], py[i], pz[i])) <= 1.0;
-    flag[i] = (unsigned char)((flag[i] & ~2) | (in2 ? 2 : 0));
+    const unsigned char fl = list.flag(i);
+    const bool in2 = (fl & 1) && ell_dist(Rf, axes, c, list.get(i)) <= 1.0;
+    list.set_flag(i, (unsigned char)((fl & ~2) | (in2 ? 2 : 0)));
   }
   __syncthreads();
   for (int guard = 0; guard <= cnt; guard++) {
-    const int ic = closest_in(px, py, pz, flag, cnt, 2, Rf, axes, c, lane);
+    const int ic = closest_in(list, cnt, 2, Rf, axes, c, lane);
     if (ic < 0) break;
-    const D3 l = mulT(Rf, d3(px[ic], py[ic], pz[ic]) - c);
+    const D3 l = mulT(Rf, list.get(ic) - c);
     const double dd = 1 - (l.x / axes.x) * (l.x / axes.x) - (l.y / axes.y) * (l.y / axes.y);
     if (dd > FH_DECOMP_EPS) axes.z = fabs(l.z) / sqrt(dd);
-    for (int i = lane; i < cnt; i += 64)
-      if ((flag[i] & 2) && !(1 - ell_dist(Rf, axes, c, d3(px[i], py[i], pz[i])) > FH_DECOMP_EPS)) flag[i] &= (unsigned char)~2;
+    for (int i = lane; i < cnt; i += 64) {
+      const unsigned char fl = list.flag(i);
+      if ((fl & 2) && !(1 - ell_dist(Rf, axes, c, list.get(i)) > FH_DECOMP_EPS)) list.set_flag(i, (unsigned char)(fl & ~2));
+    }
     __syncthreads();
   }
 
@@ -249,9 +309,9 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
   };
   const int cnt_planes = cnt;  // (every plane puts at least the point it passes through away)
   for (int guard = 0; guard <= cnt_planes; guard++) {
-    const int ic = closest_in(px, py, pz, flag, cnt, 4, Rf, axes, c, lane);
+    const int ic = closest_in(list, cnt, 4, Rf, axes, c, lane);
     if (ic < 0) break;
-    const D3 cp = d3(px[ic], py[ic], pz[ic]);
+    const D3 cp = list.get(ic);
     const D3 l = mulT(Rf, cp - c);
     const D3 g = mul(Rf, d3(l.x / (axes.x * axes.x), l.y / (axes.y * axes.y), l.z / (axes.z * axes.z)));
     const double gn = norm(g);
@@ -264,18 +324,16 @@ __device__ void decomp_segment(PD px, PD py, PD pz, PF flag, const double* __res
     for (int i0 = 0; i0 < cnt; i0 += 64) {
       const int i = i0 + lane;
       bool stay = false;
-      D3 q = d3(0, 0, 0);
-      unsigned char f = 0;
+      typename L::Entry e = typename L::Entry();
+      unsigned char fl = 0;
       if (i < cnt) {
-        f = flag[i];
-        q = d3(px[i], py[i], pz[i]);
-        stay = (f & 4) && (dot(n, q - cp) < 0);
+        fl = list.flag(i);
+        e = list.entry(i);
+        stay = (fl & 4) && (dot(n, list.point(e) - cp) < 0);
       }
       const unsigned long long m = __ballot(stay);
-      if (stay) {
-        const int pos = alive + __popcll(m & ((1ull << lane) - 1ull));
-        px[pos] = q.x; py[pos] = q.y; pz[pos] = q.z; flag[pos] = f;
-      }
+      __syncthreads();  // (every entry of this block of 64 has been read before any of them is overwritten)
+      if (stay) list.store(alive + __popcll(m & ((1ull << lane) - 1ull)), e, fl);
       alive += __popcll(m);
       __syncthreads();
     }
@@ -304,19 +362,18 @@ __global__ void __launch_bounds__(64) cloud_blocks_kernel(const double* __restri
 
 // Persistent workgroups of one wavefront, segments taken in a grid-stride loop.  segments: [n][6] = p1, p2.  faces: [n][max_faces] rows
 // (a, b); counts[n] = rows written, -1 on overflow.  workspace: per workgroup 3 * CAP_GLOBAL doubles + CAP_GLOBAL bytes.
-__global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
+__global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
                                                     int n_segments, double bx, double by, double bz, double inflate, double z_ground,
                                                     int max_faces, double* __restrict__ workspace, fh_face* __restrict__ faces,
                                                     int32_t* __restrict__ counts, const double* __restrict__ blocks, UnknownLattice lat,
                                                     const double* __restrict__ spheres) {
-  __shared__ double lpx[FH_DECOMP_CAP], lpy[FH_DECOMP_CAP], lpz[FH_DECOMP_CAP];
-  __shared__ unsigned char lflag[FH_DECOMP_CAP];  // bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
+  // the segment's list of box points: 256 inflated points (3 x 256 doubles + 256 flag bytes) or, in the same bytes, 1536 ids + flag bytes.
+  // flags: bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
+  static_assert(FH_DECOMP_CAP_IDS * 4 <= 3 * FH_DECOMP_CAP * 8 && FH_DECOMP_CAP <= FH_DECOMP_CAP_IDS, "the id list aliases the coordinate list");
+  __shared__ double lraw[3 * FH_DECOMP_CAP + FH_DECOMP_CAP_IDS / 8];
   __shared__ int lblist[FH_DECOMP_BLIST];         // blocks of the cloud that can touch the local box, ascending
   const int lane = threadIdx.x;
-  double* gpx = workspace + (size_t)blockIdx.x * (size_t)(3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8);
-  double* gpy = gpx + FH_DECOMP_CAP_GLOBAL;
-  double* gpz = gpy + FH_DECOMP_CAP_GLOBAL;
-  unsigned char* gflag = reinterpret_cast<unsigned char*>(gpz + FH_DECOMP_CAP_GLOBAL);
+  double* gws = workspace + (size_t)blockIdx.x * (size_t)(3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8);  // (ids + flags of the densest clouds)
   for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
     __syncthreads();
     const D3 p1 = d3(segments[6 * seg + 0], segments[6 * seg + 1], segments[6 * seg + 2]);
@@ -401,12 +458,25 @@ __global__ void __launch_bounds__(64) decomp_kernel(const double* __restrict__ c
       }
       cnt += __popcll(__ballot(in));
     }
-    if (cnt <= FH_DECOMP_CAP)
-      decomp_segment(lpx, lpy, lpz, lflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat,
-                     lrange);
-    else if (cnt <= FH_DECOMP_CAP_GLOBAL)
-      decomp_segment(gpx, gpy, gpz, gflag, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat,
-                     lrange);
+    const Rot Ri0 = rot_onto(p2 - p1);
+    const D3 c0 = (p1 + p2) * 0.5;
+    if (cnt <= FH_DECOMP_CAP) {
+      CoordList L;
+      L.px = lraw; L.py = lraw + FH_DECOMP_CAP; L.pz = lraw + 2 * FH_DECOMP_CAP;
+      L.fl = reinterpret_cast<unsigned char*>(lraw + 3 * FH_DECOMP_CAP);
+      decomp_segment(L, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange);
+    } else if (cnt <= FH_DECOMP_CAP_GLOBAL) {
+      IdList L;
+      if (cnt <= FH_DECOMP_CAP_IDS) {
+        L.id = reinterpret_cast<int*>(lraw);
+        L.fl = reinterpret_cast<unsigned char*>(lraw + 3 * FH_DECOMP_CAP);
+      } else {
+        L.id = reinterpret_cast<int*>(gws);
+        L.fl = reinterpret_cast<unsigned char*>(gws + FH_DECOMP_CAP_GLOBAL);
+      }
+      L.cloud = cloud; L.lat = &lat; L.lr = &lrange; L.Ri = Ri0; L.c = c0; L.inflate = inflate;
+      decomp_segment(L, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange);
+    }
     else if (lane == 0)
       counts[seg] = -1;
   }

@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for the C5 kernel (fh::solve_kernel<15, true>): kernel stats and PMC passes of bench.py --workload c5
 set -u
-TAG=${1:-r03_c5}
+TAG=${1:-r04_c5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --no-cpu --no-extra --workload c5 --pairs 65536 --inflight 1 --steps 4 --warmup 1"
+BENCH="python $R/bench.py --no-cpu --no-extra --workload c5 --c5-rule reference --pairs 65536 --inflight 1 --steps 4 --warmup 1"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_solo -o s -- $BENCH > $OUT/stats_solo.log 2>&1
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
