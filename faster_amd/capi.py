@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
-    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule", "fh_set_unknown_grid_device",
+    "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule", "fh_set_unknown_grid_device", "fh_next_goals_device",
     "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_corridor_problems_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
@@ -104,6 +104,8 @@ def lib():
         L.fh_set_pair_rule.argtypes = [vp, vp]
         L.fh_set_unknown_grid_device.restype = i32
         L.fh_set_unknown_grid_device.argtypes = [vp, vp, vp]
+        L.fh_next_goals_device.restype = i32
+        L.fh_next_goals_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
         L.fh_packed_result_size.restype = ctypes.c_size_t
         L.fh_packed_result_size.argtypes = [i32]
         L.fh_pack_results_device.restype = i32
@@ -546,6 +548,10 @@ class Context:
         """fh_append_plans_device: Faster::appendToPlan for a batch of pairs (whole samples 0..k_safe, then the safe samples)."""
         self._check(lib().fh_append_plans_device(self._h, d_whole, d_whole_results, d_safe, d_safe_results, n, r_frac, max_states, d_plans,
                                                  d_counts, d_k_safe), "fh_append_plans_device")
+
+    def next_goals_device(self, d_plans, d_counts, d_cursor, n, max_states, ticks, d_goals, d_ok=None):
+        """fh_next_goals_device: Faster::getNextGoal (without yaw) for a batch of committed plans; `ticks` calls in a row."""
+        self._check(lib().fh_next_goals_device(self._h, d_plans, d_counts, d_cursor, n, max_states, ticks, d_goals, d_ok), "fh_next_goals_device")
 
     def pair_glue_device(self, d_whole, d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly, d_safe, d_safe_faces):
         self._check(lib().fh_pair_glue_device(self._h, d_whole, d_whole_results, d_faces, n, r_frac, shrink, max_safe_poly,

@@ -753,6 +753,19 @@ int fh_append_plans_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_resu
   return FH_OK;
 }
 
+int fh_next_goals_device(fh_ctx* ctx, const fh_state* d_plans, const int32_t* d_counts, int32_t* d_cursor, int n, int max_states, int ticks,
+                         fh_state* d_goals, int32_t* d_ok) {
+  if (!ctx || n < 0 || max_states < 1 || ticks < 1) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_plans || !d_counts || !d_cursor || !d_goals) return FH_ERR_ARG;
+  hipLaunchKernelGGL(fh::next_goal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_plans, d_counts, d_cursor, n, max_states,
+                     ticks, d_goals, d_ok);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
 int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face* d_faces, int n, int max_seg, int max_faces,
                           double r_frac, double shrink, int max_safe_poly, fh_result* d_whole_results, fh_problem* d_safe,
                           fh_face* d_safe_faces, fh_result* d_safe_results) {

@@ -428,4 +428,29 @@ __global__ void __launch_bounds__(64) plan_append_kernel(const fh_problem* __res
   }
 }
 
+// Faster::getNextGoal (faster/src/faster.cpp:699-723, without the yaw of getDesiredYaw: yaw planning is out of scope) for a batch of
+// committed plans: plan i is the states plans[i][cursor[i] .. counts[i]) — `next_goal = plan_.front(); if (plan_.size() > 1)
+// plan_.pop_front()`: the front state goes out, and the plan keeps at least its last state (a vehicle that has used up its plan
+// hovers on the last state).  An empty plan (counts[i] == 0: nothing was committed) gives a zero state (next_goal.setZero()) and
+// ok[i] = 0.  `ticks` calls in a row: the state after ticks - 1 pops is returned and the cursor advanced by up to `ticks`.
+__global__ void __launch_bounds__(256) next_goal_kernel(const fh_state* __restrict__ plans, const int32_t* __restrict__ counts,
+                                                        int32_t* __restrict__ cursor, int n, int max_states, int ticks,
+                                                        fh_state* __restrict__ goals, int32_t* __restrict__ ok) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= n) return;
+  const int cnt = counts[i] < max_states ? counts[i] : max_states;  // (states actually stored)
+  fh_state g;
+  for (int k = 0; k < 3; k++) { g.pos[k] = 0; g.vel[k] = 0; g.accel[k] = 0; g.jerk[k] = 0; }
+  int c = cursor[i];
+  if (cnt > 0) {
+    c = c < 0 ? 0 : (c > cnt - 1 ? cnt - 1 : c);
+    const int last_read = c + (ticks - 1) < cnt - 1 ? c + (ticks - 1) : cnt - 1;  // front() of the last of the `ticks` calls
+    g = plans[(size_t)i * (size_t)max_states + last_read];
+    c = c + ticks < cnt - 1 ? c + ticks : cnt - 1;                                // pop_front() while more than one state is left
+    cursor[i] = c;
+  }
+  goals[i] = g;
+  if (ok) ok[i] = cnt > 0 ? 1 : 0;
+}
+
 }  // namespace fh

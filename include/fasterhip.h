@@ -298,6 +298,15 @@ int fh_append_plans_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_resu
                            const fh_result* d_safe_results, int n, double r_frac, int max_states, fh_state* d_plans, int32_t* d_counts,
                            int32_t* d_k_safe);
 
+/* Faster::getNextGoal (faster/src/faster.cpp:699-723) for a batch of committed plans — the consumer of what fh_append_plans_device
+ * wrote: plan i is d_plans[i][d_cursor[i] .. d_counts[i]); a call returns its front state and pops it unless it is the last one
+ * (`next_goal = plan_.front(); if (plan_.size() > 1) plan_.pop_front();`), `ticks` calls in a row return the state of the last of them
+ * and advance the cursor by up to `ticks`.  Yaw (getDesiredYaw) is not computed: yaw planning is out of scope.  A pair that committed
+ * nothing (d_counts[i] == 0) gets a zero state and d_ok[i] = 0 (may be NULL).  d_cursor [n] starts at zero.  Asynchronous on the
+ * context stream. */
+int fh_next_goals_device(fh_ctx* ctx, const fh_state* d_plans, const int32_t* d_counts, int32_t* d_cursor, int n, int max_states, int ticks,
+                         fh_state* d_goals, int32_t* d_ok);
+
 /* ---- next row N1 on the device: convex decomposition around path segments ------------------------------ */
 /* JPS_Manager::cvxEllipsoidDecomp (faster/src/jps_manager.cpp:80-127) for a batch of path segments that share one obstacle
  * cloud: per segment the rows [a | b] of its polytope (separating planes of the inflated obstacle points found by DecompUtil's

@@ -20,8 +20,10 @@ ctx = capi.Context(0)
 whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=10, p_choices=(2, 3, 4, 5, 6))
 
 
-def report(tag, res):
-    res = res[res["trials"] > 0]
+def report(tag, res, min_nodes=0):
+    res = res[(res["trials"] > 0) & (res["nodes"] >= min_nodes)]
+    if len(res) == 0:
+        return 0.0
     M = abi.FH_MAX_SEG
     prof = np.concatenate([res["coeff"][:, M - 1, :12], res["coeff"][:, M - 3, :12]], axis=1)
     cnt = np.concatenate([res["coeff"][:, M - 2, :12], res["coeff"][:, M - 4, :12]], axis=1).sum(axis=0)
@@ -67,4 +69,5 @@ else:
     ms = ctx.timing_read()
     a = report("whole problems of the pairs", d_wr.cpu().numpy().view(abi.result_dtype).copy())
     b = report("safe problems of the pairs", d_sr.cpu().numpy().view(abi.result_dtype).copy())
+    report("the HARD whole problems (>= 40 nodes)", d_wr.cpu().numpy().view(abi.result_dtype).copy(), min_nodes=40)
     print("per pair: %.0f cycles in the slots; launches %s ms" % (a + b, [round(float(x), 3) for x in ms[-2:]]))

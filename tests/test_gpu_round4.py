@@ -85,7 +85,16 @@ def device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dim
         ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states, d_plans.data_ptr(),
                                 d_counts.data_ptr(), d_k.data_ptr())
         ctx.sync()
-        out = {"np": d_np.cpu().numpy(), "wres": d_wr.cpu().numpy().view(abi.result_dtype).copy(), "sres": d_sr.cpu().numpy().view(abi.result_dtype).copy(),
+        # the consumer of the plans: Faster::getNextGoal for every pair, 1 call, then 7 more, then far beyond the end of every plan
+        d_cursor = torch.zeros(B, dtype=i32, device=dev)
+        d_goal_states = torch.zeros(B * abi.state_dtype.itemsize, dtype=torch.uint8, device=dev)
+        d_okg = torch.zeros(B, dtype=i32, device=dev)
+        next_goals = []
+        for ticks in (1, 7, 5000):
+            ctx.next_goals_device(d_plans.data_ptr(), d_counts.data_ptr(), d_cursor.data_ptr(), B, max_states, ticks, d_goal_states.data_ptr(), d_okg.data_ptr())
+            ctx.sync()
+            next_goals.append((d_goal_states.cpu().numpy().view(abi.state_dtype).copy(), d_cursor.cpu().numpy().copy(), d_okg.cpu().numpy().copy()))
+        out = {"next_goals": next_goals, "np": d_np.cpu().numpy(), "wres": d_wr.cpu().numpy().view(abi.result_dtype).copy(), "sres": d_sr.cpu().numpy().view(abi.result_dtype).copy(),
                "safe": d_safe.cpu().numpy().view(abi.problem_dtype).copy(), "whole": d_whole.cpu().numpy().view(abi.problem_dtype).copy(),
                "counts": d_counts.cpu().numpy(), "k": d_k.cpu().numpy(),
                "plans": d_plans.cpu().numpy().view(abi.state_dtype).reshape(B, max_states).copy(), "snp": d_snp.cpu().numpy(),
@@ -237,6 +246,18 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
         mine = np.concatenate([got["pos"], got["vel"], got["accel"], got["jerk"]], axis=1)
         worst = max(worst, float(np.abs(mine - s["plan"]).max()))
     assert worst < 1e-9, worst
+    # getNextGoal on the committed plans (faster.cpp:699-723: front(), pop_front() while more than one state is left): calls 1, 8 and 5008
+    called = 0
+    for (g, cur, okg), ticks in zip(dv["next_goals"], (1, 7, 5000)):
+        called += ticks
+        for i in range(B):
+            n = int(dv["counts"][i])
+            if n == 0:
+                assert okg[i] == 0 and not g["pos"][i].any() and not g["vel"][i].any(), i
+                continue
+            want_front = min(called - 1, n - 1)          # the state the last of the calls so far returned
+            assert okg[i] == 1 and cur[i] == min(called, n - 1), (i, cur[i], called, n)
+            assert np.array_equal(g["pos"][i], dv["plans"]["pos"][i, want_front]) and np.array_equal(g["jerk"][i], dv["plans"]["jerk"][i, want_front]), i
     # the batch exercises every outcome that matters
     assert stages[5] > 0.5 * B and sum(1 for s in st if s["needed_safe"]) > 0.15 * B and sum(1 for s in st if s["stage"] == 5 and not s["needed_safe"]) > 10
     print("replan chain == stub on %d pairs: stages %s, worst state difference %.2e" % (B, stages, worst))
