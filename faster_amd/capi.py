@@ -20,7 +20,7 @@ SYMBOLS = [
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
     "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
-    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_set_sphere", "fh_map_sync", "fh_map_read", "fh_map_read_device",
+    "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_set_records", "fh_map_workspace_bytes", "fh_map_set_sphere", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
     "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
     "fh_packed_result_size", "fh_pack_results_device", "fh_pack_results", "fh_unpack_results",
@@ -96,6 +96,10 @@ def lib():
         L.fh_map_set_sched.argtypes = [vp, i32, i32]
         L.fh_map_set_search.restype = i32
         L.fh_map_set_search.argtypes = [vp, i32]
+        L.fh_map_set_records.restype = i32
+        L.fh_map_set_records.argtypes = [vp, i32]
+        L.fh_map_workspace_bytes.restype = ctypes.c_longlong
+        L.fh_map_workspace_bytes.argtypes = [vp]
         L.fh_map_set_sphere.restype = i32
         L.fh_map_set_sphere.argtypes = [vp, f64]
         L.fh_set_pair_margin.restype = i32
@@ -308,6 +312,15 @@ class Map:
         order: the optimal path FASTER itself gets)."""
         self._check(lib().fh_map_set_search(self._h, {"astar": 0, "jps": 1}[mode]), "fh_map_set_search")
         self.search = mode
+
+    def set_records(self, slots):
+        """fh_map_set_records: 0 = one cell record per cell of the map and wavefront; a power of two = that many hashed records per
+        wavefront (jump point search only; a query that reaches more than 3/4 of them returns -2); -1 (default) = by the size of the map."""
+        self._check(lib().fh_map_set_records(self._h, int(slots)), "fh_map_set_records")
+
+    def workspace_bytes(self):
+        """fh_map_workspace_bytes: the search workspace as allocated by the last search."""
+        return int(lib().fh_map_workspace_bytes(self._h))
 
     def read(self, cloud, cells, res, center, z_ground, z_max, inflation):
         cloud = np.ascontiguousarray(cloud, dtype=np.float64).reshape(-1, 3)

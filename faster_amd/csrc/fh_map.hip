@@ -31,6 +31,11 @@ struct fh_map {
   int waves = 0;
   size_t ws_total = 0;  // cells per wavefront the workspace was sized for
   fhp::CellState* d_cells = nullptr;
+  unsigned long long* d_hkeys = nullptr;  // hashed cell records (fh_map_set_records): the keys of d_cells' slots
+  int record_slots = -1;                  // fh_map_set_records: -1 by the size of the map, 0 one record per cell and wavefront, else hashed records, that many per wavefront
+  int ws_slots = -1;                      // what the workspace was sized for
+  size_t ws_bytes = 0;
+  size_t chunk_words = 0;                 // words of d_chunks per wavefront
   unsigned* d_chunks = nullptr;
   unsigned* d_serials = nullptr;
   int* d_ticket = nullptr;
@@ -83,30 +88,46 @@ int stage(fh_map* m, int slot, size_t bytes) {
   return FH_OK;
 }
 
-// per-wavefront search state: sized by the grid; at most 12 wavefronts per CU (3 per SIMD) and 48 GB
+// per-wavefront search state: sized by the grid (or, with hashed records, by the number of slots); at most 12 wavefronts per CU
+// (3 per SIMD) and 48 GB
 int ensure_workspace(fh_map* m) {
   const size_t total = (size_t)m->nx * m->ny * m->nz;
-  const size_t per_wave = total * sizeof(fhp::CellState) + (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS * 4;
   // LDS: 12.5 KB per wavefront (A*: 12 per CU), 7.5 KB and 96 VGPRs (jump point search: 20 per CU)
   int waves = m->n_cu * (m->sched_waves_per_cu > 0 ? m->sched_waves_per_cu : (m->search_mode == 1 ? 20 : 12));
+  int slots = m->search_mode == 1 ? m->record_slots : 0;
+  if (slots < 0) slots = (size_t)waves * total * sizeof(fhp::CellState) > ((size_t)32 << 30) ? 65536 : 0;
+  const size_t records = slots > 0 ? (size_t)slots : total;
+  // the chunk pool: open-list chunks (A*), the heap levels below LDS (jump point search: 60000 entries of 20 B; with hashed records a
+  // cell has one heap entry at most, so 3/4 of the slots), and the clean-up lists of the finished path (3 x MAXRAW ints)
+  const size_t chunk_words = slots > 0 ? std::max<size_t>((size_t)(slots / 4 * 3) * 5, (size_t)3 * fhp::MAXRAW) + 16 : (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS;
+  const size_t per_wave = records * sizeof(fhp::CellState) + (slots > 0 ? (size_t)slots * 8 : 0) + chunk_words * 4;
   const size_t budget = (size_t)48 << 30;
   if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);
-  if (m->d_cells && m->ws_total == total && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
+  if (m->d_cells && m->ws_total == total && m->ws_slots == slots && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
   FM_HIP(hipStreamSynchronize(m->stream));
   if (m->d_cells) FM_HIP(hipFree(m->d_cells));
+  if (m->d_hkeys) FM_HIP(hipFree(m->d_hkeys));
+  m->d_hkeys = nullptr;
   if (m->d_chunks) FM_HIP(hipFree(m->d_chunks));
   if (m->d_serials) FM_HIP(hipFree(m->d_serials));
   m->d_cells = nullptr; m->d_chunks = nullptr; m->d_serials = nullptr;
   m->waves = 0;
-  FM_HIP(hipMalloc(&m->d_cells, (size_t)waves * total * sizeof(fhp::CellState)));
-  FM_HIP(hipMalloc(&m->d_chunks, (size_t)waves * fhp::NCHUNK * fhp::CHUNK_WORDS * 4));
+  FM_HIP(hipMalloc(&m->d_cells, (size_t)waves * records * sizeof(fhp::CellState)));
+  if (slots > 0) {
+    FM_HIP(hipMalloc(&m->d_hkeys, (size_t)waves * slots * 8));
+    FM_HIP(hipMemsetAsync(m->d_hkeys, 0, (size_t)waves * slots * 8, m->stream));  // (serial numbers start at 1: every slot free)
+  }
+  FM_HIP(hipMalloc(&m->d_chunks, (size_t)waves * chunk_words * 4));
+  m->chunk_words = chunk_words;
   FM_HIP(hipMalloc(&m->d_serials, (size_t)waves * 4));
   // stamps start at "never visited"; the serial numbers continue across calls, so this is the only clear
-  FM_HIP(hipMemsetAsync(m->d_cells, 0, (size_t)waves * total * sizeof(fhp::CellState), m->stream));
+  FM_HIP(hipMemsetAsync(m->d_cells, 0, (size_t)waves * records * sizeof(fhp::CellState), m->stream));
   FM_HIP(hipMemsetAsync(m->d_serials, 0, (size_t)waves * 4, m->stream));
   if (!m->d_ticket) FM_HIP(hipMalloc(&m->d_ticket, 64));
   m->waves = waves;
   m->ws_total = total;
+  m->ws_slots = slots;
+  m->ws_bytes = (size_t)waves * per_wave;
   return FH_OK;
 }
 }  // namespace
@@ -137,7 +158,7 @@ void fh_map_destroy(fh_map* m) {
   if (!m) return;
   MapDeviceScope scope(m);
   (void)hipStreamSynchronize(m->stream);
-  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables, (void*)m->d_jps_entries})
+  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_hkeys, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables, (void*)m->d_jps_entries})
     if (p) (void)hipFree(p);
   for (void* p : m->d_stage)
     if (p) (void)hipFree(p);
@@ -188,6 +209,22 @@ int fh_map_set_search(fh_map* m, int mode) {
   m->search_mode = mode;
   return FH_OK;
 }
+
+// How the jump point search keeps its per-cell records (g, parent, direction, closed).  slots = 0: one record per cell of the
+// map and wavefront (16 B x cells x wavefronts).  slots = a power of two in [1024, 2^22]: a hashed table of that many records per
+// wavefront (24 B per slot + 15 B per slot of heap levels, whatever the size of the map) holding the cells the running query has
+// reached; a query that reaches more than 3/4 of `slots` cells returns -2.  Same paths either way.  -1 (default): per-cell records
+// while they take at most 32 GB for all wavefronts, else 65536 hashed slots.  Measured (65536 forest queries, profiles/
+// r04_jps_records.json): 181 500 cells — per cell 71 ms / 23.8 GB, 8192 slots 80 ms / 1.6 GB; 1 452 000 cells — per cell 703 ms /
+// 51.5 GB (2064 wavefronts fit the 48 GB budget), 32768 slots 404 ms / 6.5 GB.  The A* search (mode 0) always uses per-cell records.
+int fh_map_set_records(fh_map* m, int slots) {
+  if (!m || slots < -1 || (slots > 0 && (slots < 1024 || slots > (1 << 22) || (slots & (slots - 1)) != 0))) return FH_ERR_ARG;
+  m->record_slots = slots;
+  return FH_OK;
+}
+
+// Bytes of the search workspace as it stands (sized by the first search after a change of map, mode, records or scheduling).
+long long fh_map_workspace_bytes(const fh_map* m) { return m ? (long long)m->ws_bytes : -1; }
 
 // JPS_in of Faster::replan (faster.cpp:370-382): with ra > 0 every path is cut at its first crossing of the sphere of radius
 // min(|goal - start| - 0.001, ra) around its start, the crossing point appended, BEFORE createMoreVertexes / deleteVertexes.  0 (default): off.
@@ -299,7 +336,7 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   fhp::PlanArgs pa;
   pa.starts = d_starts; pa.goals = d_goals; pa.n = n; pa.max_points = max_points;
   pa.paths = d_paths; pa.n_points = d_n_points; pa.expansions = (long long*)d_expansions;
-  pa.cells = m->d_cells; pa.chunks = m->d_chunks; pa.serials = m->d_serials; pa.ticket = m->d_ticket;
+  pa.cells = m->d_cells; pa.hkeys = m->d_hkeys; pa.hslots = m->ws_slots > 0 ? m->ws_slots : 0; pa.chunk_words = (long long)m->chunk_words; pa.chunks = m->d_chunks; pa.serials = m->d_serials; pa.ticket = m->d_ticket;
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
   pa.jps_tables = m->d_jps_tables;
   pa.sphere_ra = m->sphere_ra;
@@ -345,7 +382,8 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
     pa.order = m->d_order + 128;
   }
   const int grid = std::min(m->waves, n);
-  if (m->search_mode == 1) hipLaunchKernelGGL(fhp::plan_kernel<true>, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
+  if (m->search_mode == 1 && pa.hslots > 0) hipLaunchKernelGGL((fhp::plan_kernel<true, true>), dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
+  else if (m->search_mode == 1) hipLaunchKernelGGL(fhp::plan_kernel<true>, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
   else hipLaunchKernelGGL(fhp::plan_kernel<false>, dim3((unsigned)grid), dim3(64), 0, m->stream, mv, pa);
   FM_HIP(hipGetLastError());
   return FH_OK;

@@ -55,7 +55,10 @@ struct PlanArgs {
   double* paths;          // [n][max_points][3]
   int* n_points;          // [n]: vertices, 0 no path, -1 more than max_points, -2 a search limit was hit
   long long* expansions;  // [n] or null
-  CellState* cells;       // [waves][total]
+  CellState* cells;       // [waves][total]; hashed records (hslots > 0): [waves][hslots]
+  unsigned long long* hkeys;  // hashed records only: [waves][hslots] serial << 32 | cell (a key of another serial = a free slot)
+  int hslots;             // 0: one record per cell of the map; a power of two: that many hashed records per wavefront
+  long long chunk_words;  // words of `chunks` per wavefront (NCHUNK * CHUNK_WORDS; hashed records: what 3/4 hslots heap entries need)
   unsigned* chunks;       // [waves][NCHUNK][192]
   unsigned* serials;      // [waves]
   int* ticket;
@@ -442,10 +445,114 @@ struct Planner {
       if (__ballot(limit != 0)) return -2;
     }
     if (!found) return 0;
-    return finish_path(cells, chunks, sid, tid);
+    return finish_path<false>(cells, chunks, sid, tid);
+  }
+
+  // ---- hashed cell records (jump point search with PlanArgs::hslots > 0): the records of the cells a query has reached, instead of
+  // one record per cell of the map and wavefront.  Open addressing with linear probing over hmask + 1 slots of this wavefront;
+  // a slot belongs to the running query when the upper half of its key is the query's serial number, so nothing is cleared
+  // between queries.  Nothing is ever removed during a query: a cell's record is the first slot of its chain that carries its
+  // key, and the chain ends at the first slot that is not the query's.
+  unsigned long long* hk = nullptr;
+  CellState* hr = nullptr;
+  unsigned hmask = 0u, hshift = 0u;
+  int cap_g = CAP_G;               // heap entries in HBM (hashed records: 3/4 of the slots — a cell has one heap entry at most)
+  unsigned long long hser = 0ull;  // serial << 32
+  int hcount = 0;                  // records of the running query
+  __device__ __forceinline__ unsigned home(int id) const { return ((unsigned)id * 2654435761u) >> hshift; }
+  __device__ __forceinline__ static bool other_query(unsigned long long k, unsigned long long ser) { return (k & 0xffffffff00000000ull) != ser; }
+  // per lane: the record of cell id (stamp 0 when it has none), and where it is / where it would go
+  __device__ __forceinline__ CellState hfind(bool want, int id, unsigned& slot, bool& present) const {
+    CellState r; r.g = 0.0; r.parent = -1; r.stamp = 0u;
+    const unsigned long long key = hser | (unsigned long long)(unsigned)id;
+    slot = home(id);
+    present = false;
+    bool pend = want;
+    while (__ballot(pend)) {
+      if (pend) {
+        const unsigned long long k = hk[slot];
+        const CellState c = hr[slot];
+        if (k == key) { r = c; present = true; pend = false; }
+        else if (other_query(k, hser)) pend = false;
+        else slot = (slot + 1u) & hmask;
+      }
+    }
+    return r;
+  }
+  // the same for one cell, all lanes (uniform result)
+  __device__ __forceinline__ CellState hfind_uniform(int id, unsigned& slot, bool& present) const {
+    CellState r; r.g = 0.0; r.parent = -1; r.stamp = 0u;
+    const unsigned long long key = hser | (unsigned long long)(unsigned)id;
+    slot = home(id);
+    present = false;
+    for (;;) {
+      const unsigned long long k = hk[slot];
+      const CellState c = hr[slot];
+      const unsigned klo = (unsigned)rfl((int)(unsigned)k), khi = (unsigned)rfl((int)(unsigned)(k >> 32));
+      const unsigned long long ku = ((unsigned long long)khi << 32) | klo;
+      if (ku == key) {
+        r.g = __hiloint2double(rfl(__double2hiint(c.g)), rfl(__double2loint(c.g)));
+        r.parent = rfl(c.parent);
+        r.stamp = (unsigned)rfl((int)c.stamp);
+        present = true;
+        return r;
+      }
+      if (other_query(ku, hser)) return r;
+      slot = (slot + 1u) & hmask;
+    }
+  }
+  // per lane: write record w of cell id (distinct cells in distinct lanes) where hfind said.  New cells whose chains end in the same
+  // free slot: the lowest lane takes it, the others walk on (they see what was written: the stores are waited for).
+  // Returns false when the table is three quarters full.
+  __device__ __forceinline__ bool hwrite(bool want, int id, unsigned slot, bool present, const CellState& w) {
+    const unsigned long long key = hser | (unsigned long long)(unsigned)id;
+    if (want && present) hr[slot] = w;
+    bool need = want && !present;
+    unsigned long long nm = __ballot(need);
+    hcount += (int)__popcll(nm);
+    if (hcount > (int)(((hmask + 1u) >> 2) * 3u)) return false;
+    while (nm) {
+      bool lose = false;
+      if (__popcll(nm) > 1)
+        for (unsigned long long m2 = nm; m2; m2 &= m2 - 1ull) {
+          const int i = (int)__builtin_ctzll(m2);
+          if (need && i < lane && (unsigned)__builtin_amdgcn_readlane((int)slot, i) == slot) lose = true;
+        }
+      if (need && !lose) {
+        hk[slot] = key;
+        hr[slot] = w;
+        need = false;
+      }
+      nm = __ballot(need);
+      if (nm) {
+        settle();
+        bool pend = need;
+        if (need) slot = (slot + 1u) & hmask;
+        while (__ballot(pend)) {
+          if (pend) {
+            if (other_query(hk[slot], hser)) pend = false;
+            else slot = (slot + 1u) & hmask;
+          }
+        }
+      }
+    }
+    return true;
+  }
+  // one cell, written by lane 0 (present / slot from hfind_uniform)
+  __device__ __forceinline__ bool hwrite_uniform(int id, unsigned slot, bool present, const CellState& w) {
+    if (!present) {
+      hcount++;
+      if (hcount > (int)(((hmask + 1u) >> 2) * 3u)) return false;
+    }
+    if (lane == 0) {
+      if (!present) hk[slot] = hser | (unsigned long long)(unsigned)id;
+      hr[slot] = w;
+    }
+    return true;
   }
 
   // The parent chain goal -> start, then the clean-up of jps_planner.cpp:283-291.  Returns the number of cells in va[] (start -> goal).
+  template <bool HASHED>
   __device__ int finish_path(const CellState* cells, unsigned* chunks, int sid, int tid) {
     // ---- raw cell path, goal -> start
     raw = (int*)chunks;
@@ -457,7 +564,13 @@ struct Planner {
       if (lane == 0) raw[len] = id;
       len++;
       if (id == sid) break;
-      id = rfl(cells[id].parent);
+      if (HASHED) {
+        unsigned slot;
+        bool present;
+        id = hfind_uniform(id, slot, present).parent;
+      } else {
+        id = rfl(cells[id].parent);
+      }
       if (id < 0) break;
     }
     settle();
@@ -947,10 +1060,13 @@ struct Planner {
     return sqrt((double)dist2(x, y, z));
   }
 
-  __device__ int search_jps(CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
+  // HASHED: the cell records are the wavefront's hashed table (hk / hr above) instead of cells[cell]; what is read and written, and
+  // in which order, is the same, so the two return the same paths.
+  template <bool HASHED>
+  __device__ __forceinline__ int search_jps(CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
     gf = (double*)chunks;
-    gg = gf + CAP_G;
-    gi = (int*)(gg + CAP_G);
+    gg = gf + cap_g;
+    gi = (int*)(gg + cap_g);
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     const int nxy = mv.nx * mv.ny;
     boxes_matter = true;
@@ -961,8 +1077,15 @@ struct Planner {
       HE e;
       e.id = sid | (13 << 27); e.g = 0.0; e.f = 0.0 + heur_jps(s[0], s[1], s[2]);
       hset(0, e);
-      if (lane == 0) {
-        CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = (serial << 6) | (13u << 1);
+      CellState cs; cs.g = 0.0; cs.parent = -1; cs.stamp = (serial << 6) | (13u << 1);
+      if (HASHED) {
+        hser = (unsigned long long)serial << 32;
+        hcount = 0;
+        unsigned slot;
+        bool present;
+        (void)hfind_uniform(sid, slot, present);
+        if (!hwrite_uniform(sid, slot, present, cs)) return -2;
+      } else if (lane == 0) {
         cells[sid] = cs;
       }
     }
@@ -973,7 +1096,9 @@ struct Planner {
       if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
       const HE top = hget(0);
       const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
-      if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
+      unsigned long long ckey = 0ull;  // (hashed records: the key in the home slot of the popped cell, on its way while the heap is put in order)
+      if (HASHED) ckey = hk[home(cur)];
+      else if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
       const int cz = cur / nxy, rem = cur - cz * nxy, cy = rem / mv.nx, cx = rem - cy * mv.nx;
       const int n1 = abs(code % 3 - 1) + abs((code / 3) % 3 - 1) + abs(code / 9 - 1);
       const int num_neib = n1 == 0 ? 26 : (n1 == 1 ? 1 : (n1 == 2 ? 3 : 7)), num_fneib = n1 == 0 ? 0 : (n1 == 1 ? 8 : 12);
@@ -998,6 +1123,16 @@ struct Planner {
         sift_down(0, last, n);
       }
       if (cur == tid) break;
+      if (HASHED) {  // closed
+        unsigned cslot = home(cur);
+        const unsigned long long ku = ((unsigned long long)(unsigned)rfl((int)(unsigned)(ckey >> 32)) << 32) | (unsigned)rfl((int)(unsigned)ckey);
+        if (ku != (hser | (unsigned long long)(unsigned)cur)) {
+          bool present;
+          (void)hfind_uniform(cur, cslot, present);
+          if (!present) return -2;  // (cannot happen: a popped cell has a record)
+        }
+        if (lane == 0) hr[cslot].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;
+      }
       const bool applies = lane < num_neib || (fin && !freed(fx, fy, fz) && ((fword >> (fid & 31)) & 1u));
       int status = 2, jk = 0;  // 0 no successor, 1 a successor jk cells away, 2 not settled
       if (!cand) {}
@@ -1032,7 +1167,11 @@ struct Planner {
       const double lcost = sqrt((double)(ex * ex + ey * ey + ez * ez)), lheur = heur_jps(jx, jy, jz);
       const int lsign = (ex > 0 ? 2 : (ex < 0 ? 0 : 1)) + 3 * (ey > 0 ? 2 : (ey < 0 ? 0 : 1)) + 9 * (ez > 0 ? 2 : (ez < 0 ? 0 : 1));
       settle();
-      const CellState ns = cells[nid];
+      unsigned nslot = 0u;
+      bool npresent = false;
+      CellState ns;
+      if (HASHED) ns = hfind(ok, nid, nslot, npresent);
+      else ns = cells[nid];
       const unsigned long long okm = __ballot(ok);
       // a cell reached by two successors of this node: the second sees what the first wrote
       bool dup = false;
@@ -1050,9 +1189,13 @@ struct Planner {
       const bool improves = ok && !dup && (!visited || tentative < ns.g);
       const int lcode = !visited ? pcode : (closed ? (int)((ns.stamp >> 1) & 31u) : lsign);  // an open node takes the sign of the move (:176-181)
       const double lf = tentative + lheur;
-      if (improves) {
+      {
         CellState w; w.g = tentative; w.parent = cur; w.stamp = (serial << 6) | ((unsigned)lcode << 1) | (closed ? 1u : 0u);
-        cells[nid] = w;  // (closed: jps3d updates g and the parent and goes on)
+        if (HASHED) {
+          if (!hwrite(improves, nid, nslot, npresent, w)) return -2;
+        } else if (improves) {
+          cells[nid] = w;  // (closed: jps3d updates g and the parent and goes on)
+        }
       }
       const unsigned long long dupm = __ballot(dup);
       for (unsigned long long m2 = __ballot((improves && !closed) || dup); m2; m2 &= m2 - 1ull) {
@@ -1066,7 +1209,11 @@ struct Planner {
           me.id = nj | (__builtin_amdgcn_readlane(lcode, j) << 27);
         } else {  // the cell was reached by an earlier successor of this node: its record is read again
           settle();
-          const CellState again = cells[nj];
+          unsigned jslot = 0u;
+          bool jpresent = false;
+          CellState again;
+          if (HASHED) again = hfind_uniform(nj, jslot, jpresent);
+          else again = cells[nj];
           const unsigned nstamp = (unsigned)rfl((int)again.stamp);
           const double ng = __hiloint2double(rfl(__double2hiint(again.g)), rfl(__double2loint(again.g)));
           const bool v2 = (nstamp >> 6) == serial, c2 = v2 && (nstamp & 1u);
@@ -1075,15 +1222,19 @@ struct Planner {
           me.f = me.g + __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(lheur), j), __builtin_amdgcn_readlane(__double2loint(lheur), j));
           const unsigned ncode = !v2 ? (unsigned)__builtin_amdgcn_readlane(pcode, j) : (c2 ? ((nstamp >> 1) & 31u) : (unsigned)__builtin_amdgcn_readlane(lsign, j));
           me.id = nj | (int)(ncode << 27);
-          if (lane == 0) {
+          {
             CellState w; w.g = me.g; w.parent = cur; w.stamp = (serial << 6) | (ncode << 1) | (c2 ? 1u : 0u);
-            cells[nj] = w;
+            if (HASHED) {
+              if (!hwrite_uniform(nj, jslot, jpresent, w)) return -2;
+            } else if (lane == 0) {
+              cells[nj] = w;
+            }
           }
           if (c2) continue;
           push = !v2;
         }
         if (push) {
-          if (n >= CAP_L + CAP_G) return -2;
+          if (n >= CAP_L + cap_g) return -2;
           sift_up(n, me);
           n++;
         } else {  // pq_.increase
@@ -1095,7 +1246,7 @@ struct Planner {
       if (n == 0) return 0;
     }
     settle();
-    return finish_path(cells, chunks, sid, tid);
+    return finish_path<HASHED>(cells, chunks, sid, tid);
   }
 };
 
@@ -1105,15 +1256,22 @@ constexpr unsigned JPS_SERIAL_LIMIT = (1u << 26) - 1u;
 
 // One wavefront per workgroup.  Output vertices: the cleaned path with its ends forced onto start and goal
 // (jps_manager.cpp:175-186), then optionally createMoreVertexes / deleteVertexes.
-template <bool JPS>
+template <bool JPS, bool HASHED = false>
 __global__ void __launch_bounds__(64, JPS ? 5 : 3) plan_kernel(MapView mv, PlanArgs pa) {
   __shared__ __attribute__((aligned(16))) char lds[JPS ? JPS_LDS_BYTES : PLAN_LDS_BYTES];
   Planner pl(mv, lds);
   if (JPS) pl.init_jps(lds, pa.jps_tables, pa.jps_entries);
   const int lane = pl.lane;
   const int wave = (int)blockIdx.x;
-  CellState* cells = pa.cells + (size_t)wave * mv.total;
-  unsigned* chunks = pa.chunks + (size_t)wave * NCHUNK * CHUNK_WORDS;
+  CellState* cells = pa.cells + (size_t)wave * (HASHED ? pa.hslots : mv.total);
+  if (HASHED) {
+    pl.hk = pa.hkeys + (size_t)wave * pa.hslots;
+    pl.hr = cells;
+    pl.hmask = (unsigned)pa.hslots - 1u;
+    pl.hshift = 32u - (unsigned)(31 - __builtin_clz((unsigned)pa.hslots));
+    pl.cap_g = (pa.hslots >> 2) * 3;
+  }
+  unsigned* chunks = pa.chunks + (size_t)wave * (size_t)pa.chunk_words;
   unsigned serial = pa.serials[wave];
   for (;;) {
     int q = 0;
@@ -1133,11 +1291,12 @@ __global__ void __launch_bounds__(64, JPS ? 5 : 3) plan_kernel(MapView mv, PlanA
     if (!pl.outside(pl.s[0], pl.s[1], pl.s[2]) && !pl.outside(pl.t[0], pl.t[1], pl.t[2])) {
       serial++;
       if (serial >= (JPS ? JPS_SERIAL_LIMIT : 0x7fffffffu)) {  // 2^31 (2^26) queries of this wavefront: its stamps start over, so its cell states are cleared first
-        for (int c = lane; c < mv.total; c += 64) cells[c].stamp = 0u;
+        if (HASHED) for (int c = lane; c < pa.hslots; c += 64) pl.hk[c] = 0ull;
+        else for (int c = lane; c < mv.total; c += 64) cells[c].stamp = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         serial = 1;
       }
-      nv = JPS ? pl.search_jps(cells, chunks, serial, expansions) : pl.search(pa, cells, chunks, serial, expansions);
+      nv = JPS ? pl.template search_jps<HASHED>(cells, chunks, serial, expansions) : pl.search(pa, cells, chunks, serial, expansions);
     }
     double* out = pa.paths + (size_t)q * pa.max_points * 3;
     int np = nv;

@@ -446,6 +446,18 @@ int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
  * decides between equal-cost paths is the shim author's reading of Boost's, not Boost itself).  Limits in mode 1: 60312 open entries, 4096 jump points on the path.
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
+/* How the jump point search (mode 1) keeps its per-cell records (g, parent, direction, closed) — jps3d's hm_ / seen_
+ * (graph_search.h:150-155: one entry per cell of the map, allocated per query).  slots = 0: one 16-byte record per cell of
+ * the map and wavefront, stamped with the query's serial number instead of being cleared.  slots = a power of two in [1024, 2^22]:
+ * a hashed table of that many records per wavefront (39 bytes per slot with the heap levels that go with it, whatever the size of
+ * the map), holding the cells the running query has reached; a query that reaches more than 3/4 of `slots` cells returns
+ * n_points = -2 (raise slots, or use 0).  The same reads and writes in the same order either way: identical paths.
+ * slots = -1 (default): per-cell records while they take at most 32 GB over all wavefronts (faster on small maps: 71 vs 80 ms for
+ * 65536 queries in 181 500 cells), else 65536 hashed slots (1 452 000 cells: 404 ms and 6.5 GB against 703 ms and 51.5 GB).
+ * The A* search (mode 0) always uses per-cell records.
+ * fh_map_workspace_bytes: size of the search workspace as allocated by the last search (0 before the first). */
+int fh_map_set_records(fh_map* map, int slots);
+long long fh_map_workspace_bytes(const fh_map* map);
 /* JPS_in of Faster::replan (faster/src/faster.cpp:370-382): with ra > 0 every path of fh_map_plan_batch* is cut at its first crossing of
  * the sphere of radius min(|goal - start| - 0.001, ra) around its start (getFirstIntersectionWithSphere, utils.cpp:782-870, with the
  * reference's single-precision crossing), the crossing point E appended, BEFORE createMoreVertexes / deleteVertexes.  0 (default): off. */

@@ -261,3 +261,68 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
     # the batch exercises every outcome that matters
     assert stages[5] > 0.5 * B and sum(1 for s in st if s["needed_safe"]) > 0.15 * B and sum(1 for s in st if s["stage"] == 5 and not s["needed_safe"]) > 10
     print("replan chain == stub on %d pairs: stages %s, worst state difference %.2e" % (B, stages, worst))
+
+
+def test_hashed_cell_records_give_the_same_paths_in_a_fraction_of_the_workspace():
+    """fh_map_set_records: the jump point search with a hashed table of the cells a query has reached instead of one record per
+    cell of the map and wavefront.  Same popped nodes and vertices bit for bit as the host restatement (plan_path_jps, pinned to
+    the reference's compiled jps3d) on the forest of config C5 and on a 0.1 m map; repeated calls (stale slots of earlier
+    queries count as free); a table that is too small for some queries (1024 slots: chains collide, lanes contend for slots)
+    answers -2 for exactly the queries that reach more than 768 cells and is identical on the others; the workspace no longer
+    grows with the map."""
+    frontend.set_search("jps")
+    m = capi.Map(0)
+    try:
+        m.set_search("jps")
+        res, infl, zmax = 0.2, 0.3, 3.0
+        cloud, cells, center, starts, goals = frontend.forest_queries(4096, 23)
+        host = frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals)
+        m.read(cloud, cells, res, center, 0.0, zmax, infl)
+        m.set_records(0)
+        dense = m.plan_batch(starts, goals)
+        dense_bytes = m.workspace_bytes()
+
+        def same(a, b, what, skip=None):
+            keep = np.ones(len(a[1]), bool) if skip is None else ~skip
+            assert np.array_equal(a[1][keep], b[1][keep]), what
+            assert np.array_equal(a[2][keep], b[2][keep]), (what, "other nodes popped")
+            for i in np.nonzero(keep & (a[1] > 0))[0]:
+                assert np.array_equal(a[0][i, :a[1][i]], b[0][i, :a[1][i]]), (what, i)
+
+        same(host, dense, "per-cell records")
+        m.set_records(16384)
+        for rep in range(3):
+            same(host, m.plan_batch(starts, goals), "hashed records, call %d" % rep)
+        hashed_bytes = m.workspace_bytes()
+        assert hashed_bytes < dense_bytes / 3 and hashed_bytes <= 5120 * 16384 * 40
+        refined = (16, 1.5, 8)
+        same(frontend.plan_batch(cloud, cells, res, center, 0.0, zmax, infl, starts, goals, max_points=refined[0], max_vertex_dist=refined[1], max_poly=refined[2]),
+             m.plan_batch(starts, goals, max_points=refined[0], max_vertex_dist=refined[1], max_poly=refined[2]), "hashed records, refined vertices")
+        # a table that overflows for the long searches
+        m.set_records(1024)
+        small = m.plan_batch(starts, goals)
+        over = small[1] == -2
+        assert 0 < over.sum() < len(over) // 2, over.sum()
+        same(host, small, "1024 slots", skip=over)
+        assert host[2][over].min() > 200  # (only long searches overflow: a search reaches a few cells per popped node)
+        m.set_records(-1)  # (by the size of the map: per-cell records here)
+        same(host, m.plan_batch(starts, goals), "back to per-cell records")
+        assert m.workspace_bytes() == dense_bytes
+        # a 0.1 m map
+        rng = np.random.default_rng(9)
+        cloud, _ = frontend.forest_cloud(8, size=(10.0, 10.0, 2.0), density=0.25)
+        res, infl, cells, center = 0.1, 0.3, (100, 100, 30), np.array([5.0, 5.0, 1.0])
+        n = 512
+        starts = np.column_stack([rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
+        goals = np.column_stack([rng.uniform(6.0, 9.5, n), rng.uniform(0.5, 9.5, n), rng.uniform(0.3, 1.7, n)])
+        goals[:8] = starts[:8] + 0.01
+        goals[8] = starts[8]
+        starts[9] = [-50.0, 5.0, 1.0]
+        m.read(cloud, cells, res, center, 0.0, 2.0, infl)
+        host = frontend.plan_batch(cloud, cells, res, center, 0.0, 2.0, infl, starts, goals)
+        m.set_records(32768)
+        same(host, m.plan_batch(starts, goals), "0.1 m cells, hashed records")
+        assert m.workspace_bytes() <= 5120 * 32768 * 40
+    finally:
+        m.close()
+        frontend.set_search("astar")
