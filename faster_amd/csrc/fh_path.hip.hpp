@@ -198,7 +198,7 @@ struct Planner {
   }
 
   // ray test of removeCornerPts (MapUtil::isBlocked-style sampling every 0.8 cell): uniform result
-  __device__ bool blocked(const double a[3], const double b[3]) const {
+  __device__ __forceinline__ bool blocked(const double a[3], const double b[3]) const {
     const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
     const double mx = fmax(fabs(dx), fmax(fabs(dy), fabs(dz))) / mv.res;
     const int steps = (int)(mx / 0.8);
@@ -229,7 +229,7 @@ struct Planner {
   }
 
   // jps_planner.cpp:36-81 on a list of cells (every vertex of the clean-up is a cell centre); in -> out, returns the count
-  __device__ int remove_corner_points(const int* in, int n, int* out) const {
+  __device__ __forceinline__ int remove_corner_points(const int* in, int n, int* out) const {
     if (n < 2) {
       if (n == 1 && lane == 0) out[0] = in[0];
       return n;
@@ -553,7 +553,7 @@ struct Planner {
 
   // The parent chain goal -> start, then the clean-up of jps_planner.cpp:283-291.  Returns the number of cells in va[] (start -> goal).
   template <bool HASHED>
-  __device__ int finish_path(const CellState* cells, unsigned* chunks, int sid, int tid) {
+  __device__ __forceinline__ int finish_path(const CellState* cells, unsigned* chunks, int sid, int tid) {
     // ---- raw cell path, goal -> start
     raw = (int*)chunks;
     va = raw + MAXRAW;
@@ -721,7 +721,7 @@ struct Planner {
     return af > bf;
   }
   // the same two walks for entries that all sit in LDS (both children of a node come from one read each)
-  __device__ void sift_up_lds(int i, const HE& m) {
+  __device__ __forceinline__ void sift_up_lds(int i, const HE& m) {
     while (i != 0) {
       const int p = (i - 1) / 2;
       const double pf = hf[p], pg = hg[p];
@@ -732,21 +732,44 @@ struct Planner {
     }
     if (lane == 0) { hf[i] = m.f; hg[i] = m.g; hid[i] = m.id; }
   }
-  __device__ void sift_down_lds(int i, const HE& m, int n) {  // n <= CAP_L
+  // m sinks from the root (n <= CAP_L).  Which child a node prefers does not depend on m: every node with two children compares
+  // them at once (one ballot per 64 nodes), the path of preferred children is then walked on the scalar unit, and the entries on
+  // it are compared with m and moved up by one lane each.  The comparisons are the ones the serial walk makes (child against
+  // child, then the preferred child against m), so the heap ends up in the same state.
+  __device__ __forceinline__ void sift_down_lds(const HE& m, int n) {
+    auto prefer = [&](int base) -> unsigned long long {
+      const int first = 2 * (base + lane) + 1;
+      bool right = false;
+      if (first + 1 < n) right = lower_fg(hf[first], hg[first], hf[first + 1], hg[first + 1]);
+      return __ballot(right);
+    };
+    const int inner = n >> 1;
+    const unsigned long long p0 = prefer(0);
+    const unsigned long long p1 = inner > 64 ? prefer(64) : 0ull;
+    const unsigned long long p2 = inner > 128 ? prefer(128) : 0ull;
+    int idx = 0, depth = 0, pathv = 0;  // lane k of pathv: the k-th node of the path (lane 0: the root)
     for (;;) {
-      const int first = 2 * i + 1;
+      const int first = 2 * idx + 1;
       if (first >= n) break;
-      const double f0 = hf[first], f1 = hf[first + 1], g0 = hg[first], g1 = hg[first + 1];  // (first + 1 == n: read, not used)
-      const int i0 = hid[first], i1 = hid[first + 1];
-      const bool right = first + 1 < n && lower_fg(f0, g0, f1, g1);
-      const double bf = right ? f1 : f0, bg = right ? g1 : g0;
-      if (lower_fg(bf, bg, m.f, m.g)) break;
-      if (lane == 0) { hf[i] = bf; hg[i] = bg; hid[i] = right ? i1 : i0; }
-      i = first + (right ? 1 : 0);
+      const unsigned long long w = idx < 64 ? p0 : (idx < 128 ? p1 : p2);
+      idx = first + (int)((w >> (idx & 63)) & 1ull);
+      depth++;
+      pathv = lane == depth ? idx : pathv;
     }
-    if (lane == 0) { hf[i] = m.f; hg[i] = m.g; hid[i] = m.id; }
+    const bool on = lane >= 1 && lane <= depth;
+    const int pos = on ? pathv : 0;
+    const double ef = hf[pos], eg = hg[pos];
+    const int eid = hid[pos];
+    const unsigned long long sm = __ballot(on && lower_fg(ef, eg, m.f, m.g));
+    const int s = sm ? (int)__builtin_ctzll(sm) : depth + 1;  // m lands on node s - 1 of the path
+    if (on && lane < s) {
+      const int up = (pos - 1) >> 1;
+      hf[up] = ef; hg[up] = eg; hid[up] = eid;
+    }
+    const int dst = __builtin_amdgcn_readlane(pathv, s - 1);
+    if (lane == 0) { hf[dst] = m.f; hg[dst] = m.g; hid[dst] = m.id; }
   }
-  __device__ void sift_up(int i, const HE& m) {
+  __device__ __forceinline__ void sift_up(int i, const HE& m) {
     if (i < CAP_L) { sift_up_lds(i, m); return; }
     while (i != 0) {
       const int p = (i - 1) / 2;
@@ -757,8 +780,8 @@ struct Planner {
     }
     hset(i, m);
   }
-  __device__ void sift_down(int i, const HE& m, int n) {
-    if (n <= CAP_L) { sift_down_lds(i, m, n); return; }
+  __device__ __forceinline__ void sift_down(int i, const HE& m, int n) {
+    if (n <= CAP_L && i == 0) { sift_down_lds(m, n); return; }
     for (;;) {
       const int first = 2 * i + 1;
       if (first >= n) break;
@@ -774,7 +797,7 @@ struct Planner {
     }
     hset(i, m);
   }
-  __device__ int heap_find(int id, int n) const {
+  __device__ __forceinline__ int heap_find(int id, int n) const {
     for (int b = 0; b < n; b += 64) {
       const int i = b + lane;
       int v = -1;
@@ -858,10 +881,10 @@ struct Planner {
   // The goal can only end the jump at the diagonal cell P_kg where the smallest of its offsets along the jump's axes runs out
   // (before that a ray would need a diagonal move, after that it would have to go back): there it is the cell itself, or sits on a
   // straight ray that leaves the cell, or (space diagonal) in reach of the plane-diagonal jump that leaves it.
-  __device__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k) const {
+  __device__ __forceinline__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k) const {
     return diag_jump(x, y, z, ax, ay, az, k, entry((ax + 1) + 3 * (ay + 1) + 9 * (az + 1), x, y, z));
   }
-  __device__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k, int J) const {  // J: the entry of the jump itself
+  __device__ __forceinline__ int diag_jump(int x, int y, int z, int ax, int ay, int az, int& k, int J) const {  // J: the entry of the jump itself
     if (J == 0) return 2;
     k = J;
     const int plain = J > 0 ? 1 : 0;
@@ -906,7 +929,7 @@ struct Planner {
   // ---- jumps one per lane, in lock step.  phase 3: a straight jump along `a` from P; phase 0: a plane-diagonal jump along d2 from P
   // (0: next diagonal cell; 1 / 2: the straight jumps along a / b that leave it).  `grp` orders the lanes: when a lane has
   // succeeded, the lanes of later groups retire.  One round = one table entry or one examined cell per lane.
-  __device__ bool run_jumps(bool active, int phase, int px, int py, int pz, unsigned d2, unsigned a, unsigned b, int grp) const {
+  __device__ __forceinline__ bool run_jumps(bool active, int phase, int px, int py, int pz, unsigned d2, unsigned a, unsigned b, int grp) const {
     bool res = false;
     int qx = px, qy = py, qz = pz;
     while (__ballot(active)) {
@@ -961,7 +984,7 @@ struct Planner {
   }
 
   // graph_search.cpp:374-400 for one successor direction; (ox, oy, oz): the jump point
-  __device__ bool jump(int cx, int cy, int cz, unsigned pk, int& ox, int& oy, int& oz) const {
+  __device__ __forceinline__ bool jump(int cx, int cy, int cz, unsigned pk, int& ox, int& oy, int& oz) const {
     const int dx = ux(pk), dy = uy(pk), dz = uz(pk), code = code_of(pk), n1 = abs(dx) + abs(dy) + abs(dz);
     int bx = cx, by = cy, bz = cz;
     if (n1 == 1) {
@@ -1039,7 +1062,7 @@ struct Planner {
   }
 
   // the occupied cells inside the cube freed around centre c (they are free for this query): their bounding box
-  __device__ void dirty_box(const int c[3], int q) {
+  __device__ __forceinline__ void dirty_box(const int c[3], int q) {
     const int m = mv.m_free, w = 2 * m + 1, count = w * w * w;
     int lo0 = BIGK, lo1 = BIGK, lo2 = BIGK, hi0 = -BIGK, hi1 = -BIGK, hi2 = -BIGK;
     for (int i = lane; i < count; i += 64) {
