@@ -340,6 +340,10 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   pa.max_vertex_dist = max_vertex_dist; pa.max_poly = max_poly;
   pa.jps_tables = m->d_jps_tables;
   pa.sphere_ra = m->sphere_ra;
+  pa.profile_slot = -1;
+#ifdef FHP_PROFILE
+  if (const char* e = std::getenv("FHP_PROFILE_SLOT")) pa.profile_slot = std::atoi(e);
+#endif
   FM_HIP(hipMemsetAsync(m->d_ticket, 0, 4, m->stream));
   pa.jps_entries = nullptr;
   if (m->search_mode == 1) {

@@ -69,6 +69,7 @@ struct PlanArgs {
   double sphere_ra;       // > 0: the path is clipped to JPS_in first (Faster::replan, faster.cpp:370-382), see clip in plan_kernel
   const unsigned char* jps_tables;  // jump point search only: the neighbour tables, see Planner::init_jps
   const short* jps_entries;         // ... and the jump tables of this map [total][32], see jps_table_kernel
+  int profile_slot;                 // FHP_PROFILE builds only (scripts/jps_phase_profile.py): which phase's cycles `expansions` receives
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -112,7 +113,19 @@ __device__ inline void sphere_crossing(const double a_in[3], const double b_in[3
   if (disc <= 0) solve(c, a_in, disc);
 }
 
+// FHP_PROFILE builds: the cycles a wavefront spends in one phase of the jump point search (PlanArgs::profile_slot) are written to
+// `expansions` instead of the popped nodes.  0 pop + candidate addresses, 1 heap sift-down, 2 candidates settled from the tables,
+// 3 cell-by-cell jumps, 4 move costs + wait for the cell records, 5 relaxation, 6 heap pushes, 7 the whole query; 8 / 9 the
+// sift-down while the heap fits LDS / is deeper, 10 popped nodes with a deeper heap, 11 sum of the heap sizes.
+#ifdef FHP_PROFILE
+#define FHP_T(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); if (prof_slot == (k)) prof_acc += t__ - prof_t; prof_t = t__; } while (0)
+#else
+#define FHP_T(k) do {} while (0)
+#endif
+
 struct Planner {
+  int prof_slot = -1;
+  long long prof_acc = 0, prof_t = 0;
   const MapView& mv;
   int lane;
   int s[3], t[3];  // start / goal cells (uniform)
@@ -272,7 +285,7 @@ struct Planner {
   //      updated; two neighbours that hash to one sub-list take turns).
   // The expansion order is that of the strict total order (key, tie-breaker, cell) whatever the container: the same cells in the
   // same order as the host's std::priority_queue.
-  __device__ int search(const PlanArgs& pa, CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
+  __device__ __forceinline__ int search(const PlanArgs& pa, CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
     const unsigned st_open = serial * 2u, st_closed = serial * 2u + 1u;
     for (int i = lane; i < NCHUNK; i += 64) fstack[i] = (short)(NCHUNK - 1 - i);  // chunk 0 on top
     ftop = NCHUNK;
@@ -634,7 +647,7 @@ struct Planner {
   // The heap is jps3d's binary heap, top 312 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
   // program that all lanes execute; the position of an entry whose key decreases is found by a lane-parallel scan.
   // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
-  static constexpr int CAP_L = 312, CAP_G = 60000;  // (312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;
+  static constexpr int CAP_L = 311, CAP_G = 60000;  // (an odd number: the children of a node are both in LDS or both in the chunk pool; 312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;
                                                    //  432 and 16 per CU: 67 ms instead of 63 for 65536 forest queries; 248 and 24 per CU at 80 VGPRs, spilling: 65 ms)
   double* hf;            // LDS [CAP_L]
   double* hg;
@@ -648,7 +661,7 @@ struct Planner {
 
   struct HE { int id; double f, g; };
 
-  __device__ void init_jps(char* lds, const unsigned char* tab, const short* entries) {
+  __device__ __forceinline__ void init_jps(char* lds, const unsigned char* tab, const short* entries) {
     hf = (double*)lds;
     hg = hf + CAP_L;
     hid = (int*)(hg + CAP_L);
@@ -708,8 +721,7 @@ struct Planner {
       if (lane == 0) { hid[i] = e.id; hf[i] = e.f; hg[i] = e.g; }
     } else {
       const int j = i - CAP_L;
-      if (lane == 0) { gi[j] = e.id; gf[j] = e.f; gg[j] = e.g; }
-      settle();
+      if (lane == 0) { gi[j] = e.id; gf[j] = e.f; gg[j] = e.g; }  // (the caller waits for the stores when it is done)
     }
   }
   __device__ __forceinline__ static bool lower(const HE& a, const HE& b) {  // compare_state: a has LOWER priority than b
@@ -720,35 +732,66 @@ struct Planner {
     if (af >= bf - 0.000001 && af <= bf + 0.000001) return ag < bg;
     return af > bf;
   }
-  // the same two walks for entries that all sit in LDS (both children of a node come from one read each)
-  __device__ __forceinline__ void sift_up_lds(int i, const HE& m) {
-    while (i != 0) {
-      const int p = (i - 1) / 2;
-      const double pf = hf[p], pg = hg[p];
-      const int pid = hid[p];
-      if (!lower_fg(pf, pg, m.f, m.g)) break;
-      if (lane == 0) { hf[i] = pf; hg[i] = pg; hid[i] = pid; }
-      i = p;
+  // m rises from position i.  The ancestors of a position are arithmetic: lane k holds the k-th ((i + 1 >> k) - 1), all of them are
+  // fetched at once (LDS, or LDS and the chunk pool), compared with m at once — an ancestor of lower priority moves down, the first
+  // one that is not ends the walk — and moved down by one lane each.  The comparisons of the serial walk, so the same heap.
+  __device__ __forceinline__ void sift_up(int i, const HE& m) {
+    const int d = 31 - __builtin_clz((unsigned)(i + 1));  // ancestors
+    const bool on = lane >= 1 && lane <= d;
+    const int pos = on ? ((i + 1) >> lane) - 1 : 0;
+    if (i < CAP_L) {
+      const double ef = hf[pos], eg = hg[pos];
+      const int eid = hid[pos];
+      const unsigned long long stopm = __ballot(on && !lower_fg(ef, eg, m.f, m.g));
+      const int s = stopm ? (int)__builtin_ctzll(stopm) : d + 1;  // ancestors 1 .. s-1 move down, m lands where ancestor s-1 was
+      if (on && lane < s) {
+        const int dst = ((i + 1) >> (lane - 1)) - 1;
+        hf[dst] = ef; hg[dst] = eg; hid[dst] = eid;
+      }
+      if (lane == 0) {
+        const int dst = ((i + 1) >> (s - 1)) - 1;
+        hf[dst] = m.f; hg[dst] = m.g; hid[dst] = m.id;
+      }
+      return;
     }
-    if (lane == 0) { hf[i] = m.f; hg[i] = m.g; hid[i] = m.id; }
+    // (both homes are read, each with a valid index, and the value is selected: one address space per access)
+    const bool low = pos < CAP_L;
+    const int pl = low ? pos : 0, pg = low ? 0 : pos - CAP_L;
+    const double lf = hf[pl], lg = hg[pl], qf = gf[pg], qg = gg[pg];
+    const int lid = hid[pl], qid = gi[pg];
+    const double ef = low ? lf : qf, eg = low ? lg : qg;
+    const int eid = low ? lid : qid;
+    const unsigned long long stopm = __ballot(on && !lower_fg(ef, eg, m.f, m.g));
+    const int s = stopm ? (int)__builtin_ctzll(stopm) : d + 1;
+    const bool wr = (on && lane < s) || lane == 0;
+    const int dst = ((i + 1) >> (lane == 0 ? s - 1 : lane - 1)) - 1;
+    const double wf = lane == 0 ? m.f : ef, wg = lane == 0 ? m.g : eg;
+    const int wid = lane == 0 ? m.id : eid;
+    if (wr && dst < CAP_L) { hf[dst] = wf; hg[dst] = wg; hid[dst] = wid; }
+    asm volatile("" ::: "memory");  // (keeps the two stores apart: merged, they become flat stores through a pointer table in scratch)
+    if (wr && dst >= CAP_L) { const int j = dst - CAP_L; gf[j] = wf; gg[j] = wg; gi[j] = wid; }
+    settle();
   }
-  // m sinks from the root (n <= CAP_L).  Which child a node prefers does not depend on m: every node with two children compares
-  // them at once (one ballot per 64 nodes), the path of preferred children is then walked on the scalar unit, and the entries on
-  // it are compared with m and moved up by one lane each.  The comparisons are the ones the serial walk makes (child against
-  // child, then the preferred child against m), so the heap ends up in the same state.
-  __device__ __forceinline__ void sift_down_lds(const HE& m, int n) {
+  // m sinks from the root.  Which child a node prefers does not depend on m: while both children of a node sit in LDS (nodes below
+  // LDS_INNER) every node compares its two children at once (one ballot per 64 nodes), the path of preferred children is walked on
+  // the scalar unit, and the entries on it are compared with m and moved up by one lane each.  If m sinks past the end of that
+  // path (a heap deeper than LDS holds) the serial walk takes over there.  The comparisons are the ones the serial walk makes
+  // (child against child, then the preferred child against m), so the heap ends up in the same state.
+  static constexpr int LDS_INNER = (CAP_L - 1) / 2;  // nodes below have both children in LDS, the others both in the chunk pool
+  static_assert(CAP_L % 2 == 1, "a node's children must not straddle LDS and the chunk pool");
+  __device__ __forceinline__ void sift_down(const HE& m, int n) {
     auto prefer = [&](int base) -> unsigned long long {
-      const int first = 2 * (base + lane) + 1;
+      const int node = base + lane, first = 2 * node + 1;
       bool right = false;
-      if (first + 1 < n) right = lower_fg(hf[first], hg[first], hf[first + 1], hg[first + 1]);
+      if (node < LDS_INNER && first + 1 < n) right = lower_fg(hf[first], hg[first], hf[first + 1], hg[first + 1]);
       return __ballot(right);
     };
-    const int inner = n >> 1;
+    const int inner = min(n >> 1, LDS_INNER);
     const unsigned long long p0 = prefer(0);
     const unsigned long long p1 = inner > 64 ? prefer(64) : 0ull;
     const unsigned long long p2 = inner > 128 ? prefer(128) : 0ull;
     int idx = 0, depth = 0, pathv = 0;  // lane k of pathv: the k-th node of the path (lane 0: the root)
-    for (;;) {
+    while (idx < LDS_INNER) {
       const int first = 2 * idx + 1;
       if (first >= n) break;
       const unsigned long long w = idx < 64 ? p0 : (idx < 128 ? p1 : p2);
@@ -761,49 +804,53 @@ struct Planner {
     const double ef = hf[pos], eg = hg[pos];
     const int eid = hid[pos];
     const unsigned long long sm = __ballot(on && lower_fg(ef, eg, m.f, m.g));
-    const int s = sm ? (int)__builtin_ctzll(sm) : depth + 1;  // m lands on node s - 1 of the path
+    const int s = sm ? (int)__builtin_ctzll(sm) : depth + 1;  // m lands on node s - 1 of the path, or sinks past its end
     if (on && lane < s) {
       const int up = (pos - 1) >> 1;
       hf[up] = ef; hg[up] = eg; hid[up] = eid;
     }
-    const int dst = __builtin_amdgcn_readlane(pathv, s - 1);
-    if (lane == 0) { hf[dst] = m.f; hg[dst] = m.g; hid[dst] = m.id; }
-  }
-  __device__ __forceinline__ void sift_up(int i, const HE& m) {
-    if (i < CAP_L) { sift_up_lds(i, m); return; }
-    while (i != 0) {
-      const int p = (i - 1) / 2;
-      const HE pe = hget(p);
-      if (!lower(pe, m)) break;
-      hset(i, pe);
-      i = p;
-    }
-    hset(i, m);
-  }
-  __device__ __forceinline__ void sift_down(int i, const HE& m, int n) {
-    if (n <= CAP_L && i == 0) { sift_down_lds(m, n); return; }
-    for (;;) {
-      const int first = 2 * i + 1;
-      if (first >= n) break;
-      HE b = hget(first);
-      int best = first;
-      if (first + 1 < n) {
-        const HE c = hget(first + 1);
-        if (lower(b, c)) { b = c; best = first + 1; }
+    int i = __builtin_amdgcn_readlane(pathv, s - 1);
+    if (sm == 0ull && 2 * i + 1 < n) {  // the end of the LDS path has children: they are in the chunk pool
+      for (;;) {
+        const int first = 2 * i + 1;
+        if (first >= n) break;
+        const int j = first - CAP_L, j1 = first + 1 < n ? j + 1 : j;
+        const double f0 = gf[j], g0 = gg[j], f1 = gf[j1], g1 = gg[j1];
+        const int i0 = gi[j], i1 = gi[j1];
+        const bool right = first + 1 < n && lower_fg(f0, g0, f1, g1);
+        HE b;
+        b.f = right ? f1 : f0; b.g = right ? g1 : g0; b.id = right ? i1 : i0;
+        if (lower(b, m)) break;
+        hset(i, b);
+        i = first + (right ? 1 : 0);
       }
-      if (lower(b, m)) break;
-      hset(i, b);
-      i = best;
+      hset(i, m);
+      settle();
+      return;
     }
-    hset(i, m);
+    if (lane == 0) { hf[i] = m.f; hg[i] = m.g; hid[i] = m.id; }
   }
+  // the position of cell `id` in the heap (an entry whose key decreases); the chunk pool part four loads at a time
   __device__ __forceinline__ int heap_find(int id, int n) const {
-    for (int b = 0; b < n; b += 64) {
+    const int nl = min(n, CAP_L);
+    for (int b = 0; b < nl; b += 64) {
       const int i = b + lane;
-      int v = -1;
-      if (i < n) v = (i < CAP_L ? hid[i] : gi[i - CAP_L]) & IDMASK;
+      const int v = i < nl ? (hid[i] & IDMASK) : -1;
       const unsigned long long m = __ballot(v == id);
       if (m) return b + (int)__builtin_ctzll(m);
+    }
+    for (int b = CAP_L; b < n; b += 256) {
+      int v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = b + 64 * u + lane;
+        v[u] = i < n ? (gi[i - CAP_L] & IDMASK) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const unsigned long long m = __ballot(v[u] == id);
+        if (m) return b + 64 * u + (int)__builtin_ctzll(m);
+      }
     }
     return -1;
   }
@@ -1117,6 +1164,7 @@ struct Planner {
     for (;;) {  // graph_search.cpp:123-217
       expansions++;
       if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
+      FHP_T(-2);
       const HE top = hget(0);
       const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
       unsigned long long ckey = 0ull;  // (hashed records: the key in the home slot of the popped cell, on its way while the heap is put in order)
@@ -1141,10 +1189,21 @@ struct Planner {
       const unsigned fword = mv.bits[fid >> 5];
       const int J = jt[(size_t)cur * 32 + pcode];
       n--;
+      FHP_T(0);
+#ifdef FHP_PROFILE
+      const long long prof_t0 = (long long)__builtin_readcyclecounter();
+#endif
       if (n > 0) {
         const HE last = hget(n);
-        sift_down(0, last, n);
+        sift_down(last, n);
       }
+      FHP_T(1);
+#ifdef FHP_PROFILE
+      if (prof_slot == 8 && n <= CAP_L) prof_acc += (long long)__builtin_readcyclecounter() - prof_t0;
+      if (prof_slot == 9 && n > CAP_L) prof_acc += (long long)__builtin_readcyclecounter() - prof_t0;
+      if (prof_slot == 10 && n > CAP_L) prof_acc++;
+      if (prof_slot == 11) prof_acc += n;
+#endif
       if (cur == tid) break;
       if (HASHED) {  // closed
         unsigned cslot = home(cur);
@@ -1174,6 +1233,7 @@ struct Planner {
       }
       if (!cand || !applies) status = 0;
       int jx = cx + jk * ax, jy = cy + jk * ay, jz = cz + jk * az;
+      FHP_T(2);
       for (unsigned long long um = __ballot(status == 2); um; um &= um - 1ull) {
         const int j = (int)__builtin_ctzll(um);
         int ox, oy, oz;
@@ -1183,6 +1243,7 @@ struct Planner {
           jx = ox; jy = oy; jz = oz;
         }
       }
+      FHP_T(3);
       const bool ok = status == 1;
       const int nid = ok ? index(jx, jy, jz) : cur;
       // per successor, all at once: the cost of the move, h of the jump point, the direction id of the sign of the move
@@ -1206,6 +1267,7 @@ struct Planner {
       // ---- relaxation (:150-191).  What does not depend on the order is done by all successors at once: the comparison with the
       // stored g, the new cell record (a cell reached twice waits for its turn below).  The heap operations follow one after the
       // other in getJpsSucc's order.
+      FHP_T(4);
       const bool visited = (ns.stamp >> 6) == serial;
       const bool closed = visited && (ns.stamp & 1u);
       const double tentative = top.g + lcost;
@@ -1221,6 +1283,7 @@ struct Planner {
         }
       }
       const unsigned long long dupm = __ballot(dup);
+      FHP_T(5);
       for (unsigned long long m2 = __ballot((improves && !closed) || dup); m2; m2 &= m2 - 1ull) {
         const int j = (int)__builtin_ctzll(m2);
         const int nj = __builtin_amdgcn_readlane(nid, j);
@@ -1266,6 +1329,7 @@ struct Planner {
           sift_up(pos, me);
         }
       }
+      FHP_T(6);
       if (n == 0) return 0;
     }
     settle();
@@ -1311,6 +1375,11 @@ __global__ void __launch_bounds__(64, JPS ? 5 : 3) plan_kernel(MapView mv, PlanA
     for (int k = 0; k < 3; k++) { pl.s[k] = rfl(pl.s[k]); pl.t[k] = rfl(pl.t[k]); }
     long long expansions = 0;
     int nv = 0;
+#ifdef FHP_PROFILE
+    pl.prof_slot = pa.profile_slot;
+    pl.prof_acc = 0;
+    const long long q_t0 = (long long)__builtin_readcyclecounter();
+#endif
     if (!pl.outside(pl.s[0], pl.s[1], pl.s[2]) && !pl.outside(pl.t[0], pl.t[1], pl.t[2])) {
       serial++;
       if (serial >= (JPS ? JPS_SERIAL_LIMIT : 0x7fffffffu)) {  // 2^31 (2^26) queries of this wavefront: its stamps start over, so its cell states are cleared first
@@ -1394,6 +1463,10 @@ __global__ void __launch_bounds__(64, JPS ? 5 : 3) plan_kernel(MapView mv, PlanA
     }
     if (lane == 0) {
       pa.n_points[q] = np;
+#ifdef FHP_PROFILE
+      if (pa.profile_slot == 7) expansions = (long long)__builtin_readcyclecounter() - q_t0;
+      else if (pa.profile_slot >= 0) expansions = pl.prof_acc;
+#endif
       if (pa.expansions) pa.expansions[q] = expansions;
     }
   }

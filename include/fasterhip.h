@@ -443,7 +443,7 @@ int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
  * (thirdparty/jps3d/src/jps_planner/graph_search.cpp:123-470) — of the optimal paths, the one FASTER itself gets from
  * planner_ptr_->plan(start, goal, 1, true) (faster/src/jps_manager.cpp:166); equals plan_path_jps bit for bit, which is pinned vertex
  * for vertex to the reference's compiled sources behind a test-only Boost.Heap shim (oracle/ref_frontend/shim: the sift discipline that
- * decides between equal-cost paths is the shim author's reading of Boost's, not Boost itself).  Limits in mode 1: 60312 open entries, 4096 jump points on the path.
+ * decides between equal-cost paths is the shim author's reading of Boost's, not Boost itself).  Limits in mode 1: 60311 open entries, 4096 jump points on the path.
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
 /* How the jump point search (mode 1) keeps its per-cell records (g, parent, direction, closed) — jps3d's hm_ / seen_
