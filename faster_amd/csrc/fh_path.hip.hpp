@@ -649,23 +649,29 @@ struct Planner {
   // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
   static constexpr int CAP_L = 311, CAP_G = 60000;  // (an odd number: the children of a node are both in LDS or both in the chunk pool; 312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;
                                                    //  432 and 16 per CU: 67 ms instead of 63 for 65536 forest queries; 248 and 24 per CU at 80 VGPRs, spilling: 65 ms)
-  double* hf;            // LDS [CAP_L]
-  double* hg;
-  int* hid;
+  // (typed by address space: a select between an LDS and a chunk pool pointer cannot be formed, so an access is a ds_ or a global_
+  // instruction, never a flat_ one through a pointer picked at run time)
+  typedef __attribute__((address_space(3))) double lds_f64;
+  typedef __attribute__((address_space(3))) int lds_i32;
+  typedef __attribute__((address_space(1))) double pool_f64;
+  typedef __attribute__((address_space(1))) int pool_i32;
+  lds_f64* hf;           // LDS [CAP_L]
+  lds_f64* hg;
+  lds_i32* hid;
   const unsigned* jns;   // LDS: natural neighbours [27][28] bytes (26 used; 7 words per direction)
   const unsigned* jf1;   // cells to test [27][12] bytes (3 words per direction)
   const unsigned* jf2;   // directions to add [27][12] bytes
-  double* gf;            // HBM overflow of the heap
-  double* gg;
-  int* gi;
+  pool_f64* gf;          // HBM overflow of the heap
+  pool_f64* gg;
+  pool_i32* gi;
 
   struct HE { int id; double f, g; };
 
   __device__ __forceinline__ void init_jps(char* lds, const unsigned char* tab, const short* entries) {
-    hf = (double*)lds;
+    hf = (lds_f64*)lds;
     hg = hf + CAP_L;
-    hid = (int*)(hg + CAP_L);
-    unsigned* w = (unsigned*)(hid + CAP_L);
+    hid = (lds_i32*)(hg + CAP_L);
+    unsigned* w = (unsigned*)(lds + CAP_L * 20);
     const unsigned* tw = (const unsigned*)tab;
     for (int i = lane; i < JTAB_WORDS; i += 64) w[i] = tw[i];
     jt = entries;
@@ -710,10 +716,14 @@ struct Planner {
   __device__ __forceinline__ static int norm1_of(unsigned pk) { return abs(ux(pk)) + abs(uy(pk)) + abs(uz(pk)); }
 
   // ---- the heap: entry i in LDS below CAP_L, in HBM above
+  // (an entry read by all lanes at once is the same in all of them: said to the compiler, what is computed from it — heap sizes,
+  // positions, loop conditions — stays on the scalar unit)
+  __device__ __forceinline__ static double ufl(double v) { return __hiloint2double(rfl(__double2hiint(v)), rfl(__double2loint(v))); }
   __device__ __forceinline__ HE hget(int i) const {
     HE e;
     if (i < CAP_L) { e.id = hid[i]; e.f = hf[i]; e.g = hg[i]; }
     else { const int j = i - CAP_L; e.id = gi[j]; e.f = gf[j]; e.g = gg[j]; }
+    e.id = rfl(e.id); e.f = ufl(e.f); e.g = ufl(e.g);
     return e;
   }
   __device__ __forceinline__ void hset(int i, const HE& e) {
@@ -815,8 +825,8 @@ struct Planner {
         const int first = 2 * i + 1;
         if (first >= n) break;
         const int j = first - CAP_L, j1 = first + 1 < n ? j + 1 : j;
-        const double f0 = gf[j], g0 = gg[j], f1 = gf[j1], g1 = gg[j1];
-        const int i0 = gi[j], i1 = gi[j1];
+        const double f0 = ufl(gf[j]), g0 = ufl(gg[j]), f1 = ufl(gf[j1]), g1 = ufl(gg[j1]);
+        const int i0 = rfl(gi[j]), i1 = rfl(gi[j1]);
         const bool right = first + 1 < n && lower_fg(f0, g0, f1, g1);
         HE b;
         b.f = right ? f1 : f0; b.g = right ? g1 : g0; b.id = right ? i1 : i0;
@@ -1134,9 +1144,9 @@ struct Planner {
   // in which order, is the same, so the two return the same paths.
   template <bool HASHED>
   __device__ __forceinline__ int search_jps(CellState* cells, unsigned* chunks, unsigned serial, long long& expansions) {
-    gf = (double*)chunks;
+    gf = (pool_f64*)chunks;
     gg = gf + cap_g;
-    gi = (int*)(gg + cap_g);
+    gi = (pool_i32*)(gg + cap_g);
     const int sid = index(s[0], s[1], s[2]), tid = index(t[0], t[1], t[2]);
     const int nxy = mv.nx * mv.ny;
     boxes_matter = true;
