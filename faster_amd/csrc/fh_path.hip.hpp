@@ -734,14 +734,12 @@ struct Planner {
       if (lane == 0) { gi[j] = e.id; gf[j] = e.f; gg[j] = e.g; }  // (the caller waits for the stores when it is done)
     }
   }
-  __device__ __forceinline__ static bool lower(const HE& a, const HE& b) {  // compare_state: a has LOWER priority than b
-    if (a.f >= b.f - 0.000001 && a.f <= b.f + 0.000001) return a.g < b.g;
-    return a.f > b.f;
-  }
+  // compare_state (graph_search.h:19-29): a has LOWER priority than b.  Without branches: both comparisons are made, one is taken.
   __device__ __forceinline__ static bool lower_fg(double af, double ag, double bf, double bg) {
-    if (af >= bf - 0.000001 && af <= bf + 0.000001) return ag < bg;
-    return af > bf;
+    const bool tie = (af >= bf - 0.000001) & (af <= bf + 0.000001);
+    return (tie & (ag < bg)) | (!tie & (af > bf));
   }
+  __device__ __forceinline__ static bool lower(const HE& a, const HE& b) { return lower_fg(a.f, a.g, b.f, b.g); }
   // m rises from position i.  The ancestors of a position are arithmetic: lane k holds the k-th ((i + 1 >> k) - 1), all of them are
   // fetched at once (LDS, or LDS and the chunk pool), compared with m at once — an ancestor of lower priority moves down, the first
   // one that is not ends the walk — and moved down by one lane each.  The comparisons of the serial walk, so the same heap.
