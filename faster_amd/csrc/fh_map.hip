@@ -215,8 +215,8 @@ int fh_map_set_search(fh_map* m, int mode) {
 // wavefront (24 B per slot + 15 B per slot of heap levels, whatever the size of the map) holding the cells the running query has
 // reached; a query that reaches more than 3/4 of `slots` cells returns -2.  Same paths either way.  -1 (default): per-cell records
 // while they take at most 32 GB for all wavefronts, else 65536 hashed slots.  Measured (65536 forest queries, profiles/
-// r04_jps_records.json): 181 500 cells — per cell 66 ms / 23.8 GB, 8192 slots 79 ms / 1.6 GB; 1 452 000 cells — per cell 656 ms /
-// 51.5 GB (2064 wavefronts fit the 48 GB budget), 32768 slots 392 ms / 6.5 GB.  The A* search (mode 0) always uses per-cell records.
+// r04_jps_records.json): 181 500 cells — per cell 54 ms / 23.8 GB, 8192 slots 66 ms / 1.6 GB; 1 452 000 cells — per cell 476 ms /
+// 51.5 GB (2064 wavefronts fit the 48 GB budget), 32768 slots 298 ms / 6.5 GB.  The A* search (mode 0) always uses per-cell records.
 int fh_map_set_records(fh_map* m, int slots) {
   if (!m || slots < -1 || (slots > 0 && (slots < 1024 || slots > (1 << 22) || (slots & (slots - 1)) != 0))) return FH_ERR_ARG;
   m->record_slots = slots;

@@ -644,7 +644,7 @@ struct Planner {
   //   * a space-diagonal jump does the same for 8 diagonal cells x (3 straight + 3 plane-diagonal jumps), one jump per lane.
   // A jump only returns "some cell of this ray ends it" and the diagonal cell it happened at, so the order in which the lanes
   // find that out does not matter: the successor list and its order are jps3d's.
-  // The heap is jps3d's binary heap, top 312 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
+  // The heap is jps3d's binary heap, top 311 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
   // program that all lanes execute; the position of an entry whose key decreases is found by a lane-parallel scan.
   // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
   static constexpr int CAP_L = 311, CAP_G = 60000;  // (an odd number: the children of a node are both in LDS or both in the chunk pool; 312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;

@@ -452,8 +452,8 @@ int fh_map_set_search(fh_map* map, int mode);
  * a hashed table of that many records per wavefront (39 bytes per slot with the heap levels that go with it, whatever the size of
  * the map), holding the cells the running query has reached; a query that reaches more than 3/4 of `slots` cells returns
  * n_points = -2 (raise slots, or use 0).  The same reads and writes in the same order either way: identical paths.
- * slots = -1 (default): per-cell records while they take at most 32 GB over all wavefronts (faster on small maps: 66 vs 78 ms for
- * 65536 queries in 181 500 cells), else 65536 hashed slots (1 452 000 cells: 392 ms and 6.5 GB against 656 ms and 51.5 GB).
+ * slots = -1 (default): per-cell records while they take at most 32 GB over all wavefronts (faster on small maps: 54 vs 66 ms for
+ * 65536 queries in 181 500 cells), else 65536 hashed slots (1 452 000 cells: 298 ms and 6.5 GB against 476 ms and 51.5 GB).
  * The A* search (mode 0) always uses per-cell records.
  * fh_map_workspace_bytes: size of the search workspace as allocated by the last search (0 before the first). */
 int fh_map_set_records(fh_map* map, int slots);
