@@ -360,13 +360,15 @@ __global__ void __launch_bounds__(64) cloud_blocks_kernel(const double* __restri
   }
 }
 
-// Persistent workgroups of one wavefront, segments taken in a grid-stride loop.  segments: [n][6] = p1, p2.  faces: [n][max_faces] rows
+// Persistent workgroups of one wavefront; segments are drawn from a counter (`ticket`, zeroed by the caller) — a segment's cost goes
+// with the number of points in its box (a few to 1500 and more with unknown voxels), so a fixed stride leaves the launch waiting
+// for the unluckiest workgroup.  segments: [n][6] = p1, p2.  faces: [n][max_faces] rows
 // (a, b); counts[n] = rows written, -1 on overflow.  workspace: per workgroup 3 * CAP_GLOBAL doubles + CAP_GLOBAL bytes.
 __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
                                                     int n_segments, double bx, double by, double bz, double inflate, double z_ground,
                                                     int max_faces, double* __restrict__ workspace, fh_face* __restrict__ faces,
                                                     int32_t* __restrict__ counts, const double* __restrict__ blocks, UnknownLattice lat,
-                                                    const double* __restrict__ spheres) {
+                                                    const double* __restrict__ spheres, int* __restrict__ ticket) {
   // the segment's list of box points: 256 inflated points (3 x 256 doubles + 256 flag bytes) or, in the same bytes, 1536 ids + flag bytes.
   // flags: bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
   static_assert(FH_DECOMP_CAP_IDS * 4 <= 3 * FH_DECOMP_CAP * 8 && FH_DECOMP_CAP <= FH_DECOMP_CAP_IDS, "the id list aliases the coordinate list");
@@ -374,8 +376,12 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
   __shared__ int lblist[FH_DECOMP_BLIST];         // blocks of the cloud that can touch the local box, ascending
   const int lane = threadIdx.x;
   double* gws = workspace + (size_t)blockIdx.x * (size_t)(3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8);  // (ids + flags of the densest clouds)
-  for (int seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
+  for (;;) {
     __syncthreads();
+    int seg = 0;
+    if (lane == 0) seg = atomicAdd(ticket, 1);
+    seg = __builtin_amdgcn_readfirstlane(seg);
+    if (seg >= n_segments) break;
     const D3 p1 = d3(segments[6 * seg + 0], segments[6 * seg + 1], segments[6 * seg + 2]);
     const D3 p2 = d3(segments[6 * seg + 3], segments[6 * seg + 4], segments[6 * seg + 5]);
     fh_face* out = faces + (size_t)seg * (size_t)max_faces;

@@ -1,6 +1,6 @@
 """Where a wavefront of the jump point search spends its cycles (FHP_PROFILE build of the library: bash scripts/build_variant.sh
 jpsprof -DFHP_PROFILE; run with FASTERHIP_SO=build/libfasterhip_jpsprof.so).  One launch per phase: `expansions` receives the cycles
-of that phase.   usage: jps_phase_profile.py [n_queries] [slots]"""
+of that phase.   usage: jps_phase_profile.py [n_queries] [slots] [cell size, default 0.2]"""
 import os
 import sys
 import time
@@ -13,12 +13,15 @@ from faster_amd import capi, frontend  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 slots = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+res = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
 torch.cuda.init()
 cloud, cells, center, starts, goals = frontend.forest_queries(n, 5)
 m = capi.Map(0)
 m.set_search("jps")
 m.set_records(slots)
-m.read(cloud, cells, 0.2, center, 0.0, 3.0, 0.3)
+if res != 0.2:
+    cells = tuple(int(round(c * 0.2 / res)) for c in cells)
+m.read(cloud, cells, res, center, 0.0, 3.0, 0.3)
 dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
 d_s, d_g = dev(starts, np.float64), dev(goals, np.float64)
 mp = 64
