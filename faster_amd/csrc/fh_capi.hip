@@ -853,6 +853,13 @@ static int decompose_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud,
   }
   if ((rc = ensure(ctx, 18, 64)) != FH_OK) return rc;
   FH_HIP(hipMemsetAsync(ctx->d_buf[18], 0, sizeof(int), ctx->stream));  // the segment counter of this launch
+#ifdef FHD_EXPERIMENT
+  {
+    const char* e = std::getenv("FHD_STOP_AFTER");
+    const int v = e ? std::atoi(e) : 0;
+    FH_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(fh::fhd_stop_after), &v, sizeof(int), 0, hipMemcpyHostToDevice, ctx->stream));
+  }
+#endif
   hipLaunchKernelGGL(fh::decomp_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_cloud_xyz, n_cloud, d_segments, n_segments,
                      local_bbox[0], local_bbox[1], local_bbox[2], drone_radius, z_ground, max_faces, (double*)ctx->d_buf[7], d_faces,
                      d_counts, d_blocks, lat, lat.on ? d_seg_spheres : nullptr, (int*)ctx->d_buf[18]);

@@ -81,6 +81,9 @@ __device__ __forceinline__ double ell_dist(const Rot& R, D3 ax, D3 c, D3 q) {
 __device__ __forceinline__ int sgn_i(double v) { return (0.0 < v) - (v < 0.0); }
 
 // arg-min of the ellipsoid distance over the list entries whose flag has `bit`; returns the list index (-1 if none)
+#ifdef FHD_EXPERIMENT
+__constant__ int fhd_stop_after;
+#endif
 template <class L>
 __device__ __forceinline__ int closest_in(const L& list, int cnt, unsigned char bit, const Rot& R, D3 ax, D3 c, int lane) {
   double best = INFINITY;
@@ -125,11 +128,21 @@ struct UnknownLattice {
 };
 struct LatticeRange {
   int x0, cx, y0, cy, z0, cz, total;  // sub-block of the grid: first cell and count per axis
+  unsigned inv_cxy, inv_cx;           // floor(2^32 / (cx cy)), floor(2^32 / cx): a cell number is split with two multiply-highs (udiv_by)
   double ax, ay, az, r2;              // the sphere of known space
 };
+// n / d for n < 2^28 with inv = floor(2^32 / d) (0xffffffff for d = 1): mulhi(n, inv) is the quotient or one less, one correction —
+// 5 vector instructions where the compiler's expansion of a 32-bit division takes 20+ (the sweeps split every cell number twice).
+__device__ __forceinline__ unsigned udiv_inverse_of(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(4294967296.0 / (double)d); }  // (exact: the fraction of 2^32 / d is 0 or >= 2^-20)
+__device__ __forceinline__ int udiv_by(int n, int d, unsigned inv) {
+  unsigned q = __umulhi((unsigned)n, inv);
+  if ((unsigned)n - q * (unsigned)d >= (unsigned)d) q++;
+  return (int)q;
+}
 __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat, const double lo[3], const double hi[3], const double* sphere) {
   LatticeRange g;
   g.total = 0; g.x0 = g.y0 = g.z0 = g.cx = g.cy = g.cz = 0;
+  g.inv_cxy = g.inv_cx = 0xffffffffu;
   g.ax = g.ay = g.az = g.r2 = 0;
   if (!lat.on || (!sphere && !lat.flags)) return g;
   auto first = [](double v, double o, double res, int n) { int i = (int)floor((v - o) / res) - 1; return i < 0 ? 0 : (i > n ? n : i); };
@@ -141,6 +154,8 @@ __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat,
   const long long cells = (long long)g.cx * g.cy * g.cz;
   g.total = (cells > (1ll << 28) || g.cx > 1024 || g.cy > 1024 || g.cz > 1024) ? -1 : (int)cells;  // -1: a grid far too fine for the local box — the segment reports failure (count -1)
   if (sphere) { g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3]; }
+  g.inv_cxy = udiv_inverse_of(g.cx * g.cy);
+  g.inv_cx = udiv_inverse_of(g.cx);
   return g;
 }
 // centre of the cell (ix, iy, iz) of the sub-block; `packed` = iz << 20 | iy << 10 | ix (a sub-block has at most 1024 cells per axis)
@@ -151,7 +166,7 @@ __device__ __forceinline__ D3 lattice_centre(const UnknownLattice& lat, const La
 // cell number idx of the sub-block: its centre, its packed coordinates, and whether it is an unknown voxel
 __device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const LatticeRange& g, int idx, D3& q, int* packed = nullptr) {
   if (idx >= g.total) return false;
-  const int iz = idx / (g.cx * g.cy), rem = idx - iz * (g.cx * g.cy), iy = rem / g.cx, ix = rem - iy * g.cx;
+  const int iz = udiv_by(idx, g.cx * g.cy, g.inv_cxy), rem = idx - iz * (g.cx * g.cy), iy = udiv_by(rem, g.cx, g.inv_cx), ix = rem - iy * g.cx;
   if (packed) *packed = (iz << 20) | (iy << 10) | ix;
   q = d3(((double)(g.x0 + ix) + 0.5) * lat.res + lat.ox, ((double)(g.y0 + iy) + 0.5) * lat.res + lat.oy, ((double)(g.z0 + iz) + 0.5) * lat.res + lat.oz);
   if (lat.flags) return lat.flags[((size_t)(g.z0 + iz) * lat.ny + (g.y0 + iy)) * lat.nx + (g.x0 + ix)] != 0;
@@ -204,18 +219,19 @@ struct IdList {
 };
 
 // The decomposition of one segment with its list of box points in `list` (CoordList / IdList in LDS, IdList in the per-workgroup HBM
-// workspace for the densest clouds).  The first pass of the cloud sweep (the count) has been made by the caller; this is the second.
+// workspace for the densest clouds).  prebuilt >= 0: the caller's sweep has already put the `prebuilt` points of the box into the
+// list; -1: the list is filled here (a list that did not fit LDS and lives in the workspace).
 template <class L>
 __device__ void decomp_segment(const L& list, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
                                const D3* bn, double inflate, double z_ground, int max_faces, fh_face* __restrict__ out,
                                int32_t* __restrict__ count_out, int lane, const int* blist, int nb, const UnknownLattice& lat,
-                               const LatticeRange& lrange) {
+                               const LatticeRange& lrange, int prebuilt) {
   const D3 dvec = p2 - p1;
   const double f = norm(dvec) / 2;
   const Rot Ri = rot_onto(dvec);
   const D3 c = (p1 + p2) * 0.5;
   // ---- sweep the points: keep those inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
-  int cnt = 0;
+  int cnt = prebuilt >= 0 ? prebuilt : 0;
   auto keep = [&](bool in, D3 q, int ident) {
 #pragma unroll
     for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
@@ -233,13 +249,13 @@ __device__ void decomp_segment(const L& list, const double* __restrict__ cloud, 
       cnt += __popcll(m);
     }
   };
-  for (int base = 0; base < lrange.total; base += 64) {  // the unknown voxels first (a cloud of unknown + occupied points lists them first)
+  for (int base = 0; prebuilt < 0 && base < lrange.total; base += 64) {  // the unknown voxels first (a cloud of unknown + occupied points lists them first)
     D3 q = d3(0, 0, 0);
     int packed = 0;
     const bool in = lattice_point(lat, lrange, base + lane, q, &packed);
     keep(in, q, (int)(0x80000000u | (unsigned)packed));
   }
-  const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;  // (the blocks of 64 cloud points that can touch the box, in cloud order)
+  const int n_sweep = prebuilt >= 0 ? 0 : (nb >= 0 ? nb : (n_cloud + 63) / 64);  // (the blocks of 64 cloud points that can touch the box, in cloud order)
   for (int j = 0; j < n_sweep; j++) {
     const int base = (nb >= 0 ? blist[j] : j) * 64;
     const int i = base + lane;
@@ -252,6 +268,12 @@ __device__ void decomp_segment(const L& list, const double* __restrict__ cloud, 
     keep(in, q, i);
   }
   __syncthreads();
+#ifdef FHD_EXPERIMENT
+  if (lat.on && fhd_stop_after == 2) {
+    if (lane == 0) *count_out = cnt ? 0 : 0;
+    return;
+  }
+#endif
 
   // ---- ellipsoid fit (line_segment.h:156-252)
   D3 axes = d3(f, f, f);
@@ -296,6 +318,12 @@ __device__ void decomp_segment(const L& list, const double* __restrict__ cloud, 
     __syncthreads();
   }
 
+#ifdef FHD_EXPERIMENT
+  if (lat.on && fhd_stop_after == 3) {
+    if (lane == 0) *count_out = (axes.z > 0) ? 0 : 0;
+    return;
+  }
+#endif
   // ---- separating planes (decomp_base.h:83-115), written straight as rows oriented around the midpoint (polyhedron.h:131-152)
   int rows = 0;
   bool too_many = false;
@@ -405,8 +433,7 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
     bp[3] = p1 - dir * bx; bn[3] = dir * -1.0;
     bp[4] = p1 + dv * bz; bn[4] = dv;
     bp[5] = p1 - dv * bz; bn[5] = dv * -1.0;
-    // first sweep: how many cloud points fall in the box decides where the list lives
-    // Blocks of 64 consecutive cloud points whose bounding box (blocks: cloud_blocks_kernel) misses the bounding box of the local box
+    // the candidates of the sweep.  Blocks of 64 consecutive cloud points whose bounding box (blocks: cloud_blocks_kernel) misses the bounding box of the local box
     // hold no point of interest: a mapper's cloud is spatially coherent, so most blocks are skipped.  The candidates are visited in
     // cloud order, so the list of points — and with it every tie rule — is the one of the full sweep.
     int nb = -1;
@@ -443,45 +470,77 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
       }
       __syncthreads();
     }
+    // ONE sweep over the candidates: the points of the box are listed as ids (a cloud index, or the packed cell of an unknown voxel)
+    // in LDS, up to FH_DECOMP_CAP_IDS of them, and counted beyond that.  (Round 3 swept twice — count, then store: the count decided
+    // where the list lives.)  A short list is then turned into coordinates in place; a list that does not fit LDS is swept again
+    // into the workspace.
+    int* lids = reinterpret_cast<int*>(lraw);
+    unsigned char* lflags = reinterpret_cast<unsigned char*>(lraw + 3 * FH_DECOMP_CAP);
     int cnt = 0;
-    for (int base = 0; base < lrange.total; base += 64) {
-      D3 q = d3(0, 0, 0);
-      bool in = lattice_point(lat, lrange, base + lane, q);
+    auto note = [&](bool in, D3 q, int ident) {
 #pragma unroll
       for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
-      cnt += __popcll(__ballot(in));
+      const unsigned long long m = __ballot(in);
+      if (m) {
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && pos < FH_DECOMP_CAP_IDS) lids[pos] = ident;
+        cnt += __popcll(m);
+      }
+    };
+    for (int base = 0; base < lrange.total; base += 64) {
+      D3 q = d3(0, 0, 0);
+      int packed = 0;
+      const bool in = lattice_point(lat, lrange, base + lane, q, &packed);
+      note(in, q, (int)(0x80000000u | (unsigned)packed));
     }
     const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;
     for (int j = 0; j < n_sweep; j++) {
       const int base = (nb >= 0 ? lblist[j] : j) * 64;
       const int i = base + lane;
       bool in = false;
+      D3 q = d3(0, 0, 0);
       if (i < n_cloud) {
-        const D3 q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
+        q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
         in = true;
-#pragma unroll
-        for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
       }
-      cnt += __popcll(__ballot(in));
+      note(in, q, i);
     }
+    __syncthreads();
+#ifdef FHD_EXPERIMENT  // (timing experiments only: what a launch with unknown voxels costs up to here; FHD_STOP_AFTER in the environment)
+    if (lat.on && fhd_stop_after == 1) {
+      if (lane == 0) counts[seg] = cnt ? 0 : 0;
+      continue;
+    }
+#endif
     const Rot Ri0 = rot_onto(p2 - p1);
     const D3 c0 = (p1 + p2) * 0.5;
+    IdList I;
+    I.id = lids; I.fl = lflags;
+    I.cloud = cloud; I.lat = &lat; I.lr = &lrange; I.Ri = Ri0; I.c = c0; I.inflate = inflate;
     if (cnt <= FH_DECOMP_CAP) {
+      // ids -> inflated coordinates, in the same bytes: every lane takes its ids out first (IdList::point is the arithmetic the
+      // coordinate list used to apply while sweeping: the same doubles)
       CoordList L;
       L.px = lraw; L.py = lraw + FH_DECOMP_CAP; L.pz = lraw + 2 * FH_DECOMP_CAP;
-      L.fl = reinterpret_cast<unsigned char*>(lraw + 3 * FH_DECOMP_CAP);
-      decomp_segment(L, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange);
+      L.fl = lflags;
+      int mine[FH_DECOMP_CAP / 64];
+#pragma unroll
+      for (int k = 0; k < FH_DECOMP_CAP / 64; k++) mine[k] = (64 * k + lane < cnt) ? lids[64 * k + lane] : 0;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < FH_DECOMP_CAP / 64; k++)
+        if (64 * k + lane < cnt) {
+          const D3 pt = I.point(mine[k]);
+          L.px[64 * k + lane] = pt.x; L.py[64 * k + lane] = pt.y; L.pz[64 * k + lane] = pt.z;
+        }
+      __syncthreads();
+      decomp_segment(L, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange, cnt);
+    } else if (cnt <= FH_DECOMP_CAP_IDS) {
+      decomp_segment(I, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange, cnt);
     } else if (cnt <= FH_DECOMP_CAP_GLOBAL) {
-      IdList L;
-      if (cnt <= FH_DECOMP_CAP_IDS) {
-        L.id = reinterpret_cast<int*>(lraw);
-        L.fl = reinterpret_cast<unsigned char*>(lraw + 3 * FH_DECOMP_CAP);
-      } else {
-        L.id = reinterpret_cast<int*>(gws);
-        L.fl = reinterpret_cast<unsigned char*>(gws + FH_DECOMP_CAP_GLOBAL);
-      }
-      L.cloud = cloud; L.lat = &lat; L.lr = &lrange; L.Ri = Ri0; L.c = c0; L.inflate = inflate;
-      decomp_segment(L, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange);
+      I.id = reinterpret_cast<int*>(gws);
+      I.fl = reinterpret_cast<unsigned char*>(gws + FH_DECOMP_CAP_GLOBAL);
+      decomp_segment(I, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange, -1);
     }
     else if (lane == 0)
       counts[seg] = -1;
