@@ -15,6 +15,7 @@
 
 #include "../../include/fasterhip.h"
 #include "fh_solve.hip.hpp"  // wave reductions
+#include "fh_udiv.hpp"
 
 // every decision of the decomposition (which point is closest, on which side of a plane a point lies) must fall as on the host:
 // the same products and sums, no fused multiply-adds
@@ -128,17 +129,9 @@ struct UnknownLattice {
 };
 struct LatticeRange {
   int x0, cx, y0, cy, z0, cz, total;  // sub-block of the grid: first cell and count per axis
-  unsigned inv_cxy, inv_cx;           // floor(2^32 / (cx cy)), floor(2^32 / cx): a cell number is split with two multiply-highs (udiv_by)
+  unsigned inv_cxy, inv_cx;           // floor(2^32 / (cx cy)), floor(2^32 / cx): a cell number is split with two multiply-highs (fhu::div, fh_udiv.hpp)
   double ax, ay, az, r2;              // the sphere of known space
 };
-// n / d for n < 2^28 with inv = floor(2^32 / d) (0xffffffff for d = 1): mulhi(n, inv) is the quotient or one less, one correction —
-// 5 vector instructions where the compiler's expansion of a 32-bit division takes 20+ (the sweeps split every cell number twice).
-__device__ __forceinline__ unsigned udiv_inverse_of(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(4294967296.0 / (double)d); }  // (exact: the fraction of 2^32 / d is 0 or >= 2^-20)
-__device__ __forceinline__ int udiv_by(int n, int d, unsigned inv) {
-  unsigned q = __umulhi((unsigned)n, inv);
-  if ((unsigned)n - q * (unsigned)d >= (unsigned)d) q++;
-  return (int)q;
-}
 __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat, const double lo[3], const double hi[3], const double* sphere) {
   LatticeRange g;
   g.total = 0; g.x0 = g.y0 = g.z0 = g.cx = g.cy = g.cz = 0;
@@ -154,8 +147,8 @@ __device__ __forceinline__ LatticeRange lattice_range(const UnknownLattice& lat,
   const long long cells = (long long)g.cx * g.cy * g.cz;
   g.total = (cells > (1ll << 28) || g.cx > 1024 || g.cy > 1024 || g.cz > 1024) ? -1 : (int)cells;  // -1: a grid far too fine for the local box — the segment reports failure (count -1)
   if (sphere) { g.ax = sphere[0]; g.ay = sphere[1]; g.az = sphere[2]; g.r2 = sphere[3] * sphere[3]; }
-  g.inv_cxy = udiv_inverse_of(g.cx * g.cy);
-  g.inv_cx = udiv_inverse_of(g.cx);
+  g.inv_cxy = fhu::inverse_fp(g.cx * g.cy);
+  g.inv_cx = fhu::inverse_fp(g.cx);
   return g;
 }
 // centre of the cell (ix, iy, iz) of the sub-block; `packed` = iz << 20 | iy << 10 | ix (a sub-block has at most 1024 cells per axis)
@@ -166,7 +159,7 @@ __device__ __forceinline__ D3 lattice_centre(const UnknownLattice& lat, const La
 // cell number idx of the sub-block: its centre, its packed coordinates, and whether it is an unknown voxel
 __device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const LatticeRange& g, int idx, D3& q, int* packed = nullptr) {
   if (idx >= g.total) return false;
-  const int iz = udiv_by(idx, g.cx * g.cy, g.inv_cxy), rem = idx - iz * (g.cx * g.cy), iy = udiv_by(rem, g.cx, g.inv_cx), ix = rem - iy * g.cx;
+  const int iz = fhu::div(idx, g.cx * g.cy, g.inv_cxy), rem = idx - iz * (g.cx * g.cy), iy = fhu::div(rem, g.cx, g.inv_cx), ix = rem - iy * g.cx;
   if (packed) *packed = (iz << 20) | (iy << 10) | ix;
   q = d3(((double)(g.x0 + ix) + 0.5) * lat.res + lat.ox, ((double)(g.y0 + iy) + 0.5) * lat.res + lat.oy, ((double)(g.z0 + iz) + 0.5) * lat.res + lat.oz);
   if (lat.flags) return lat.flags[((size_t)(g.z0 + iz) * lat.ny + (g.y0 + iy)) * lat.nx + (g.x0 + ix)] != 0;

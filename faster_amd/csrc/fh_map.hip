@@ -330,7 +330,7 @@ int fh_map_plan_batch_device(fh_map* m, const double* d_starts, const double* d_
   fhp::MapView mv;
   mv.nx = m->nx; mv.ny = m->ny; mv.nz = m->nz;
   mv.total = m->nx * m->ny * m->nz;
-  mv.inv_nxy = fhp::udiv_inverse(m->nx * m->ny); mv.inv_nx = fhp::udiv_inverse(m->nx);
+  mv.inv_nxy = fhu::inverse(m->nx * m->ny); mv.inv_nx = fhu::inverse(m->nx);
   mv.m_free = (int)std::round((double)(float)m->inflation / m->res + 0.5);  // setFreeVoxelAndSurroundings(center, const float d), map_util.h:248-263
   mv.res = m->res; mv.ox = m->origin[0]; mv.oy = m->origin[1]; mv.oz = m->origin[2];
   mv.bits = m->d_bits;

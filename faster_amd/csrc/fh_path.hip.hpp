@@ -27,6 +27,8 @@
 
 #pragma clang fp contract(off)   // cell indices must equal the host's: no fused multiply-adds in the coordinate arithmetic
 
+#include "fh_udiv.hpp"
+
 namespace fhp {
 
 constexpr int NCHUNK = 2048;    // chunks of 64 open-list entries per wavefront (131072 entries)
@@ -37,7 +39,7 @@ constexpr double KEY_SCALE = 1048576.0;
 
 struct MapView {
   int nx, ny, nz, total, m_free;
-  unsigned inv_nxy, inv_nx;  // floor(2^32 / (nx ny)), floor(2^32 / nx) (0xffffffff for a divisor of 1): see udiv_cell
+  unsigned inv_nxy, inv_nx;  // floor(2^32 / (nx ny)), floor(2^32 / nx) (0xffffffff for a divisor of 1): see fhu::div
   double res, ox, oy, oz;
   const unsigned* bits;  // occupancy, one bit per cell
 };
@@ -74,16 +76,7 @@ struct PlanArgs {
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// n / d for a cell index n < 2^27 with inv = floor(2^32 / d): the estimate mulhi(n, inv) is the quotient or one less (n r / (d 2^32)
-// < 1/32 for the remainder r of 2^32 by d), one correction.  On a wave-uniform n this is three scalar instructions; the compiler's
-// own expansion of the division runs on the vector unit whatever the operand (45 vector instructions per popped node for the two
-// divisions of a cell index).
-__host__ __device__ __forceinline__ unsigned udiv_inverse(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned)d); }
-__device__ __forceinline__ int udiv_cell(int n, int d, unsigned inv) {
-  unsigned q = __umulhi((unsigned)n, inv);
-  if ((unsigned)n - q * (unsigned)d >= (unsigned)d) q++;
-  return (int)q;
-}
+// (cell indices are split with fhu::div, fh_udiv.hpp: on a wave-uniform index three scalar instructions instead of 45 vector ones)
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ int rank_in(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -193,9 +186,9 @@ struct Planner {
   }
   __device__ __forceinline__ void decode(int id, int& x, int& y, int& z) const {
     const int nxy = mv.nx * mv.ny;
-    z = udiv_cell(id, nxy, mv.inv_nxy);
+    z = fhu::div(id, nxy, mv.inv_nxy);
     const int rem = id - z * nxy;
-    y = udiv_cell(rem, mv.nx, mv.inv_nx);
+    y = fhu::div(rem, mv.nx, mv.inv_nx);
     x = rem - y * mv.nx;
   }
   __device__ __forceinline__ void center(int id, double c[3]) const {  // MapUtil::intToFloat
@@ -1188,7 +1181,7 @@ struct Planner {
       unsigned long long ckey = 0ull;  // (hashed records: the key in the home slot of the popped cell, on its way while the heap is put in order)
       if (HASHED) ckey = hk[home(cur)];
       else if (lane == 0) cells[cur].stamp = (serial << 6) | ((unsigned)code << 1) | 1u;  // closed
-      const int cz = udiv_cell(cur, nxy, mv.inv_nxy), rem = cur - cz * nxy, cy = udiv_cell(rem, mv.nx, mv.inv_nx), cx = rem - cy * mv.nx;
+      const int cz = fhu::div(cur, nxy, mv.inv_nxy), rem = cur - cz * nxy, cy = fhu::div(rem, mv.nx, mv.inv_nx), cx = rem - cy * mv.nx;
       const int n1 = abs(code % 3 - 1) + abs((code / 3) % 3 - 1) + abs(code / 9 - 1);
       const int num_neib = n1 == 0 ? 26 : (n1 == 1 ? 1 : (n1 == 2 ? 3 : 7)), num_fneib = n1 == 0 ? 0 : (n1 == 1 ? 8 : 12);
       // ---- the successors (getJpsSucc, :318-368), one candidate per lane in jps3d's order: lanes < num_neib the natural neighbours,

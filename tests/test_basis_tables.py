@@ -32,3 +32,16 @@ def test_sample_clock_short_cut_equals_the_loop():
         assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
         assert int(r.stdout.split()[0]) > 500000
     assert os.path.getsize(hdr) > 0
+
+
+def test_divisions_by_multiply_high_are_exact():
+    """faster_amd/csrc/fh_udiv.hpp: a cell number split by a launch-constant divisor with one multiply-high and one correction is the
+    integer quotient for every n < 2^28 (tests/cpp/test_udiv.cpp: every divisor up to 200 000, powers of two and their neighbours,
+    random divisors up to 2^27; multiples of the divisor and their neighbours), and the inverse computed with one double division is
+    floor(2^32 / d) for d <= 2^20."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_udiv.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_udiv")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+    assert int(r.stdout.split()[0]) > 100000000
