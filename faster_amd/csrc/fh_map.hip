@@ -95,13 +95,20 @@ int ensure_workspace(fh_map* m) {
   // LDS: 12.5 KB per wavefront (A*: 12 per CU), 7.5 KB and 96 VGPRs (jump point search: 20 per CU)
   int waves = m->n_cu * (m->sched_waves_per_cu > 0 ? m->sched_waves_per_cu : (m->search_mode == 1 ? 20 : 12));
   int slots = m->search_mode == 1 ? m->record_slots : 0;
-  if (slots < 0) slots = (size_t)waves * total * sizeof(fhp::CellState) > ((size_t)32 << 30) ? 65536 : 0;
+  const size_t budget = (size_t)48 << 30;
+  if (slots < 0) {
+    // by the size of the map: per-cell records while the budget still holds them for at least half of the wavefronts — fewer
+    // wavefronts cost less than the table (measured: 816 k cells, 13 of 20 wavefronts per CU, are faster per cell; 1.45 M cells, 8 of
+    // 20, are 1.6x faster hashed) and per-cell records have no limit on the cells a query may reach.  Else 131072 hashed slots
+    // (5 MB per wavefront; a query may reach 98 304 cells).
+    const size_t dense_per_wave = total * sizeof(fhp::CellState) + (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS * 4;
+    slots = budget / dense_per_wave >= (size_t)waves / 2 ? 0 : 131072;
+  }
   const size_t records = slots > 0 ? (size_t)slots : total;
-  // the chunk pool: open-list chunks (A*), the heap levels below LDS (jump point search: 60000 entries of 20 B; with hashed records a
+  // the chunk pool: open-list chunks (A*), the heap levels below LDS (jump point search: 78000 entries of 20 B — what the pool holds; with hashed records a
   // cell has one heap entry at most, so 3/4 of the slots), and the clean-up lists of the finished path (3 x MAXRAW ints)
   const size_t chunk_words = slots > 0 ? std::max<size_t>((size_t)(slots / 4 * 3) * 5, (size_t)3 * fhp::MAXRAW) + 16 : (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS;
   const size_t per_wave = records * sizeof(fhp::CellState) + (slots > 0 ? (size_t)slots * 8 : 0) + chunk_words * 4;
-  const size_t budget = (size_t)48 << 30;
   if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);
   if (m->d_cells && m->ws_total == total && m->ws_slots == slots && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
   FM_HIP(hipStreamSynchronize(m->stream));
@@ -214,7 +221,7 @@ int fh_map_set_search(fh_map* m, int mode) {
 // map and wavefront (16 B x cells x wavefronts).  slots = a power of two in [1024, 2^22]: a hashed table of that many records per
 // wavefront (24 B per slot + 15 B per slot of heap levels, whatever the size of the map) holding the cells the running query has
 // reached; a query that reaches more than 3/4 of `slots` cells returns -2.  Same paths either way.  -1 (default): per-cell records
-// while they take at most 32 GB for all wavefronts, else 65536 hashed slots.  Measured (65536 forest queries, profiles/
+// while the 48 GB budget holds them for at least half of the wavefronts, else 131072 hashed slots.  Measured (65536 forest queries, profiles/
 // r04_jps_records.json): 181 500 cells — per cell 54 ms / 23.8 GB, 8192 slots 66 ms / 1.6 GB; 1 452 000 cells — per cell 476 ms /
 // 51.5 GB (2064 wavefronts fit the 48 GB budget), 32768 slots 298 ms / 6.5 GB.  The A* search (mode 0) always uses per-cell records.
 int fh_map_set_records(fh_map* m, int slots) {

@@ -121,6 +121,12 @@ __device__ inline void sphere_crossing(const double a_in[3], const double b_in[3
 // `expansions` instead of the popped nodes.  0 pop + candidate addresses, 1 heap sift-down, 2 candidates settled from the tables,
 // 3 cell-by-cell jumps, 4 move costs + wait for the cell records, 5 relaxation, 6 heap pushes, 7 the whole query; 8 / 9 the
 // sift-down while the heap fits LDS / is deeper, 10 popped nodes with a deeper heap, 11 sum of the heap sizes.
+// (diagnostic builds tell the limits apart: n_points = -20 - k)
+#ifdef FHP_DEBUG_CODES
+#define FHP_LIMIT(k) (-20 - (k))
+#else
+#define FHP_LIMIT(k) (-2)
+#endif
 #ifdef FHP_PROFILE
 #define FHP_T(k) do { const long long t__ = (long long)__builtin_readcyclecounter(); if (prof_slot == (k)) prof_acc += t__ - prof_t; prof_t = t__; } while (0)
 #else
@@ -577,7 +583,7 @@ struct Planner {
     vb = va + MAXRAW;
     int len = 0;
     for (int id = tid;;) {
-      if (len >= MAXRAW) return -2;
+      if (len >= MAXRAW) return FHP_LIMIT(4);
       if (lane == 0) raw[len] = id;
       len++;
       if (id == sid) break;
@@ -651,7 +657,7 @@ struct Planner {
   // The heap is jps3d's binary heap, top 311 entries in LDS (the rest in the wavefront's chunk pool), moved by one scalar
   // program that all lanes execute; the position of an entry whose key decreases is found by a lane-parallel scan.
   // Cell state: g, parent, stamp = serial << 6 | direction id << 1 | closed.
-  static constexpr int CAP_L = 311, CAP_G = 60000;  // (an odd number: the children of a node are both in LDS or both in the chunk pool; 312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;
+  static constexpr int CAP_L = 311, CAP_G = 78000;  // (78000 x 20 B: what the wavefront's chunk pool, NCHUNK x CHUNK_WORDS words, holds; 311, an odd number: the children of a node are both in LDS or both in the chunk pool; 312: 7 644 B of LDS with the tables = 6 granules -> 20 workgroups per CU at 96 VGPRs;
                                                    //  432 and 16 per CU: 67 ms instead of 63 for 65536 forest queries; 248 and 24 per CU at 80 VGPRs, spilling: 65 ms)
   // (typed by address space: a select between an LDS and a chunk pool pointer cannot be formed, so an access is a ds_ or a global_
   // instruction, never a flat_ one through a pointer picked at run time)
@@ -789,6 +795,7 @@ struct Planner {
   // the scalar unit, and the entries on it are compared with m and moved up by one lane each.  If m sinks past the end of that
   // path (a heap deeper than LDS holds) the serial walk takes over there.  The comparisons are the ones the serial walk makes
   // (child against child, then the preferred child against m), so the heap ends up in the same state.
+  static_assert((size_t)CAP_G * 20 <= (size_t)NCHUNK * CHUNK_WORDS * 4, "the heap levels below LDS live in the chunk pool");
   static constexpr int LDS_INNER = (CAP_L - 1) / 2;  // nodes below have both children in LDS, the others both in the chunk pool
   static_assert(CAP_L % 2 == 1, "a node's children must not straddle LDS and the chunk pool");
   __device__ __forceinline__ void sift_down(const HE& m, int n) {
@@ -1174,7 +1181,7 @@ struct Planner {
     long long pops = 0;
     for (;;) {  // graph_search.cpp:123-217
       expansions++;
-      if (++pops > (long long)mv.total) return -2;  // (a cell is opened once: cannot happen)
+      if (++pops > (long long)mv.total) return FHP_LIMIT(1);  // (a cell is opened once: cannot happen)
       FHP_T(-2);
       const HE top = hget(0);
       const int cur = rfl(top.id) & IDMASK, code = (rfl(top.id) >> 27) & 31;  // (the heap entry carries the direction the node was reached in)
@@ -1331,12 +1338,12 @@ struct Planner {
           push = !v2;
         }
         if (push) {
-          if (n >= CAP_L + cap_g) return -2;
+          if (n >= CAP_L + cap_g) return FHP_LIMIT(2);
           sift_up(n, me);
           n++;
         } else {  // pq_.increase
           const int pos = heap_find(nj, n);
-          if (pos < 0) return -2;  // (cannot happen)
+          if (pos < 0) return FHP_LIMIT(3);  // (cannot happen)
           sift_up(pos, me);
         }
       }

@@ -443,7 +443,7 @@ int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
  * (thirdparty/jps3d/src/jps_planner/graph_search.cpp:123-470) — of the optimal paths, the one FASTER itself gets from
  * planner_ptr_->plan(start, goal, 1, true) (faster/src/jps_manager.cpp:166); equals plan_path_jps bit for bit, which is pinned vertex
  * for vertex to the reference's compiled sources behind a test-only Boost.Heap shim (oracle/ref_frontend/shim: the sift discipline that
- * decides between equal-cost paths is the shim author's reading of Boost's, not Boost itself).  Limits in mode 1: 60311 open entries, 4096 jump points on the path.
+ * decides between equal-cost paths is the shim author's reading of Boost's, not Boost itself).  Limits in mode 1: 78311 open entries, 4096 jump points on the path.
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
 /* How the jump point search (mode 1) keeps its per-cell records (g, parent, direction, closed) — jps3d's hm_ / seen_
@@ -452,8 +452,9 @@ int fh_map_set_search(fh_map* map, int mode);
  * a hashed table of that many records per wavefront (39 bytes per slot with the heap levels that go with it, whatever the size of
  * the map), holding the cells the running query has reached; a query that reaches more than 3/4 of `slots` cells returns
  * n_points = -2 (raise slots, or use 0).  The same reads and writes in the same order either way: identical paths.
- * slots = -1 (default): per-cell records while they take at most 32 GB over all wavefronts (faster on small maps: 54 vs 66 ms for
- * 65536 queries in 181 500 cells), else 65536 hashed slots (1 452 000 cells: 298 ms and 6.5 GB against 476 ms and 51.5 GB).
+ * slots = -1 (default): per-cell records while the 48 GB workspace budget holds them for at least half of the wavefronts (faster on
+ * small maps: 54 vs 66 ms for 65536 queries in 181 500 cells — and without a limit on the cells a query may reach), else 131072
+ * hashed slots (1 452 000 cells: 298 ms and 6.5 GB with 32768 slots against 476 ms and 51.5 GB).
  * The A* search (mode 0) always uses per-cell records.
  * fh_map_workspace_bytes: size of the search workspace as allocated by the last search (0 before the first). */
 int fh_map_set_records(fh_map* map, int slots);

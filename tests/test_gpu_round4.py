@@ -323,6 +323,16 @@ def test_hashed_cell_records_give_the_same_paths_in_a_fraction_of_the_workspace(
         m.set_records(32768)
         same(host, m.plan_batch(starts, goals), "0.1 m cells, hashed records")
         assert m.workspace_bytes() <= 5120 * 32768 * 40
+        # by the size of the map (-1): per-cell records while the budget holds them for half of the wavefronts, hashed beyond
+        m.set_records(-1)
+        same(host, m.plan_batch(starts, goals), "0.1 m cells, records by the size of the map")
+        assert m.workspace_bytes() > 5120 * 300000 * 16  # (300 000 cells: per-cell records)
+        cloud, cells, center, starts, goals = frontend.forest_queries(128, 5)
+        cells = tuple(2 * c for c in cells)  # the C5 forest at 0.1 m: 1.45 M cells
+        m.read(cloud, cells, 0.1, center, 0.0, 3.0, infl)
+        host = frontend.plan_batch(cloud, cells, 0.1, center, 0.0, 3.0, infl, starts, goals)
+        same(host, m.plan_batch(starts, goals), "1.45 M cells, records by the size of the map")
+        assert m.workspace_bytes() <= 5120 * 131072 * 40  # (hashed: 27 GB, not the 48 GB of as many per-cell records as fit)
     finally:
         m.close()
         frontend.set_search("astar")
