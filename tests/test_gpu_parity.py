@@ -520,6 +520,24 @@ def test_gpu_decomposition_edge_cases(ctx):
         keep &= np.linalg.norm(dense - (a + t[:, None] * (b - a)), axis=1) > 0.4
     dense = dense[keep]
     check(dense, path, drone_radius=0.1)
+    # the three homes of a segment's point list: coordinates in LDS (<= 256 points), ids in LDS (<= 1536), ids in the workgroup's
+    # HBM workspace (the sweep is repeated into it) — one cloud per regime, the same rows as the host every time
+    for size, lo, hi in ((600, 1, 256), (9000, 257, 1536), (45000, 1537, 16384)):
+        cl = rng.uniform([-2.5, -2.5, 0.0], [5.5, 3.0, 3.5], size=(size, 3))
+        keep = np.ones(len(cl), bool)
+        for a, b in zip(path[:-1], path[1:]):
+            t = np.clip(((cl - a) @ (b - a)) / ((b - a) @ (b - a)), 0, 1)
+            keep &= np.linalg.norm(cl - (a + t[:, None] * (b - a)), axis=1) > 0.4
+        cl = cl[keep]
+        inside = []
+        for a, b in zip(path[:-1], path[1:]):  # points of the local box (2 x 2 x 1 m around the leg), roughly: which regime the leg is in
+            d = (b - a) / np.linalg.norm(b - a)
+            rel = cl - a
+            along = rel @ d
+            perp = np.linalg.norm(rel - np.outer(along, d), axis=1)
+            inside.append(int(((along > -2.0) & (along < np.linalg.norm(b - a) + 2.0) & (perp < 1.0)).sum()))
+        assert any(lo <= k <= hi for k in inside), (size, inside)
+        check(cl, path, drone_radius=0.1)
     # many segments (more than resident workgroups): every copy of a segment gives the same polytope
     segs = np.tile(np.hstack([path[:-1], path[1:]]), (1500, 1))
     faces, counts = ctx.decompose_batch(dense[::8], segs, max_faces=96)
