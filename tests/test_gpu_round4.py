@@ -336,3 +336,35 @@ def test_hashed_cell_records_give_the_same_paths_in_a_fraction_of_the_workspace(
     finally:
         m.close()
         frontend.set_search("astar")
+
+
+def test_jump_point_search_with_heaps_far_deeper_than_lds():
+    """A cube of 81 x 81 x 80 cells with dense trees and goals that cannot be reached from many starts: the searches exhaust what
+    they can reach (tens of thousands of popped nodes, heaps of tens of thousands of entries — the 311 entries of LDS are the tip),
+    so that the sinking of an entry continues in the chunk pool, entries rise across the boundary and `increase` finds its entry in
+    the pool.  Same popped nodes and vertices as the host restatement, with per-cell records and with a hashed table big enough."""
+    frontend.set_search("jps")
+    m = capi.Map(0)
+    try:
+        m.set_search("jps")
+        side, res, infl = 12.0, 0.15, 0.45
+        cloud, _ = frontend.forest_cloud(116, size=(side, side, side), density=0.3)
+        cells = (int(side / res) + 1, int(side / res) + 1, int(side / res))
+        center = np.array([side / 2, side / 2, side / 2])
+        rng = np.random.default_rng(3)
+        n = 192
+        starts = np.column_stack([rng.uniform(0.3, side - 0.3, n), rng.uniform(0.3, side - 0.3, n), rng.uniform(0.0, side, n)])
+        goals = np.column_stack([rng.uniform(0.3, side - 0.3, n), rng.uniform(0.3, side - 0.3, n), rng.uniform(0.0, side, n)])
+        host = frontend.plan_batch(cloud, cells, res, center, 0.0, side, infl, starts, goals)
+        assert host[2].max() > 30000 and (host[1] == 0).sum() >= 4 and (host[1] > 0).sum() >= 100, (host[2].max(), (host[1] == 0).sum())
+        m.read(cloud, cells, res, center, 0.0, side, infl)
+        for slots in (0, 262144):
+            m.set_records(slots)
+            dp, dn, dex = m.plan_batch(starts, goals)
+            assert np.array_equal(host[1], dn), (slots, np.nonzero(host[1] != dn)[0][:8], dn[host[1] != dn][:8])
+            assert np.array_equal(host[2], dex), slots
+            for i in np.nonzero(dn > 0)[0]:
+                assert np.array_equal(host[0][i, :dn[i]], dp[i, :dn[i]]), (slots, i)
+    finally:
+        m.close()
+        frontend.set_search("astar")
