@@ -401,7 +401,8 @@ class Context:
 
     def set_sched(self, **kw):
         """fh_set_sched: scheduling of a solve launch (launch_order, publish_factor, backlog, waiting_workgroups, min_nodes,
-        cloud_blocks, workgroups_per_cu, child_bound); unnamed fields keep their defaults.  No result field depends on them."""
+        cloud_blocks, workgroups_per_cu, child_bound); unnamed fields keep their defaults.  No result field depends on them.
+        workgroups_per_cu in 1..8 also selects the kernel build for two wavefronts per SIMD (a batch alone on the device is done sooner)."""
         s = abi.default_sched()
         for k, v in kw.items():
             s[k] = v

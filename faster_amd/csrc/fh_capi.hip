@@ -39,7 +39,7 @@ struct fh_ctx {
                      nullptr, nullptr, nullptr, nullptr};
   size_t d_cap[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
-  size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
+  size_t lds_attr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
   unsigned int* d_abort = nullptr;          // its device address
   unsigned int* h_report = nullptr;         // pinned: the control block's report words of the last launch (copied with the results)
@@ -105,11 +105,13 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   using SV = fh::Solver<NSEG>;
   const int n = ka.n;
   const size_t lds = SV::lds_bytes(ka.max_faces);
-  auto kern = fh::solve_kernel<NSEG, PAIRS>;
+  // fh_sched.workgroups_per_cu <= 8: the instantiation compiled for two wavefronts per SIMD (all its registers, no scratch)
+  const bool two_waves = FH_WAVES_PER_SIMD > 2 && ctx->sched.workgroups_per_cu > 0 && ctx->sched.workgroups_per_cu <= 8;
+  auto kern = two_waves ? fh::solve_kernel<NSEG, PAIRS, 2> : fh::solve_kernel<NSEG, PAIRS>;
   // persistent grid: what is resident at once (LDS-limited, <= 8 workgroups per CU)
   // LDS is handed out in granules of 1280 B (residency census on MI355X: 14 080 B admit 11 workgroups per CU, 14 336 B only 10)
   const size_t lds_alloc = (lds + 1279) / 1280 * 1280;
-  int per_cu = (int)std::min<size_t>(FH_WAVES_PER_SIMD * 4, (160 * 1024) / lds_alloc);
+  int per_cu = (int)std::min<size_t>((two_waves ? 2 : FH_WAVES_PER_SIMD) * 4, (160 * 1024) / lds_alloc);
   if (per_cu < 1) per_cu = 1;
   // fh_sched.workgroups_per_cu: fewer resident solves per CU than would fit.  The launch then asks for so much LDS that the hardware
   // cannot place more either, whatever else is in flight.
@@ -158,7 +160,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   ka.workspace = (double*)ctx->d_buf[5];
   ka.basis = (const double*)ctx->d_buf[15];
   {  // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it
-    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : (NSEG <= 15 ? 2 : 3))) + (PAIRS ? 4 : 0)];
+    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : (NSEG <= 15 ? 2 : 3))) + (PAIRS ? 4 : 0) + (two_waves ? 8 : 0)];
     if (lds_launch > have) {
       FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
       have = lds_launch;

@@ -2505,8 +2505,11 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
 // Faster::replan (faster.cpp:427 whole genNewTraj, :475 R = X_whole[k], :521-536 safe genNewTraj) is per pair, so nothing waits
 // for the stragglers of a batch-wide whole launch before the safe solves start.  The safe problem record and its face rows are
 // written and read back through L2 inside the launch (possibly by another workgroup): agent-scope fences order the two.
-template <int NSEG, bool PAIRS>
-__global__ void __launch_bounds__(64, FH_WAVES_PER_SIMD) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
+// WPS: wavefronts per SIMD the kernel is compiled for.  3 (168 registers, some spilled: 11 resident solves per CU at N = 10) is the
+// throughput build; 2 (193 registers at N = 10, nothing spilled, no scratch: 8 per CU) solves a batch that is alone on the device
+// 13 % sooner and many batches in flight 14 % slower — fh_sched.workgroups_per_cu <= 8 selects it.  The same arithmetic: the same bits.
+template <int NSEG, bool PAIRS, int WPS = FH_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
                                                    fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Solver<NSEG> sv;

@@ -455,7 +455,8 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
     ref = run(ctx)
     assert (ref[1]["solved"] == 1).mean() > 0.7
     # (fh_set_sched: explicit fields, no environment.  min_nodes 64: almost nothing is given to idle workgroups; child_bound 0: every
-    # child of a node is visited — the tree of the CPU oracle, about twice the nodes)
+    # child of a node is visited — the tree of the CPU oracle, about twice the nodes; workgroups_per_cu 5: also ANOTHER BUILD of the
+    # kernel — compiled for two wavefronts per SIMD, nothing spilled — selected by any value up to 8)
     variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0, "workgroups_per_cu": 5, "min_nodes": 64, "child_bound": 0}
     for k, v in variants.items():
         ctx.set_sched(**{k: v})
