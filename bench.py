@@ -819,7 +819,7 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
 def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
     """BASELINE config C5 as a record of the N=1 line (outside the C4 timed region): 65536 start/goal pairs in one random forest,
     corridors from the DEVICE front-end (voxel map + path search + ellipsoid decomposition), then one fused whole+safe launch over
-    all of them with `solve_kernel<15, true>`; everything stays in HBM between the two.  Median of `reps` fenced steps."""
+    all of them with `solve_kernel<15, true, 2>` (LDS admits 5 solves per CU: the build for two wavefronts per SIMD); everything stays in HBM between the two.  Median of `reps` fenced steps."""
     import numpy as np
 
     from faster_amd import abi, capi, corridor, frontend
@@ -867,7 +867,7 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
     front_s = ft["map_s"] + ft["path_search_s"] + ft["decomposition_s"]
     return {"workload": "C5: %d whole+safe pairs (of %d queries with a path) in a random forest (20x20x3 m, 0.1 trees/m^2), N=15, <=8 polytopes, "
                         "corridors from the device front-end; one fused launch alone on the GPU" % (B, pairs),
-            "kernel": "fh::solve_kernel<15, true>", "pairs": B, "step_ms_median": med, "pairs_per_s": B / (med * 1e-3), "repetitions": reps,
+            "kernel": "fh::solve_kernel<15, true, 2>", "pairs": B, "step_ms_median": med, "pairs_per_s": B / (med * 1e-3), "repetitions": reps,
             "front_end": {"map_s": ft["map_s"], "path_search_s": ft["path_search_s"], "decomposition_s": ft["decomposition_s"],
                           "corridors_per_s": pairs / front_s, "expansions": ft["expansions"],
                           "path_search": "jump point search in jps3d's own order (fh_map_set_search 1): FASTER's exact vertex lists; the jump "

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for the C5 kernel (fh::solve_kernel<15, true>): kernel stats and PMC passes of bench.py --workload c5
+# rocprofv3 evidence for the C5 kernel (fh::solve_kernel<15, true, 2>): kernel stats and PMC passes of bench.py --workload c5
 set -u
 TAG=${1:-r04_c5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
