@@ -109,9 +109,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // LDS is handed out in granules of 1280 B (residency census on MI355X: 14 080 B admit 11 workgroups per CU, 14 336 B only 10)
   const size_t lds_alloc = (lds + 1279) / 1280 * 1280;
   // The instantiation compiled for two wavefronts per SIMD (all its registers, no scratch) whenever no more than 8 solves are
-  // resident per CU anyway: because LDS admits no more (N = 15: 5 per CU — the C5 workload: +3.4 %), or because the caller says so
-  // (fh_sched.workgroups_per_cu <= 8: a batch alone on the device is done 13 % sooner).
-  const bool two_waves = FH_WAVES_PER_SIMD > 2 && ((160 * 1024) / lds_alloc <= 8 || (ctx->sched.workgroups_per_cu > 0 && ctx->sched.workgroups_per_cu <= 8));
+  // resident per CU anyway: because LDS admits no more (N = 15: 5 per CU — the C5 workload: +3.4 %), because the batch is no larger
+  // (one vehicle's replan, SolverHip::genNewTraj: a single problem), or because the caller says so (fh_sched.workgroups_per_cu <= 8:
+  // a batch alone on the device is done 13 % sooner).
+  const bool two_waves = FH_WAVES_PER_SIMD > 2 && ((160 * 1024) / lds_alloc <= 8 || n <= 8 * ctx->n_cu ||
+                                                   (ctx->sched.workgroups_per_cu > 0 && ctx->sched.workgroups_per_cu <= 8));
   auto kern = two_waves ? fh::solve_kernel<NSEG, PAIRS, 2> : fh::solve_kernel<NSEG, PAIRS>;
   int per_cu = (int)std::min<size_t>((two_waves ? 2 : FH_WAVES_PER_SIMD) * 4, (160 * 1024) / lds_alloc);
   if (per_cu < 1) per_cu = 1;
