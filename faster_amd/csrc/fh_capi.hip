@@ -112,8 +112,9 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // resident per CU anyway: because LDS admits no more (N = 15: 5 per CU — the C5 workload: +3.4 %), because the batch is no larger
   // (one vehicle's replan, SolverHip::genNewTraj: a single problem), or because the caller says so (fh_sched.workgroups_per_cu <= 8:
   // a batch alone on the device is done 13 % sooner).
-  const bool two_waves = FH_WAVES_PER_SIMD > 2 && ((160 * 1024) / lds_alloc <= 8 || n <= 8 * ctx->n_cu ||
-                                                   (ctx->sched.workgroups_per_cu > 0 && ctx->sched.workgroups_per_cu <= 8));
+  // (fh_sched.workgroups_per_cu > 8 asks for the three-wavefront build whatever the batch: the tests run both on the same inputs)
+  const int wpc = ctx->sched.workgroups_per_cu;
+  const bool two_waves = FH_WAVES_PER_SIMD > 2 && (wpc > 0 ? wpc <= 8 : ((160 * 1024) / lds_alloc <= 8 || n <= 8 * ctx->n_cu));
   auto kern = two_waves ? fh::solve_kernel<NSEG, PAIRS, 2> : fh::solve_kernel<NSEG, PAIRS>;
   int per_cu = (int)std::min<size_t>((two_waves ? 2 : FH_WAVES_PER_SIMD) * 4, (160 * 1024) / lds_alloc);
   if (per_cu < 1) per_cu = 1;

@@ -172,8 +172,9 @@ typedef struct fh_sched {
   int32_t workgroups_per_cu;  /* resident solves per CU (0 = default: as many as LDS and registers admit, 11 for the C4 kernel).
                                * 1..8 also selects the kernel build for two wavefronts per SIMD (all registers, no scratch): a
                                * batch that is alone on the device is done 13 % sooner (C4: 3.0 instead of 3.5 ms), batches
-                               * streamed back to back 14 % later.  Same results bit for bit.  (Launches that cannot have more
-                               * than 8 solves per CU anyway — N >= 15: LDS; batches of up to 8 problems per CU — run that build.)  */
+                               * streamed back to back 14 % later.  Same results bit for bit.  With 0, launches that cannot have
+                               * more than 8 solves per CU anyway (N >= 15: LDS; batches of up to 8 problems per CU) run that build
+                               * too; a value above 8 asks for the three-wavefront build whatever the batch.                        */
   int32_t child_bound;        /* 1 (default): a child of a branch-and-bound node is not visited when a lower bound of its QP that is
                                  known at the parent — the parent's multipliers plus one multiplier on the child's most violated
                                  row: cost* + v^2 / |n|^2 — already loses against the incumbent (it holds no better leaf: the result

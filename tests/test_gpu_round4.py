@@ -372,19 +372,22 @@ def test_jump_point_search_with_heaps_far_deeper_than_lds():
 
 def test_the_two_builds_of_the_solve_kernel_give_the_same_bits():
     """fh_sched.workgroups_per_cu <= 8 selects solve_kernel<N, PAIRS, 2> — the same source compiled for two wavefronts per SIMD (all
-    registers, no scratch; a batch alone on the device is done sooner): plain batches at every instantiation of N give the same
-    result fields bit for bit as the throughput build (the fused pairs: test_results_do_not_depend_on_launch_order_or_publishing_ahead)."""
+    registers, no scratch; a batch alone on the device is done sooner; small batches run it by default): plain batches at every
+    instantiation of N give the same result fields bit for bit as the throughput build, which a value above 8 asks for (the fused
+    pairs: test_results_do_not_depend_on_launch_order_or_publishing_ahead; the oracle parity of both: tests/tools/parity_sweep.py
+    alternates between them)."""
     fields = ("solved", "status", "trials", "factor", "dt", "cost", "coeff", "assign")  # (not the work counters: who explores what may differ)
     c = capi.Context(0)
     try:
         for n_seg, pch, n in ((5, (1, 2, 3), 2048), (10, (3, 4, 5, 6), 2048), (13, (4, 5), 512), (16, (3, 4), 256)):
             pr, faces, _ = corridor.make_batch(n, n_seg, pch, True, 1000 + n_seg)
-            c.set_sched()
+            c.set_sched(workgroups_per_cu=12)  # (above 8: the three-wavefront build whatever the batch)
             ref = c.solve_batch(pr, faces)
-            c.set_sched(workgroups_per_cu=8)
-            got = c.solve_batch(pr, faces)
             assert (ref["solved"] == 1).mean() > 0.3
-            for f in fields:
-                assert np.array_equal(ref[f], got[f]), (n_seg, f)
+            for wpc in (8, 0):  # (8: the two-wavefront build; 0: the library's choice — that build again for a batch this small)
+                c.set_sched(workgroups_per_cu=wpc)
+                got = c.solve_batch(pr, faces)
+                for f in fields:
+                    assert np.array_equal(ref[f], got[f]), (n_seg, wpc, f)
     finally:
         c.close()

@@ -26,6 +26,7 @@ while done < total and time.time() - t0 < budget_s:
     if rng.random() < 0.3 and n_seg * pmax <= 40:   # tighter corridors: pull every face 0.3-0.8 m inwards (skipped for
         # many segments x many polytopes: mostly-infeasible MIQPs there need 1e4-1e5 nodes per trial — minutes of oracle time)
         faces = faces.copy(); faces["b"] -= rng.uniform(0.3, 0.8)
+    ctx.set_sched(workgroups_per_cu=12 if cfg % 2 else 8)  # (both builds of the kernel: three / two wavefronts per SIMD, alternating)
     got = ctx.solve_batch(pr, faces)
     ref = oracle.solve_batch(pr, faces)
     flags = (got["solved"] != ref["solved"]) | (got["trials"] != ref["trials"]) | (got["factor"] != ref["factor"]) | (got["dt"] != ref["dt"]) | (got["status"] != ref["status"])
