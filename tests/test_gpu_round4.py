@@ -391,3 +391,39 @@ def test_the_two_builds_of_the_solve_kernel_give_the_same_bits():
                     assert np.array_equal(ref[f], got[f]), (n_seg, wpc, f)
     finally:
         c.close()
+
+
+def test_the_two_builds_of_the_pair_kernel_give_the_same_bits():
+    """The same for the fused whole -> hand-off -> safe kernel at the instantiations the big test does not reach (N = 6: FASTER's own
+    N_whole = N_safe; N = 15: config C5): fh_sched.workgroups_per_cu 12 (three wavefronts per SIMD) against 8 (two)."""
+    import torch
+
+    fields = [n for n in abi.result_dtype.names if n not in ("nodes", "qp_iters", "kflops")]
+    dev = "cuda:0"
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev)
+    c = capi.Context(0)
+    try:
+        for N, pch, B in ((6, (2, 3), 1024), (15, (4, 5, 6), 256)):
+            whole, faces, _ = corridor.whole_batch(B, seed=500 + N, n_seg=N, p_choices=pch)
+            safe_t = corridor.safe_templates(whole)
+            mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+            d_whole, d_faces = to_dev(whole), to_dev(faces)
+            out = []
+            for wpc in (12, 8):
+                c.set_sched(workgroups_per_cu=wpc)
+                c.set_pair_margin(0.05)
+                d_safe, d_sf = to_dev(safe_t), torch.zeros_like(d_faces)
+                d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device=dev)
+                d_sr = torch.zeros_like(d_wr)
+                c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(),
+                                     d_sf.data_ptr(), d_sr.data_ptr())
+                c.sync()
+                out.append((d_wr.cpu().numpy().view(abi.result_dtype).copy(), d_sr.cpu().numpy().view(abi.result_dtype).copy(),
+                            d_safe.cpu().numpy().copy(), d_sf.cpu().numpy().copy()))
+            assert (out[0][0]["solved"] == 1).mean() > 0.5 and (out[0][1]["solved"] == 1).mean() > 0.3
+            for k in (0, 1):
+                for f in fields:
+                    assert np.array_equal(out[0][k][f], out[1][k][f]), (N, k, f)
+            assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3]), N  # the safe problems and their faces
+    finally:
+        c.close()
