@@ -299,7 +299,7 @@ void fh_default_sched(fh_sched* s) {
 
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s) {
   if (!ctx || !s) return FH_ERR_ARG;
-  if (s->publish_factor < 0 || s->backlog < 0 || s->backlog > 512 || s->waiting_workgroups < 0 || s->min_nodes < 0) return FH_ERR_ARG;
+  if (s->publish_factor < 0 || s->backlog < 0 || s->backlog > 512 || s->waiting_workgroups < 0 || s->min_nodes < 0 || s->workgroups_per_cu < 0) return FH_ERR_ARG;
   ctx->sched = *s;
   return FH_OK;
 }
