@@ -1,6 +1,6 @@
 """Per-phase cycle breakdown of fh::solve_kernel (diagnostic build with -DFH_PROFILE; not part of the product).
    FASTERHIP_EXTRA_FLAGS=-DFH_PROFILE python -c "from faster_amd import build; build.build_device(force=True)"   (or an -o elsewhere + FASTERHIP_SO)
-   python scripts/phase_profile.py [pairs] [plain|pairs]
+   python scripts/phase_profile.py [pairs] [plain|pairs] [workgroups_per_cu: 0 the library's choice, 8 the two-wavefront build]
 The C4 batch of bench.py (seed 3) through the fused pair kernel (default) or the whole problems alone; every problem record of the
 launch carries its own cycle counters in the unused coefficient rows 12..15 (N <= 12)."""
 import os, sys
@@ -17,6 +17,8 @@ names = ["staging (record, faces, LDS init)", "setup_trial", "states+CP", "scan"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 mode = sys.argv[2] if len(sys.argv) > 2 else "pairs"
 ctx = capi.Context(0)
+if len(sys.argv) > 3 and int(sys.argv[3]):
+    ctx.set_sched(workgroups_per_cu=int(sys.argv[3]))
 whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=10, p_choices=(2, 3, 4, 5, 6))
 
 
