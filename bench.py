@@ -18,7 +18,8 @@ Usage (driver contract):  python bench.py --gpus N --steps K --warmup W
 N>1 is launched by torch.distributed.run (one rank per GPU).  Prints ONE JSON line on rank 0.
 
 Besides the timed region (K steps, `--inflight` independent pipelines) the N=1 run measures, outside the timed region:
-a single batch alone on the GPU (`roofline.solo`: no overlap between launches), the PCIe-inclusive host-pointer path
+a single batch alone on the GPU (`roofline.solo`: no overlap between launches; `roofline.solo_two_wavefronts_per_simd`: the same with
+the kernel build a caller who waits for one batch selects, fh_sched.workgroups_per_cu <= 8), the PCIe-inclusive host-pointer path
 (`e2e_with_copies`), the FP64 flop rate against the measured FP64 FMA peak (`roofline.compute`) and the CPU baseline.
 """
 import argparse
