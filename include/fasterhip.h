@@ -452,7 +452,7 @@ int fh_map_set_sched(fh_map* map, int waves_per_cu, int launch_order);
  * Switching re-initialises the search workspace. */
 int fh_map_set_search(fh_map* map, int mode);
 /* How the jump point search (mode 1) keeps its per-cell records (g, parent, direction, closed) — jps3d's hm_ / seen_
- * (graph_search.h:150-155: one entry per cell of the map, allocated per query).  slots = 0: one 16-byte record per cell of
+ * (graph_search.h:258-259, sized by the map in the constructor, graph_search.cpp:25-26: one entry per cell of the map, allocated per query).  slots = 0: one 16-byte record per cell of
  * the map and wavefront, stamped with the query's serial number instead of being cleared.  slots = a power of two in [1024, 2^22]:
  * a hashed table of that many records per wavefront (39 bytes per slot with the heap levels that go with it, whatever the size of
  * the map), holding the cells the running query has reached; a query that reaches more than 3/4 of `slots` cells returns
