@@ -18,6 +18,7 @@
 #ifndef FASTERHIP_H
 #define FASTERHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -34,6 +34,18 @@ def test_header_declares_the_entry_points():
         assert n in names
 
 
+def test_header_compiles_on_its_own_as_c_and_cxx():
+    """include/fasterhip.h is the drop-in boundary: a C99 or C++11 translation unit that includes nothing else must compile
+    (a cgo / JNI / ctypes-generator consumer sees exactly this file)."""
+    import subprocess
+
+    hdr = os.path.join(ROOT, "include", "fasterhip.h")
+    for cmd in (["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-pedantic", hdr],
+                ["g++", "-fsyntax-only", "-x", "c++", "-std=c++11", "-Wall", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0 and not r.stderr.strip(), (cmd, r.stderr[-2000:])
+
+
 def test_library_exports_every_declared_symbol(built):
     from faster_amd import capi
 
