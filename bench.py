@@ -47,22 +47,23 @@ def algorithmic_bytes(problems, n_seg_out):
     return reads + writes
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected
-    in separate runs by scripts/profile_round.sh, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes)."""
-    import glob
+ROUND = "r05"   # the round whose profiles/ this bench line may quote (never an older round's counters for a newer kernel)
 
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))):
-        try:
-            d = json.load(open(f))
-            t = d.get("_hbm_traffic_per_launch_bytes")
-            k = d.get("_kernel", "")
-        except Exception:
-            t = None
-        if t and (not k or k.startswith(kernel_prefix)):
-            best = (t["total"], os.path.basename(f))
-    return best
+
+def measured_traffic(kernel_name):
+    """HBM bytes per launch of the solve kernel from THIS round's committed rocprofv3 PMC passes (profiles/<ROUND>_pmc_summary.json:
+    FETCH_SIZE / WRITE_SIZE collected in separate runs by scripts/profile_round.sh, corrected as /opt/skills/guides/MI355X_MICROARCH.md
+    §HBM prescribes) — only if that file is about exactly the kernel instantiation that ran (fh_last_launch); otherwise None."""
+    f = os.path.join(ROOT, "profiles", ROUND + "_pmc_summary.json")
+    try:
+        d = json.load(open(f))
+        t = d.get("_hbm_traffic_per_launch_bytes")
+        k = d.get("_kernel", "")
+    except Exception:
+        return None
+    if t and k == kernel_name:
+        return (t["total"], os.path.basename(f))
+    return None
 
 
 def host_cores():
@@ -389,7 +390,7 @@ def main():
 
     if rank == 0:
         fused = args.pipeline == "fused"
-        kname = "fh::solve_kernel<%d, %s>" % (6 if N <= 6 else (10 if N <= 10 else (15 if N <= 15 else 16)), "true" if fused else "false")
+        launch_info, kname = last.ctx.last_launch()   # the instantiation and build that really ran, as rocprofv3 names it
         pairs_total = (total_pairs if strong else world * B) * args.steps
         value = pairs_total / elapsed
         bytes_whole = algorithmic_bytes(whole, N)
@@ -450,6 +451,8 @@ def main():
                 "frac": achieved / (HBM_PEAK / 1e9),
                 "traffic": traffic[0],
                 "traffic_source": traffic[1],
+                "wasted_x": (traffic[0] / bytes_per_launch) if traffic[0] else None,
+                "launch": launch_info,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": int(len(kernel_ms)),
@@ -952,13 +955,19 @@ def cpu_baseline(whole, faces, safe, sfaces, target_s):
     orc.build()
     cores = max(1, min(host_cores(), orc.max_threads()))
 
+    work = {}
+
     def run(k, threads):
         t = time.perf_counter()
-        orc.solve_batch(whole[:k], faces, threads=threads)
+        w = orc.solve_batch(whole[:k], faces, threads=threads)
         act = safe[:k][safe[:k]["n_seg"] > 0]
+        it, nd, tr = float(w["qp_iters"].sum()), float(w["nodes"].sum()), float(w["trials"].sum())
         if len(act):
-            orc.solve_batch(act, sfaces, threads=threads)
-        return time.perf_counter() - t
+            r = orc.solve_batch(act, sfaces, threads=threads)
+            it, nd, tr = it + float(r["qp_iters"].sum()), nd + float(r["nodes"].sum()), tr + float(r["trials"].sum())
+        dt = time.perf_counter() - t
+        work.update(mean_qp_iters_per_pair=it / k, mean_bnb_nodes_per_pair=nd / k, mean_trials_per_pair=tr / k)
+        return dt
 
     k1 = min(512, len(whole))
     t1 = run(k1, 1)                       # single thread
@@ -975,7 +984,10 @@ def cpu_baseline(whole, faces, safe, sfaces, target_s):
                       "over problems on %d threads (os.sched_getaffinity / cgroup quota; os.cpu_count() = %d); NOT Gurobi (absent)"
                       % (passes, k, cores, os.cpu_count() or 0),
             "seconds": spent, "single_thread_value": k1 / t1, "single_thread_sample": "%d pairs" % k1,
-            "eight_thread_value": k8 / t8, "scaling_vs_one_thread": (passes * k / spent) / (k1 / t1)}
+            "eight_thread_value": k8 / t8, "scaling_vs_one_thread": (passes * k / spent) / (k1 / t1),
+            # what the port DOES per pair (full jerk space, cold-started nodes, no box bound, no child bound): the GPU/CPU ratio mixes
+            # algorithm and hardware — compare with config.mean_qp_iters_per_pair of the device
+            **work}
 
 
 if __name__ == "__main__":

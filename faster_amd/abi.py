@@ -70,8 +70,11 @@ assert params_dtype.itemsize == 48
 
 
 sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("backlog", "<i4"), ("waiting_workgroups", "<i4"),
-                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("child_bound", "<i4")])
+                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("no_child_bound", "<i4")])
 assert sched_dtype.itemsize == 32
+
+launch_info_dtype = np.dtype([("n_seg", "<i4"), ("pairs", "<i4"), ("waves_per_simd", "<i4"), ("grid", "<i4"), ("workgroups_per_cu", "<i4"),
+                              ("lds_bytes", "<i4")])
 
 
 voxel_grid_dtype = np.dtype([("origin", "<f8", (3,)), ("res", "<f8"), ("dims", "<i4", (3,)), ("reserved", "<i4")])
@@ -85,7 +88,7 @@ assert pair_rule_dtype.itemsize == 40
 
 def default_sched():
     s = np.zeros((), dtype=sched_dtype)
-    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"], s["child_bound"] = 1, 4, 32, 2, 1, 1
+    s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"], s["no_child_bound"] = 1, 4, 32, 2, 1, 0
     return s
 
 

@@ -22,8 +22,8 @@ SYMBOLS = [
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
     "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_set_records", "fh_map_workspace_bytes", "fh_map_set_sphere", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
-    "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_version",
-    "fh_packed_result_size", "fh_pack_results_device", "fh_pack_results", "fh_unpack_results",
+    "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_last_launch", "fh_version",
+    "fh_packed_result_size", "fh_pack_results_device", "fh_pack_results", "fh_unpack_results", "fh_control_points",
 ]
 
 _LIB = None
@@ -35,6 +35,17 @@ class FasterHipError(RuntimeError):
 
 def packed_result_size(n_seg):
     return int(lib().fh_packed_result_size(int(n_seg)))
+
+
+def control_points(results, n_seg):
+    """fh_control_points: getCP0..3 of every segment of every result -> [n][n_seg][4][3] (zero rows for unsolved results)."""
+    results = np.ascontiguousarray(results)
+    assert results.dtype == abi.result_dtype
+    cp = np.zeros((results.shape[0], int(n_seg), 4, 3), dtype=np.float64)
+    rc = lib().fh_control_points(abi.ptr(results), results.shape[0], int(n_seg), abi.ptr(cp))
+    if rc != 0:
+        raise FasterHipError("fh_control_points: rc=%d" % rc)
+    return cp
 
 
 def pack_results(results, n_seg):
@@ -202,6 +213,8 @@ def lib():
         L.fh_timing_read.argtypes = [vp, vp, i32]
         L.fh_last_kernel_ms.restype = f64
         L.fh_last_kernel_ms.argtypes = [vp]
+        L.fh_last_launch.restype = i32
+        L.fh_last_launch.argtypes = [vp, vp]
         L.fh_version.restype = ctypes.c_char_p
         _LIB = L
     return _LIB
@@ -405,7 +418,10 @@ class Context:
         workgroups_per_cu in 1..8 also selects the kernel build for two wavefronts per SIMD (a batch alone on the device is done sooner)."""
         s = abi.default_sched()
         for k, v in kw.items():
-            s[k] = v
+            if k == "child_bound":   # the field is fh_sched.no_child_bound (0 = default: the bound is on)
+                s["no_child_bound"] = 0 if v else 1
+            else:
+                s[k] = v
         s = np.ascontiguousarray(s).reshape(1)
         self._check(lib().fh_set_sched(self._h, abi.ptr(s)), "fh_set_sched")
 
@@ -475,6 +491,13 @@ class Context:
 
     def last_kernel_ms(self):
         return lib().fh_last_kernel_ms(self._h)
+
+    def last_launch(self):
+        """fh_last_launch: which solve kernel the most recent solve launch ran — (dict of the fields, the name as rocprofv3 prints it)."""
+        info = np.zeros(1, dtype=abi.launch_info_dtype)
+        self._check(lib().fh_last_launch(self._h, abi.ptr(info)), "fh_last_launch")
+        d = {k: int(info[0][k]) for k in info.dtype.names}
+        return d, "fh::solve_kernel<%d, %s, %d>" % (d["n_seg"], "true" if d["pairs"] else "false", d["waves_per_simd"])
 
     # ---- host-pointer entry points (numpy in, numpy out) ----
     def solve_batch(self, problems, faces):

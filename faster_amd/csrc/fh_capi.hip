@@ -49,6 +49,7 @@ struct fh_ctx {
   bool ctl_ready = false;                   // the device-side control block is in its initial state (left so by the previous launch)
   bool launched = false;                    // a solve launch has been issued since the control block was last checked
   int last_grid = 0;
+  fh_launch_info last_launch = {0, 0, 0, 0, 0, 0};  // fh_last_launch
   bool order_ready = false;                 // the launch-order counters are zero (left so by the previous scatter kernel)
 };
 
@@ -126,9 +127,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     lds_launch = std::max(lds, (size_t)(160 * 1024) / (size_t)per_cu / 1280 * 1280 - 16);
   }
   const int resident = ctx->n_cu * per_cu;
+  ctx->last_launch = {NSEG, PAIRS ? 1 : 0, two_waves ? 2 : FH_WAVES_PER_SIMD, 0, per_cu, (int32_t)lds_launch};
   const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;
   // small batches get helper workgroups (one per CU) that take over subtrees of hard problems
   const int grid = share ? std::min(resident, std::max(n, ctx->n_cu)) : std::min(resident, n);
+  ctx->last_launch.grid = grid;
   int rc;
   if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * SV::SNAP_PADDED)) != FH_OK) return rc;
   const size_t slot_stride = sizeof(fh::TaskHdr) + sizeof(double) * (size_t)SV::SNAP_PADDED;
@@ -160,7 +163,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   sa.backlog = ctx->sched.backlog;
   sa.giant_nodes = 1 << 30;
   sa.giant_factor = ctx->sched.publish_factor;
-  sa.child_bound = ctx->sched.child_bound ? 1 : 0;
+  sa.child_bound = ctx->sched.no_child_bound ? 0 : 1;
   ka.par = ctx->par;
   ka.workspace = (double*)ctx->d_buf[5];
   ka.basis = (const double*)ctx->d_buf[15];
@@ -283,7 +286,30 @@ int fh_unpack_results(const void* packed, int n, int n_seg, fh_result* results) 
   return FH_OK;
 }
 
-const char* fh_version(void) { return "fasterhip 0.2 gfx950"; }
+int fh_control_points(const fh_result* results, int n, int n_seg, double* cp) {
+  if (n < 0 || n_seg < 1 || n_seg > FH_MAX_SEG || (n > 0 && (!results || !cp))) return FH_ERR_ARG;
+  for (int i = 0; i < n; i++) {
+    const fh_result& r = results[i];
+    double* o = cp + (size_t)i * n_seg * 12;
+    if (!r.solved) {
+      std::memset(o, 0, sizeof(double) * (size_t)n_seg * 12);
+      continue;
+    }
+    const double dt = r.dt;
+    for (int t = 0; t < n_seg; t++, o += 12)
+      for (int ax = 0; ax < 3; ax++) {
+        const double a = r.coeff[t][0 + ax], b = r.coeff[t][3 + ax], c = r.coeff[t][6 + ax], d = r.coeff[t][9 + ax];
+        const double Bn = b * dt * dt, Cn = c * dt, Dn = d;             // getBn / getCn / getDn
+        o[0 + ax] = a * 0.0 * 0.0 * 0.0 + b * 0.0 * 0.0 + c * 0.0 + d;  // getCP0 = getPos(t, 0)
+        o[3 + ax] = (Cn + 3 * Dn) / 3;                                  // getCP1
+        o[6 + ax] = (Bn + 2 * Cn + 3 * Dn) / 3;                         // getCP2
+        o[9 + ax] = a * dt * dt * dt + b * dt * dt + c * dt + d;        // getCP3 = getPos(t, dt)
+      }
+  }
+  return FH_OK;
+}
+
+const char* fh_version(void) { return "fasterhip 0.3 gfx950"; }
 
 void fh_default_sched(fh_sched* s) {
   if (!s) return;
@@ -293,7 +319,7 @@ void fh_default_sched(fh_sched* s) {
   s->backlog = 32;
   s->waiting_workgroups = 0;
   s->min_nodes = 2;
-  s->child_bound = 1;
+  s->no_child_bound = 0;
   s->cloud_blocks = 1;
 }
 
@@ -799,6 +825,12 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   if (max_seg <= 10) return launch_solve<10, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   if (max_seg <= 15) return launch_solve<15, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   return launch_solve<FH_MAX_SEG, true>(ctx, d_whole, d_faces, d_whole_results, ka);
+}
+
+int fh_last_launch(const fh_ctx* ctx, fh_launch_info* out) {
+  if (!ctx || !out || ctx->last_launch.n_seg == 0) return FH_ERR_ARG;
+  *out = ctx->last_launch;
+  return FH_OK;
 }
 
 int fh_timing_reset(fh_ctx* ctx) {

@@ -15,7 +15,7 @@
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FH_CLOCK_FN __host__ __device__ inline
 #else
 #define FH_CLOCK_FN inline

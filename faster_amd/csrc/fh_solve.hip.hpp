@@ -7,7 +7,7 @@
 //
 // Mapping to the machine
 //   * one problem (= one genNewTraj call) per 64-lane wavefront, one wavefront per workgroup; the grid is what is
-//     resident at once (up to 12 workgroups per CU: LDS limited — fh_capi.hip computes it from the carve —, 3 wavefronts per SIMD by VGPRs) and every workgroup pulls problems from a
+//     resident at once (12 workgroups per CU at N <= 6, 11 at N = 10, 5 at N = 15: LDS limited — fh_capi.hip computes it from the carve —, 3 wavefronts per SIMD by VGPRs) and every workgroup pulls problems from a
 //     device-scope ticket counter, so problems of different difficulty balance across the 256 CUs;
 //   * control flow is wave-uniform: the whole search (factor loop -> branch and bound -> dual active set) is a
 //     scalar program; the 64 lanes are the data-parallel axis inside every step (rows of the constraint scan,
@@ -2120,7 +2120,9 @@ struct Solver {
                 for (int k2 = 0; k2 < 4; k2++) b4 = fmax(b4, readlane_f64(bnd, 4 * p2 + k2));
                 bmax = (lane == p2) ? b4 : bmax;
               }
-              const double lbv = cost + bmax * (1.0 - 1e-9);
+              // slack: 1e-9 of the increment (the rounding of the scaled violation) and 1e-12 of the bound itself — the leaf costs it is
+              // compared with carry rounding noise relative to THEIR size, which the first term does not cover when bmax << cost
+              const double lbv = (cost + bmax * (1.0 - 1e-9)) * (1.0 - 1e-12);
               if (cand) {
                 if (depth < TC) tbnd[depth * FH_MAX_POLY + rank] = lbv;
                 else ws[(size_t)depth * SNAP_PADDED + SNAP_BOUNDS + rank] = lbv;

@@ -12,7 +12,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FH_UDIV_FN __host__ __device__ inline
 #else
 #define FH_UDIV_FN inline

@@ -157,6 +157,15 @@ int fh_pack_results_device(fh_ctx* ctx, const fh_result* d_results, int n, int n
 int fh_pack_results(const fh_result* results, int n, int n_seg, void* packed);
 int fh_unpack_results(const void* packed, int n, int n_seg, fh_result* results);
 
+/* The Bezier control points of every segment of every result: SolverGurobi::getCP0..getCP3 (solverGurobi.cpp:833-862) evaluated on
+ * the result's coefficients with the reference's own expressions and operation order — cp0 = getPos(t, 0), cp1 = (Cn + 3 Dn) / 3,
+ * cp2 = (Bn + 2 Cn + 3 Dn) / 3, cp3 = getPos(t, dt), with the normalised coefficients An = a dt^3, Bn = b dt^2, Cn = c dt, Dn = d
+ * (:810-830) and getPos = a tau tau tau + b tau tau + c tau + d (:761-767).  These are the points the indicator rows of
+ * setPolytopesConstraints constrain (:254-288) — with cost and the feasibility flag, the outputs BASELINE names.
+ * cp: [n][n_seg][4][3] doubles (control point, axis); rows of unsolved results are zero.  Host side, no device needed (a format
+ * conversion of fh_result like fh_unpack_results, not a solver). */
+int fh_control_points(const fh_result* results, int n, int n_seg, double* cp);
+
 
 /* Scheduling of a solve launch: how the persistent workgroups order and share the work of a batch.  NO RESULT FIELD DEPENDS ON
  * ANY OF THESE (tests/test_gpu_round2.py solves 8192 pairs with each of them switched off and compares bit for bit); only
@@ -176,10 +185,13 @@ typedef struct fh_sched {
                                * streamed back to back 14 % later.  Same results bit for bit.  With 0, launches that cannot have
                                * more than 8 solves per CU anyway (N >= 15: LDS; batches of up to 8 problems per CU) run that build
                                * too; a value above 8 asks for the three-wavefront build whatever the batch.                        */
-  int32_t child_bound;        /* 1 (default): a child of a branch-and-bound node is not visited when a lower bound of its QP that is
-                                 known at the parent — the parent's multipliers plus one multiplier on the child's most violated
-                                 row: cost* + v^2 / |n|^2 — already loses against the incumbent (it holds no better leaf: the result
-                                 is unchanged, the trees are half as large).  0: every child is visited, the tree of the CPU oracle   */
+  int32_t no_child_bound;     /* 0 (default — also what a zero-initialised fh_sched asks for): a child of a branch-and-bound node is not
+                                 visited when a lower bound of its QP that is known at the parent — the parent's multipliers plus one
+                                 multiplier on the child's most violated row: cost* + v^2 / |n|^2 — already loses against the incumbent
+                                 (it holds no better leaf: the result is unchanged up to ties of two leaves' costs below 1e-12 relative,
+                                 the trees are half as large).  1: every child is visited, the tree of the CPU oracle.
+                                 (Round 4 called this field child_bound with 1 = default; inverted so that a caller who fills a
+                                 zero-initialised struct by hand keeps the default behaviour.)                                        */
 } fh_sched;
 void fh_default_sched(fh_sched* s);
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s);
@@ -489,6 +501,16 @@ int fh_map_plan_batch_device(fh_map* map, const double* d_starts, const double* 
 int fh_timing_reset(fh_ctx* ctx);
 int fh_timing_read(fh_ctx* ctx, double* ms, int cap);
 double fh_last_kernel_ms(fh_ctx* ctx);
+
+/* Which solve kernel the most recent solve launch of the context ran, as the profiler names it:
+ * fh::solve_kernel<n_seg, pairs, waves_per_simd> — the instantiation (6 / 10 / 15 / 16 segments), the fused pair form, and the build
+ * (3 = three wavefronts per SIMD, 168 registers; 2 = two, all registers: fh_sched.workgroups_per_cu) — with its grid, the resident
+ * solves per CU and the LDS bytes per workgroup.  Measurement only (bench.py matches its rocprofv3 summaries by this name);
+ * returns FH_ERR_ARG before the first launch. */
+typedef struct fh_launch_info {
+  int32_t n_seg, pairs, waves_per_simd, grid, workgroups_per_cu, lds_bytes;
+} fh_launch_info;
+int fh_last_launch(const fh_ctx* ctx, fh_launch_info* out);
 
 /* library / build identification, e.g. "fasterhip 0.1 gfx950" */
 const char* fh_version(void);

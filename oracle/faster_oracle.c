@@ -949,6 +949,33 @@ long orc_bruteforce_dt(const fh_problem* pr, const fh_face* faces, const fh_para
   return feasible;
 }
 
+/* The Bezier control points of a result, by the ORACLE's route (the jerk-space form it builds its rows from, cp_weights above):
+ * with P = d, V = c, A = 2b, j = 6a at the start of a segment of length h = dt,
+ *   cp0 = P, cp1 = P + V h/3, cp2 = P + 2 V h/3 + A h^2/6, cp3 = P + V h + A h^2/2 + j h^3/6
+ * — algebraically getCP0..3 (solverGurobi.cpp:833-862), evaluated otherwise than the reference's literal expressions, which the
+ * product's fh_control_points follows.  cp: [n_seg][4][3]; zero if the result is unsolved. */
+static void control_points_one(const fh_result* res, int n_seg, double* cp) {
+  memset(cp, 0, sizeof(double) * (size_t)n_seg * 12);
+  if (!res->solved) return;
+  const double h = res->dt;
+  for (int t = 0; t < n_seg; t++)
+    for (int i = 0; i < 3; i++) {
+      const double P = res->coeff[t][9 + i], V = res->coeff[t][6 + i], A = 2.0 * res->coeff[t][3 + i], j = 6.0 * res->coeff[t][0 + i];
+      double* o = cp + (size_t)t * 12;
+      for (int k = 0; k < 3; k++) {
+        double wp, wv, wa;
+        int next;
+        cp_weights(h, k, &wp, &wv, &wa, &next);
+        o[3 * k + i] = wp * P + wv * V + wa * A;
+      }
+      o[9 + i] = P + V * h + 0.5 * A * h * h + j * h * h * h / 6.0;
+    }
+}
+
+void orc_control_points(const fh_result* res, int n, int n_seg, double* cp) {
+  for (int i = 0; i < n; i++) control_points_one(res + i, n_seg, cp + (size_t)i * n_seg * 12);
+}
+
 void orc_default_params(fh_params* p) {
   p->feas_tol = 1e-9;
   p->dep_tol = 1e-10;

@@ -44,6 +44,7 @@ def lib():
         L.orc_bruteforce_dt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
         L.orc_sample.restype = ctypes.c_int
         L.orc_sample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_control_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.orc_sizeof_problem.restype = ctypes.c_size_t
         L.orc_sizeof_result.restype = ctypes.c_size_t
         _LIB = L
@@ -107,6 +108,14 @@ def bruteforce_dt(problem, faces, dt, params=None):
     par = _params(params)
     nfeas = lib().orc_bruteforce_dt(abi.ptr(pr), abi.ptr(np.ascontiguousarray(faces)), abi.ptr(par.reshape(1)), dt, abi.ptr(res))
     return nfeas, res[0]
+
+
+def control_points(results, n_seg):
+    """orc_control_points: the Bezier control points of every result by the oracle's jerk-space route -> [n][n_seg][4][3]."""
+    rs = np.ascontiguousarray(results)
+    cp = np.zeros((rs.shape[0], int(n_seg), 4, 3), dtype=np.float64)
+    lib().orc_control_points(abi.ptr(rs), rs.shape[0], int(n_seg), abi.ptr(cp))
+    return cp
 
 
 def sample(problem, result, max_samples=None):

@@ -211,113 +211,6 @@ def test_pool_shards_equal_one_way(ctx):
     pool1.close()
 
 
-def hard_problems(n=64, seed=77):
-    """Dense N=15 / P=8 corridors pulled 0.76 m inwards with 19 factor trials: mostly infeasible.  Most are rejected at once; a
-    few need 1e4-1e5 branch-and-bound nodes per trial (exact enumeration without an incumbent): the batch (64, seed 77) holds
-    one with 2.5e5 nodes in total."""
-    pr, faces, _ = corridor.whole_batch(n, seed=seed, n_seg=15, p_choices=(8,), f_inc=0.5)
-    faces = faces.copy()
-    faces["b"] -= 0.76
-    return pr, faces
-
-
-def test_stop_request_from_another_thread():
-    """a12: SolverGurobi::StopExecution() is meant to be called from another thread while m.optimize() runs (solverGurobi.cpp:15-39).
-    fh_request_stop() raises a word in mapped host memory; the workgroups poll it between branch-and-bound nodes."""
-    import torch  # noqa: F401
-
-    c = capi.Context(0)
-    pr, faces = hard_problems(n=64)       # contains a problem with 2.5e5 nodes: 3.8 s with work sharing, 38 s on one wavefront
-    out = {}
-
-    def run():
-        t = time.perf_counter()
-        out["res"] = c.solve_batch(pr, faces)
-        out["t_end"] = time.perf_counter()
-        out["dur"] = out["t_end"] - t
-
-    th = threading.Thread(target=run)
-    th.start()
-    time.sleep(0.25)                      # the launch is well under way
-    assert th.is_alive(), "the hard batch finished before it could be cancelled: make it harder"
-    t_stop = time.perf_counter()
-    c.request_stop()
-    th.join(timeout=30)
-    assert not th.is_alive()
-    latency = out["t_end"] - t_stop
-    res = out["res"]
-    assert (res["status"] == abi.FH_ST_INTERRUPTED).sum() >= 1 and np.all(res["solved"][res["status"] == abi.FH_ST_INTERRUPTED] == 0)
-    print("stop latency %.3f ms (launch had run %.0f ms)" % (1e3 * latency, 1e3 * (out["dur"] - latency)))
-    assert latency < 0.02, latency        # measured ~1 ms: poll every 2-4 nodes + D2H of the results
-    # the request stays raised: the next launch returns at once — problems that a workgroup had drawn before the word was seen
-    # (one workgroup in 32 polls it) still finish if they take no time, the expensive ones are interrupted ...
-    t = time.perf_counter()
-    again = c.solve_batch(pr, faces)
-    assert time.perf_counter() - t < 0.05
-    assert (again["status"] == abi.FH_ST_INTERRUPTED).sum() >= 8 and again["status"][np.argmax(res["nodes"])] == abi.FH_ST_INTERRUPTED
-    assert np.all(again["nodes"][again["status"] != abi.FH_ST_INTERRUPTED] < 64)
-    # ... until it is cleared (ResetToNormalState)
-    c.clear_stop()
-    easy, efaces, _ = corridor.whole_batch(64, seed=5)
-    r = c.solve_batch(easy, efaces)
-    assert r["solved"].sum() > 50 and not np.any(r["status"] == abi.FH_ST_INTERRUPTED)
-    c.close()
-
-
-def test_deadline():
-    """fh_params.deadline_ms: a wall-clock budget for a launch (the reference's replan period is 10 ms, faster.yaml:5)."""
-    import torch  # noqa: F401
-
-    c = capi.Context(0)
-    par = abi.default_params()
-    par["deadline_ms"] = 10.0
-    c.set_params(par)
-    pr, faces = hard_problems(n=64)
-    easy, efaces, _ = corridor.whole_batch(256, seed=6)
-    allpr, allfaces = corridor.concat([(easy, efaces), (pr, faces)])
-    c.solve_batch(easy, efaces)           # (first launch: allocations)
-    t = time.perf_counter()
-    res = c.solve_batch(allpr, allfaces)
-    dur = time.perf_counter() - t
-    assert dur < 0.05, dur                # 10 ms budget + copies, not the seconds the hard problems would take
-    assert res["solved"][:256].sum() > 200                       # the easy ones were done long before the deadline
-    assert (res["status"][256:] == abi.FH_ST_INTERRUPTED).sum() >= 1
-    par["deadline_ms"] = 0.0
-    c.set_params(par)
-    r = c.solve_batch(easy, efaces)
-    assert not np.any(r["status"] == abi.FH_ST_INTERRUPTED)
-    c.close()
-
-
-def test_solver_hip_stop_execution_from_another_thread(tmp_path):
-    """The same through the C++ class: SolverHip::StopExecution() from another thread during genNewTraj() (tests/cpp/test_stop.cpp)."""
-    from faster_amd import build as fb
-
-    fb.build_all()
-    exe = os.path.join(ROOT, "tests", "cpp", "test_stop")
-    src = exe + ".cpp"
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(fb.HOST_SO)):
-        subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "faster_amd", "host"), src,
-                               "-o", exe, "-L", os.path.join(ROOT, "faster_amd"), "-lsolverhip", "-lfasterhip", "-Wl,-rpath," + os.path.join(ROOT, "faster_amd")])
-    pr, faces = hard_problems(n=64)
-    probe = capi.Context(0)
-    hardest = int(np.argmax(probe.solve_batch(pr, faces)["nodes"]))   # (the 2.5e5-node problem: seconds even with 256 helpers)
-    probe.close()
-    p = pr[hardest]
-    lines = ["15 0.01 5 5 8 0.5", " ".join(repr(float(v)) for v in p["x0"]), " ".join(repr(float(v)) for v in p["xf"][:3]), str(int(p["n_poly"]))]
-    for k in range(int(p["n_poly"])):
-        f0, f1 = p["face_begin"] + p["face_off"][k], p["face_begin"] + p["face_off"][k + 1]
-        lines.append(str(f1 - f0))
-        for f in range(f0, f1):
-            lines.append("%r %r %r %r" % (float(faces["a"][f][0]), float(faces["a"][f][1]), float(faces["a"][f][2]), float(faces["b"][f])))
-    sc = tmp_path / "hard.txt"
-    sc.write_text("\n".join(lines) + "\n")
-    r = subprocess.run([exe, str(sc)], capture_output=True, text=True, timeout=180)
-    print(r.stdout[-600:])
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    assert "STOP_OK" in r.stdout
-
-
 # ---- voxel map + batched path search on the device (fh_map_*), SURVEY.md 8(f) N1 first half -------------------------------------
 
 def _compare_plans(host, dev, refined=False):

@@ -110,3 +110,27 @@ def test_fixture_first_feasible_factor_against_highs(oracle, fixture_corridor, k
     args = (c["x0"], c["xf"], *c["vaj"], True, polys)
     assert py_model.milp_feasible(c["N"], 2 * dti, *args) is False
     assert py_model.milp_feasible(c["N"], 3 * dti, *args) is True
+
+
+def test_control_points_two_routes_agree(oracle, fixture_corridor, known_answers):
+    """getCP0..3 (solverGurobi.cpp:833-862): the product's host conversion fh_control_points (the reference's literal expressions) and
+    the oracle's jerk-space route give the same points on the known answers, and every point lies in its segment's polytope."""
+    from faster_amd import capi
+
+    batches = []
+    for name in ("KA-1", "KA-2", "KA-3", "KA-4"):
+        c = known_answers["cases"][name]
+        batches.append(corridor.fixture_problem(fixture_corridor, c["N"], c["vaj"], c["force_final"], c["polys"], c["x0"], c["xf"]))
+    for (pr, faces) in batches:
+        res = oracle.solve_batch(pr, faces)
+        assert res["solved"][0] == 1
+        N = int(pr[0]["n_seg"])
+        a, b = capi.control_points(res, N), oracle.control_points(res, N)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(a[0, 0, 0], pr[0]["x0"][:3])          # cp0 of the first segment is the start
+        for t in range(N):
+            q = int(res["assign"][0][t])
+            f0, f1 = pr[0]["face_begin"] + pr[0]["face_off"][q], pr[0]["face_begin"] + pr[0]["face_off"][q + 1]
+            assert np.max(faces["a"][f0:f1] @ a[0, t].T - faces["b"][f0:f1, None]) <= 1e-6
+        if N > 1:
+            np.testing.assert_allclose(a[0, :-1, 3], a[0, 1:, 0], rtol=0, atol=1e-9)   # C0: cp3 of a segment is cp0 of the next
