@@ -182,6 +182,39 @@ def test_independent_model_on_64_gpu_results_at_n10(ctx):
     assert done == 64
 
 
+def test_independent_model_on_gpu_results_at_n15_and_on_safe_problems(ctx):
+    """The same independent check (SciPy SLSQP on the unreduced 12N-coefficient model, oracle/py_model.py) where the first one does not
+    reach: 12 solved N = 15 problems with up to 8 polytopes (the C5 kernel instantiation) and 32 solved SAFE problems (no final position
+    row, solverGurobi.cpp:343-356 with forceFinalConstraint_ false; x0 = the R the device's hand-off chose) of fused C4 pairs."""
+    from oracle import py_model
+
+    def polys_of(p, faces):
+        fb = int(p["face_begin"])
+        return [(faces["a"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy(), faces["b"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy())
+                for q in range(int(p["n_poly"]))]
+
+    def check(p, faces, r, n_seg, force):
+        s = py_model.solve_fixed(n_seg, float(r["dt"]), p["x0"], p["xf"], float(p["v_max"]), float(p["a_max"]), float(p["j_max"]), force, polys_of(p, faces),
+                                 [int(a) for a in r["assign"][:n_seg]])
+        assert s is not None
+        assert s[0] == pytest.approx(r["cost"], rel=1e-6, abs=1e-7), (s[0], r["cost"])
+        np.testing.assert_allclose(s[1], r["coeff"][:n_seg], atol=1e-5)
+
+    pr, faces, _ = corridor.whole_batch(32, seed=402, n_seg=15, p_choices=(4, 5, 6, 7, 8))
+    res = ctx.solve_batch(pr, faces)
+    big = np.nonzero(res["solved"])[0][:12]
+    assert len(big) == 12
+    for i in big:
+        check(pr[i], faces, res[i], 15, True)
+    whole, wfaces, _ = corridor.whole_batch(96, seed=403, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    wres, sres, safe, sfaces = fused_pairs(ctx, whole, wfaces, corridor.safe_templates(whole), 10, 0.05)
+    ok = np.nonzero((safe["n_seg"] > 0) & (sres["solved"] == 1))[0][:32]
+    assert len(ok) == 32
+    for j in ok:
+        assert safe[j]["force_final_pos"] == 0
+        check(safe[j], sfaces, sres[j], 10, False)
+
+
 # ---- row N1 on the device against the reference's OWN sources (oracle/_ref/libref_frontend.so: untouched DecompUtil / jps3d behind
 # test-only shims, oracle/ref_frontend/; built in the development container, travels with the snapshot) ----
 @pytest.fixture(scope="module")

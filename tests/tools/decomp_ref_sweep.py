@@ -1,7 +1,9 @@
 """The host restatement of JPS_Manager::cvxEllipsoidDecomp (faster_amd/host/corridor_frontend.cpp, what the device kernel K4 equals bit for
 bit) against the reference's OWN DecompUtil headers compiled untouched (oracle/_ref/libref_frontend.so) on the corridors of forest paths:
-every polytope compared as a SET of rows (1e-9); how many also come in the same order is reported.  CPU only; needs /root/reference.
-usage: PYTHONPATH=. python tests/tools/decomp_ref_sweep.py [paths_per_map] [maps]"""
+every polytope compared as a SET of rows (1e-9); how many also come in the same order is reported.  CPU only by default (building
+oracle/_ref needs /root/reference; the GPU box uses the prebuilt file).  With a third argument `device` the same legs are also decomposed
+by the device kernel K4 (fh_decompose_batch) and its rows are compared with the host restatement's BIT FOR BIT and in order.
+usage: PYTHONPATH=. python tests/tools/decomp_ref_sweep.py [paths_per_map] [maps] [device]"""
 import sys
 import time
 
@@ -12,6 +14,14 @@ from oracle.ref_frontend import ref
 
 npaths = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 nmaps = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+device = len(sys.argv) > 3 and sys.argv[3] == "device"
+ctx = None
+if device:
+    import torch  # noqa: F401  (one HIP runtime per process)
+    from faster_amd import capi
+
+    ctx = capi.Context(0)
+dev_polys = dev_equal = 0
 rng = np.random.default_rng(31)
 key = lambda M: M[np.lexsort(np.round(M, 6).T[::-1])]
 polys = same_set = same_order = worst = 0
@@ -38,6 +48,12 @@ for k in range(nmaps):
         want = ref.decompose(path, cloud, radius, 0.0)
         got, _ = frontend.decompose(path, cloud, drone_radius=radius, z_ground=0.0)
         assert len(got) == len(want)
+        if device:
+            dfaces, dcounts = ctx.decompose_batch(cloud, np.hstack([path[:-1], path[1:]]), drone_radius=radius, z_ground=0.0, max_faces=96)
+            for j, (A, b) in enumerate(got):
+                dev_polys += 1
+                rows = np.column_stack([dfaces["a"][j, :max(dcounts[j], 0)], dfaces["b"][j, :max(dcounts[j], 0)]])
+                dev_equal += int(dcounts[j] == len(b) and np.array_equal(rows, np.column_stack([A, b])))
         for (A, b), (A2, b2) in zip(got, want):
             mp += 1
             if len(b) != len(b2):
@@ -53,3 +69,6 @@ for k in range(nmaps):
           % (k, side, res, infl, radius, max_poly, mvd, mp, ms, mo, time.time() - t0), flush=True)
 print("DECOMPOSITION REFERENCE SWEEP DONE: %d maps, %d polytopes, %d equal to the reference's DecompUtil as sets of rows (1e-9; worst difference %.1e), "
       "%d of them with the rows in the same order" % (nmaps, polys, same_set, worst, same_order))
+if device:
+    print("DEVICE K4 (fh_decompose_batch) on the same %d legs: %d equal to the host restatement bit for bit and in order" % (dev_polys, dev_equal))
+    assert dev_polys == dev_equal == polys
