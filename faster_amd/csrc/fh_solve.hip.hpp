@@ -385,6 +385,7 @@ struct Solver {
   int K, zc0;             // Z = columns zc0 .. zc0 + K - 1 of Zm (zc0 = 2 safe, 3 whole; K = max(N - zc0, 0))
   int qe;                 // equality rows in the factorisation: always 0 (they are eliminated; kept in the frame header layout)
   bool eq_ok;             // the final-state equalities of this trial are consistent (always, unless N < 3)
+  bool early_inf;         // setup_trial: the trial is refuted at y = 0 by the jerk box (|xp|^2 > 3N j_max^2) — nothing else was set up
   double c0;              // |xp|^2: cost of the trial at y = 0
   double box_ub;          // 3N j_max^2 (1 + 1e-9): no feasible trajectory costs more
   double gx2;             // |normal in jerk space|^2 of the row build_g built last
@@ -586,7 +587,7 @@ struct Solver {
 
   // ---- per trial (step h): states for y = 0 and the inverse row norms.  bt: the basis table of this N (fh_basis.hip.hpp) ----
   template <class PR>
-  __device__ void setup_trial(const PR& pr, const double* __restrict__ bt) {
+  __device__ void setup_trial(const PR& pr, const double* __restrict__ bt, bool may_end_early = false) {
     // Inlined twice — the trial loop, and the worker that writes the result of a shared problem — and results must not depend on
     // which copy ran: no contraction into fused multiply-adds left to the optimiser's choice per site.
 #pragma clang fp contract(off)
@@ -665,6 +666,14 @@ struct Solver {
       c0 = wave_sum(xp * xp);
     }
     FH_SYNC();
+#ifndef FH_NO_EARLY_OUT
+    // The cheapest trajectory that meets the final-state equalities already costs more than any trajectory inside the jerk box may
+    // (|x|^2 <= 3N j_max^2, setMaxConstraints :403-405): the root of this trial is infeasible before its first active-set iteration —
+    // what qp_loop finds at y = 0 with the same comparison.  Most failed trials of a whole problem (94 % on C4) and a third of a safe
+    // problem's end here: the states, the row norms, the screening and the root's set-up are skipped (run_problem counts the node).
+    early_inf = may_end_early && eq_ok && !(c0 <= box_ub);
+    if (early_inf) return;
+#endif
     {
       double dp, dv, da;
       moments(dp, dv, da);
@@ -1886,6 +1895,14 @@ struct Solver {
 
   // ---- MIQP for one dt: depth-first branch and bound.  entry 0: from the root; entry 1: from the frame installed as
   // stack level 0 (install_frame).  returns FH_ST_* (OPTIMAL / INFEASIBLE refer to what THIS worker saw) ----
+  // jerk-independent rows of the box: |v0| <= v_max, |a0| <= a_max (setMaxConstraints t = 0, :397-401)
+  template <class PR>
+  __device__ __forceinline__ bool x0_outside_box(const PR& pr) const {
+    bool x0bad = false;
+    for (int i = 0; i < 3; i++) x0bad |= (fabs(pr.x0[3 + i]) - vmax > tol) || (fabs(pr.x0[6 + i]) - amax > tol);
+    return x0bad;
+  }
+
   template <class PR>
   __device__ int search(const PR& pr, const fh_params& par, const ShareArgs& sa, double* __restrict__ ws, int entry,
                         double& best_cost, int& nodes, int& iters) {
@@ -1902,9 +1919,7 @@ struct Solver {
       depth0 = 0;
       if (lane < NSEG) assign[lane] = -1;
       // jerk-independent rows of the box: |v0| <= v_max, |a0| <= a_max (setMaxConstraints t = 0, :397-401)
-      bool x0bad = false;
-      for (int i = 0; i < 3; i++) x0bad |= (fabs(pr.x0[3 + i]) - vmax > tol) || (fabs(pr.x0[6 + i]) - amax > tol);
-      if (x0bad) return FH_ST_INFEASIBLE;
+      if (x0_outside_box(pr)) return FH_ST_INFEASIBLE;
       {
         FH_T0();
         screen_constant_rows(pr);
@@ -2320,7 +2335,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     last_trial = !(f + pr.f_inc <= pr.f_final);
     sv.h = dt;
     if (lane == 0) sv.tb_put64(sv.TB_F, sv.f64_bits(f));  // (what a frame given away by this trial has to say about it)
-    { FH_T0(); sv.setup_trial(pr, bt);
+    { FH_T0(); sv.setup_trial(pr, bt, entry != 1);
 #ifdef FH_PROFILE
       sv.prof[1] += __builtin_readcyclecounter() - t0__; sv.cnt[1] += 1;
 #endif
@@ -2336,7 +2351,15 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
 #ifdef FH_PROFILE
     const unsigned long long ts0__ = __builtin_readcyclecounter();
 #endif
-    const int st = sv.search(pr, par, sa, ws, entry == 1 ? 1 : 0, best, nodes, iters);
+    int st;
+#ifndef FH_NO_EARLY_OUT
+    // (the limits that search() tests before it opens a node keep their say: a node cap of zero, a work cap already used up)
+    if (sv.early_inf && !sv.x0_outside_box(pr) && par.max_nodes > 0 && !(par.max_work > 0 && iters >= par.max_work)) {  // the root node, refuted without an iteration
+      st = FH_ST_INFEASIBLE;
+      nodes += 1;
+    } else  // (x0 outside the v / a box: search() says so before it touches what setup_trial skipped, and counts no node)
+#endif
+    st = sv.search(pr, par, sa, ws, entry == 1 ? 1 : 0, best, nodes, iters);
 #ifdef FH_PROFILE
     sv.prof[15] += __builtin_readcyclecounter() - ts0__; sv.cnt[15] += 1;
 #endif
