@@ -16,9 +16,9 @@ SO_PATH = os.environ.get("FASTERHIP_SO", os.path.join(_HERE, "libfasterhip.so"))
 SYMBOLS = [
     "fh_create", "fh_destroy", "fh_last_error", "fh_default_params", "fh_set_params", "fh_default_sched", "fh_set_sched", "fh_set_stream",
     "fh_request_stop", "fh_clear_stop", "fh_share_stats_read", "fh_share_profile_read", "fh_fp64_peak", "fh_set_pair_margin", "fh_set_pair_rule", "fh_set_unknown_grid_device", "fh_next_goals_device",
-    "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_corridor_problems_device", "fh_solve_pairs_device",
+    "fh_dt_initial_batch", "fh_dt_initial_batch_device", "fh_solve_batch", "fh_solve_batch_speculative", "fh_solve_batch_device", "fh_sample_batch", "fh_sample_batch_device", "fh_pair_glue_device", "fh_append_plans_device", "fh_safe_corridor_batch_device", "fh_corridor_problems_device", "fh_solve_pairs_device",
     "fh_decompose_batch", "fh_decompose_batch_device", "fh_corridor_batch_device",
-    "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule",
+    "fh_pool_create", "fh_pool_destroy", "fh_pool_size", "fh_pool_last_error", "fh_pool_set_params", "fh_pool_set_pair_margin", "fh_pool_set_pair_rule", "fh_pool_set_unknown_grid",
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
     "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_set_records", "fh_map_workspace_bytes", "fh_map_set_sphere", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
@@ -181,6 +181,8 @@ def lib():
         L.fh_pool_set_pair_margin.argtypes = [vp, f64]
         L.fh_pool_set_pair_rule.restype = i32
         L.fh_pool_set_pair_rule.argtypes = [vp, vp]
+        L.fh_pool_set_unknown_grid.restype = i32
+        L.fh_pool_set_unknown_grid.argtypes = [vp, vp, vp]
         L.fh_pool_solve_batch.restype = i32
         L.fh_pool_solve_batch.argtypes = [vp, vp, vp, i64, i32, vp, i32, vp]
         L.fh_pool_solve_pairs.restype = i32
@@ -213,6 +215,10 @@ def lib():
         L.fh_timing_read.argtypes = [vp, vp, i32]
         L.fh_last_kernel_ms.restype = f64
         L.fh_last_kernel_ms.argtypes = [vp]
+        L.fh_dt_initial_batch.restype = i32
+        L.fh_dt_initial_batch.argtypes = [vp, vp, i32, vp]
+        L.fh_dt_initial_batch_device.restype = i32
+        L.fh_dt_initial_batch_device.argtypes = [vp, vp, i32, vp]
         L.fh_last_launch.restype = i32
         L.fh_last_launch.argtypes = [vp, vp]
         L.fh_version.restype = ctypes.c_char_p
@@ -258,6 +264,22 @@ class Pool:
 
     def set_pair_margin(self, r_margin):
         self._check(lib().fh_pool_set_pair_margin(self._h, float(r_margin)), "fh_pool_set_pair_margin")
+
+    def set_pair_rule(self, mode=0, r_known=0.0, drone_radius=0.0, delta_h=1.0, delta_a=0.5):
+        r = np.zeros(1, dtype=abi.pair_rule_dtype)
+        r["mode"], r["r_known"], r["drone_radius"], r["delta_h"], r["delta_a"] = mode, r_known, drone_radius, delta_h, delta_a
+        self._check(lib().fh_pool_set_pair_rule(self._h, abi.ptr(r)), "fh_pool_set_pair_rule")
+
+    def set_unknown_grid(self, flags, origin=None, res=None, dims=None):
+        """fh_pool_set_unknown_grid: HOST flags [nz][ny][nx] (x fastest), copied to every device of the pool; None: no grid."""
+        if flags is None:
+            self._check(lib().fh_pool_set_unknown_grid(self._h, None, None), "fh_pool_set_unknown_grid")
+            return
+        g = np.zeros((), dtype=abi.voxel_grid_dtype)
+        g["origin"], g["res"], g["dims"] = origin, res, dims
+        g = np.ascontiguousarray(g).reshape(1)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(lib().fh_pool_set_unknown_grid(self._h, abi.ptr(g), abi.ptr(flags)), "fh_pool_set_unknown_grid")
 
     def solve_batch(self, problems, faces, root=0, d_results_root=None):
         problems = np.ascontiguousarray(problems)
@@ -500,6 +522,14 @@ class Context:
         return d, "fh::solve_kernel<%d, %s, %d>" % (d["n_seg"], "true" if d["pairs"] else "false", d["waves_per_simd"])
 
     # ---- host-pointer entry points (numpy in, numpy out) ----
+    def dt_initial_batch(self, problems):
+        """fh_dt_initial_batch: SolverGurobi::getDTInitial per problem."""
+        problems = np.ascontiguousarray(problems)
+        assert problems.dtype == abi.problem_dtype
+        dt = np.zeros(problems.shape[0], dtype=np.float64)
+        self._check(lib().fh_dt_initial_batch(self._h, abi.ptr(problems), problems.shape[0], abi.ptr(dt)), "fh_dt_initial_batch")
+        return dt
+
     def solve_batch(self, problems, faces):
         problems = np.ascontiguousarray(problems)
         faces = np.ascontiguousarray(faces)

@@ -39,7 +39,7 @@ struct fh_ctx {
                      nullptr, nullptr, nullptr, nullptr};
   size_t d_cap[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int n_cu = 0;
-  size_t lds_attr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
+  size_t lds_attr[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // largest dynamic-LDS size already set per kernel instantiation
   unsigned int* h_abort = nullptr;          // mapped host word polled by the kernels (fh_request_stop)
   unsigned int* d_abort = nullptr;          // its device address
   unsigned int* h_report = nullptr;         // pinned: the control block's report words of the last launch (copied with the results)
@@ -115,8 +115,10 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // a batch alone on the device is done 13 % sooner).
   // (fh_sched.workgroups_per_cu > 8 asks for the three-wavefront build whatever the batch: the tests run both on the same inputs)
   const int wpc = ctx->sched.workgroups_per_cu;
-  const bool two_waves = FH_WAVES_PER_SIMD > 2 && (wpc > 0 ? wpc <= 8 : ((160 * 1024) / lds_alloc <= 8 || n <= 8 * ctx->n_cu));
-  auto kern = two_waves ? fh::solve_kernel<NSEG, PAIRS, 2> : fh::solve_kernel<NSEG, PAIRS>;
+  // (rule mode 2 — the hand-off asks the caller's unknown voxels — has its instantiations in the two-wavefront build only)
+  const bool unk = PAIRS && ka.rule.mode == 2;
+  const bool two_waves = FH_WAVES_PER_SIMD > 2 && (unk || (wpc > 0 ? wpc <= 8 : ((160 * 1024) / lds_alloc <= 8 || n <= 8 * ctx->n_cu)));
+  auto kern = unk ? fh::solve_kernel<NSEG, PAIRS, 2, PAIRS> : (two_waves ? fh::solve_kernel<NSEG, PAIRS, 2> : fh::solve_kernel<NSEG, PAIRS>);
   int per_cu = (int)std::min<size_t>((two_waves ? 2 : FH_WAVES_PER_SIMD) * 4, (160 * 1024) / lds_alloc);
   if (per_cu < 1) per_cu = 1;
   // fh_sched.workgroups_per_cu: fewer resident solves per CU than would fit.  The launch then asks for so much LDS that the hardware
@@ -168,7 +170,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   ka.workspace = (double*)ctx->d_buf[5];
   ka.basis = (const double*)ctx->d_buf[15];
   {  // raise the dynamic-LDS limit of this instantiation only when a launch needs more than any before it
-    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : (NSEG <= 15 ? 2 : 3))) + (PAIRS ? 4 : 0) + (two_waves ? 8 : 0)];
+    size_t& have = ctx->lds_attr[(NSEG <= 6 ? 0 : (NSEG <= 10 ? 1 : (NSEG <= 15 ? 2 : 3))) + (unk ? 16 : (PAIRS ? 4 : 0) + (two_waves ? 8 : 0))];
     if (lds_launch > have) {
       FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch));
       have = lds_launch;
@@ -750,6 +752,42 @@ int fh_sample_batch(fh_ctx* ctx, const fh_problem* problems, const fh_result* re
   return FH_OK;
 }
 
+// getDTInitial for a batch: one wavefront per problem, the device function the solve kernels call (fh_solve.hip.hpp: dt_initial)
+__global__ void __launch_bounds__(64) dt_initial_kernel(const fh_problem* __restrict__ problems, int n, double* __restrict__ dt) {
+  const int lane = threadIdx.x;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const double v = fh::dt_initial(problems[i], lane);
+    if (lane == 0) dt[i] = v;
+  }
+}
+
+int fh_dt_initial_batch_device(fh_ctx* ctx, const fh_problem* d_problems, int n, double* d_dt) {
+  if (!ctx || n < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!d_problems || !d_dt) return FH_ERR_ARG;
+  hipLaunchKernelGGL(dt_initial_kernel, dim3((unsigned)std::min(n, 32 * ctx->n_cu)), dim3(64), 0, ctx->stream, d_problems, n, d_dt);
+  FH_HIP(hipGetLastError());
+  return FH_OK;
+}
+
+int fh_dt_initial_batch(fh_ctx* ctx, const fh_problem* problems, int n, double* dt) {
+  if (!ctx || n < 0) return FH_ERR_ARG;
+  if (ctx->device < 0) return FH_ERR_DEVICE;
+  DeviceScope device_scope(ctx);
+  if (n == 0) return FH_OK;
+  if (!problems || !dt) return FH_ERR_ARG;
+  int rc;
+  if ((rc = ensure(ctx, 0, sizeof(fh_problem) * (size_t)n)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 4, sizeof(double) * (size_t)n)) != FH_OK) return rc;
+  FH_HIP(hipMemcpyAsync(ctx->d_buf[0], problems, sizeof(fh_problem) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = fh_dt_initial_batch_device(ctx, (const fh_problem*)ctx->d_buf[0], n, (double*)ctx->d_buf[4])) != FH_OK) return rc;
+  FH_HIP(hipMemcpyAsync(dt, ctx->d_buf[4], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  FH_HIP(hipStreamSynchronize(ctx->stream));
+  return FH_OK;
+}
+
 int fh_pair_glue_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_result* d_whole_results, const fh_face* d_faces,
                         int n, double r_frac, double shrink, int max_safe_poly, fh_problem* d_safe, fh_face* d_safe_faces) {
   if (!ctx || n < 0) return FH_ERR_ARG;
@@ -808,9 +846,8 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   if (n == 0) return FH_OK;
   if (!d_whole || !d_whole_results || !d_safe || !d_safe_results) return FH_ERR_ARG;
   if (max_safe_poly < 0 || max_safe_poly > FH_MAX_POLY || !(r_frac >= 0) || !(r_frac <= 1) || !(shrink >= 0)) return FH_ERR_ARG;
-  if (ctx->pair_rule.mode == 2) {  // the fused kernel's hand-off knows the modelled unknown space only (rule modes 0 and 1)
-    ctx->err = "fh_solve_pairs_device: fh_pair_rule mode 2 (unknown voxels as an input) runs as stages: fh_solve_batch_device, "
-               "fh_safe_corridor_batch_device or fh_pair_glue_device, fh_solve_batch_device, fh_append_plans_device";
+  if (ctx->pair_rule.mode == 2 && !ctx->unknown.flags) {
+    ctx->err = "fh_pair_rule mode 2 needs the unknown voxels: fh_set_unknown_grid_device";
     return FH_ERR_ARG;
   }
   if (max_seg <= 0 || max_seg > FH_MAX_SEG) max_seg = FH_MAX_SEG;
@@ -821,6 +858,7 @@ int fh_solve_pairs_device(fh_ctx* ctx, const fh_problem* d_whole, const fh_face*
   ka.n = n; ka.max_faces = max_faces;
   ka.safe = d_safe; ka.sfaces = d_safe_faces; ka.sres = d_safe_results;
   ka.r_frac = r_frac; ka.shrink = shrink; ka.max_safe_poly = max_safe_poly; ka.r_margin = ctx->pair_margin; ka.rule = ctx->pair_rule;
+  ka.unknown = ctx->unknown;
   if (max_seg <= 6) return launch_solve<6, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   if (max_seg <= 10) return launch_solve<10, true>(ctx, d_whole, d_faces, d_whole_results, ka);
   if (max_seg <= 15) return launch_solve<15, true>(ctx, d_whole, d_faces, d_whole_results, ka);

@@ -28,8 +28,8 @@ struct PoolDev {
   int device = -1;
   fh_ctx* ctx = nullptr;
   hipStream_t stream = nullptr;
-  void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // problems, faces, results, safe problems, safe faces, safe results
-  size_t cap[6] = {0, 0, 0, 0, 0, 0};
+  void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // problems, faces, results, safe problems, safe faces, safe results,
+  size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};                                            // the unknown voxel flags (fh_pool_set_unknown_grid)
   std::string err;
   int rc = FH_OK;
 };
@@ -232,7 +232,7 @@ void fh_pool_destroy(fh_pool* pool) {
   for (PoolDev& d : pool->dev) {
     (void)hipSetDevice(d.device);
     if (d.ctx) fh_destroy(d.ctx);
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 7; i++)
       if (d.buf[i]) (void)hipFree(d.buf[i]);
     if (d.stream) (void)hipStreamDestroy(d.stream);
   }
@@ -266,6 +266,33 @@ int fh_pool_set_pair_rule(fh_pool* pool, const fh_pair_rule* rule) {
   for (PoolDev& d : pool->dev) {
     const int rc = fh_set_pair_rule(d.ctx, rule);
     if (rc != FH_OK) return rc;
+  }
+  return FH_OK;
+}
+
+// Unknown space as an input for the pool (rule mode 2): the flags are host memory here — every device of the pool gets its own copy
+// (synchronous) and its context is told (fh_set_unknown_grid_device).  flags = NULL: none.
+int fh_pool_set_unknown_grid(fh_pool* pool, const fh_voxel_grid* grid, const unsigned char* flags) {
+  if (!pool) return FH_ERR_ARG;
+  if (flags && (!grid || grid->dims[0] < 1 || grid->dims[1] < 1 || grid->dims[2] < 1)) return FH_ERR_ARG;
+  for (PoolDev& d : pool->dev) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(d.device);
+    int rc = FH_OK;
+    if (!flags) {
+      rc = fh_set_unknown_grid_device(d.ctx, nullptr, nullptr);
+    } else {
+      const size_t bytes = (size_t)grid->dims[0] * (size_t)grid->dims[1] * (size_t)grid->dims[2];
+      (void)hipStreamSynchronize(d.stream);  // (a launch that still reads the old flags)
+      if (!grow(d, 6, bytes) || hipMemcpy(d.buf[6], flags, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = FH_ERR_DEVICE;
+      else rc = fh_set_unknown_grid_device(d.ctx, grid, (const unsigned char*)d.buf[6]);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (rc != FH_OK) {
+      pool->err = "fh_pool_set_unknown_grid: device " + std::to_string(d.device);
+      return rc;
+    }
   }
   return FH_OK;
 }

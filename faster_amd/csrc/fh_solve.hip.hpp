@@ -292,8 +292,10 @@ __device__ inline double quad_root_of_lane(double c2, double c1, double c0, int 
   if (qq == 0) return 0.0;
   return j == 0 ? qq / c2 : (j == 1 ? c0 / qq : 0.0);
 }
+// getDTInitial as the oracle evaluates it, one candidate root per lane (lane = 3 * axis + j; the exact path: closed forms with the
+// double-precision cbrt / acos / cos of the device library, ~1100 vector instructions on nine useful lanes).
 template <class PR>
-__device__ inline double dt_initial(const PR& pr, int lane) {
+__device__ __attribute__((noinline)) double dt_initial_exact(const PR& pr, int lane) {  // (out of line: the rare path must not cost the kernels registers)
   const int ax = lane / 3, j = lane - 3 * ax;
   const int i = ax < 3 ? ax : 2;  // (lanes beyond 8 repeat axis 2: harmless duplicates)
   const double x0p = i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2]);
@@ -321,6 +323,125 @@ __device__ inline double dt_initial(const PR& pr, int lane) {
   double dt0 = (double)(mx / (float)pr.n_seg);  // :751  (float / int)
   if (dt0 > 10000) dt0 = 0;                     // :752-756
   return dt0;
+}
+
+// ---- the same value with a tenth of the transcendental work ------------------------------------------------------
+// What the closed forms are FOR is a starting point of polish3: its three Newton steps square the error of the start three times, so
+// a start that is good to 1e-5 ends on the same rounding-level neighbourhood of the root as one that is good to 1e-16 — and the
+// result is stored as a float (:662-670).  The starts below are therefore computed with the hardware's single-precision
+// transcendentals (v_log / v_exp for the cube roots, a 7th-degree polynomial for acos, v_cos) on quantities brought into their range
+// first, the double-precision square root by v_sqrt_f64 without its correction steps.  Everything that DECIDES something is still the
+// oracle's double arithmetic: B, C, D, p, q and the discriminant with their divisions, which roots are real, MinPositiveElement, and
+// the quadratic's roots, which are used as they come (no polish: correctly rounded sqrt and divisions).  Where the polish could not
+// repair a poor start — two roots closer than a thousandth of their size: |disc| below 1e-6 of its terms, or terms so small that the
+// 1e-12 test for an imaginary part decides; or a root at zero (dx = 0), whose sign is rounding noise — any lane says so and the whole
+// wavefront takes the exact path.
+// Lane = 4 * axis + j (an axis' candidates share a quad: their minimum is two quad permutes), nine useful lanes.
+__device__ __forceinline__ double cbrt_start(double a) {  // relative error ~1e-6
+  const int e = __builtin_amdgcn_frexp_exp(a);              // a = m 2^e, |m| in [0.5, 1)
+  const float m = (float)fabs(__builtin_amdgcn_frexp_mant(a));
+  const int e3 = (e + 3072) / 3 - 1024, r = e - 3 * e3;     // e = 3 e3 + r, r in {0, 1, 2}
+  const float y = __builtin_amdgcn_exp2f((__builtin_amdgcn_logf(m) + (float)r) * (1.0f / 3.0f));
+  return copysign(__builtin_ldexp((double)y, e3), a);        // (a = 0: log -> -inf, exp -> 0)
+}
+__device__ __forceinline__ float acos_start(float x) {  // |error| < 1e-6 on [-1, 1] (Abramowitz & Stegun 4.4.46 in single precision)
+  const float ax = fabsf(x);
+  float pl = -0.0012624911f;
+  pl = pl * ax + 0.0066700901f;
+  pl = pl * ax - 0.0170881256f;
+  pl = pl * ax + 0.0308918810f;
+  pl = pl * ax - 0.0501743046f;
+  pl = pl * ax + 0.0889789874f;
+  pl = pl * ax - 0.2145988016f;
+  pl = pl * ax + 1.5707963050f;
+  const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * pl;
+  return x < 0.f ? 3.14159265f - r : r;
+}
+template <class PR>
+__device__ __forceinline__ double dt_initial(const PR& pr, int lane) {
+#ifdef FH_DT_EXACT_ONLY
+  return dt_initial_exact(pr, lane);
+#else
+  const int ax = lane >> 2, j = lane & 3;
+  const int i = ax < 3 ? ax : 2;  // (lanes beyond 11 repeat axis 2, lane j = 3 of a quad holds no candidate)
+  const double x0p = i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2]);
+  const double x0v = i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5]);
+  const double x0a = i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8]);
+  const double xfp = i == 0 ? pr.xf[0] : (i == 1 ? pr.xf[1] : pr.xf[2]);
+  const double dx = xfp - x0p;
+  const float tv = (float)(fabs(dx) / pr.v_max);                     // :672-674
+  const float jerk = (float)(copysign(1.0, dx) * pr.j_max);          // :679-681
+  const float a0 = (float)x0a, v0 = (float)x0v;                      // :682-687
+  // the cubic (jerk / 6) t^3 + (a0 / 2) t^2 + v0 t - dx (:691-713).  Its depressed form only chooses the case and the starting points
+  // here, so its divisions are multiplications by a reciprocal that is good to an ulp or two (v_rcp_f64 and one correction step)
+  const double c3 = (double)jerk / 6.0, c2 = (double)a0 / 2.0, c1 = (double)v0, c0 = -dx;
+  double ic3 = __builtin_amdgcn_rcp(c3);
+  ic3 = fma(fma(-c3, ic3, 1.0), ic3, ic3);
+  const double B = c2 * ic3, C = c1 * ic3, D = c0 * ic3, B3 = B * (1.0 / 3.0);
+  const double p = C - B * B3;
+  const double q = 2.0 * B3 * B3 * B3 - B3 * C + D;
+  const double q2 = 0.5 * q, p3 = p * (1.0 / 3.0);
+  const double p27 = p3 * p3 * p3;
+  const double disc = q2 * q2 + p27;
+  const double scale = q2 * q2 + fabs(p27);
+  // the quadratic (acc / 2) t^2 + v0 t - dx (:724-746): its roots are used as they come, so the square root and the two divisions
+  // are the correctly rounded ones.  acc has the sign of dx: its discriminant v0^2 + 2 |acc| |dx| is never negative
+  const float acc = (float)(copysign(1.0, dx) * pr.a_max);           // :718-720
+  const double qc2 = 0.5 * (double)acc;
+  const double qdisc = c1 * c1 - 4.0 * qc2 * c0;
+  const bool triple = !(disc > 0) && p == 0;  // (B = C = D = 0 — at rest on this axis with nowhere to go — is the case that occurs)
+  // (dx = 0 — same height at start and goal, say — puts a root of the cubic AT zero: whether it comes out as +1e-17, 0 or -1e-17, and
+  // with that whether MinPositiveElement sees it, is decided by the last bit of the closed form: only the oracle's own arithmetic follows it)
+  const bool ill = !(fabs(disc) >= 1e-6 * scale) || (scale > 0.0 && scale < 1e-40) || !(scale < 1e280) || !(qdisc >= 0.0) || (triple && B != 0.0) ||
+                   !(fabs(dx) >= 1e-30);
+  if (wave_any(ill && lane < 12)) return dt_initial_exact(pr, opaque(lane));
+  double rj = 0.0;
+  if (disc > 0) {  // one real root (the pair's imaginary part is far above 1e-12 here: j = 1 has no candidate)
+    const double sq = __builtin_amdgcn_sqrt(disc);
+    const double u = cbrt_start(sq - q2), v = cbrt_start(-q2 - sq);
+    rj = u + v - B3;
+  } else if (triple) {
+    rj = 0.0;  // -B / 3 with B = 0, used as it is
+  } else {  // three real roots
+    const double m = 2.0 * __builtin_amdgcn_sqrt(-p3);
+    const float arg = fminf(1.0f, fmaxf(-1.0f, (float)(3.0 * q * __builtin_amdgcn_rcp(p * m))));
+    const float rev = acos_start(arg) * (1.0f / (3.0f * 6.28318531f)) - (float)j * (1.0f / 3.0f);  // (phi - 2 pi j / 3) in revolutions
+    rj = m * (double)__builtin_amdgcn_cosf(rev) - B3;
+  }
+  if (!triple) {  // polish3 with the same kind of reciprocal: a Newton step's quotient is a correction, an ulp of it is far below one of t
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      const double f = ((c3 * rj + c2) * rj + c1) * rj + c0;
+      const double df = (3 * c3 * rj + 2 * c2) * rj + c1;
+      double r = __builtin_amdgcn_rcp(df);
+      r = fma(fma(-df, r, 1.0), r, r);
+      const double tn = rj - f * r;
+      rj = (df == 0 || !isfinite(df) || !isfinite(tn)) ? rj : tn;
+    }
+  }
+  if (((disc > 0 || triple) && j != 0) || j == 3) rj = 0.0;  // one real root: only j = 0 holds a candidate
+  double ra = 0.0;
+  {
+    const double sr = sqrt(qdisc);
+    const double qq = -0.5 * (c1 + (c1 >= 0 ? sr : -sr));
+    if (qq != 0) ra = j == 0 ? qq / qc2 : (j == 1 ? c0 / qq : 0.0);
+  }
+  // MinPositiveElement (solverGurobi_utils.hpp:19-32) over the candidates of an axis (a quad), cast to float as the reference stores
+  // them; then the maximum over the nine values
+  double mj = rj > 0 ? rj : INFINITY, ma = ra > 0 ? ra : INFINITY;
+  mj = vmin_f64(mj, dpp_f64<0xB1, 0xf>(INFINITY, mj));  // quad_perm [1, 0, 3, 2]
+  ma = vmin_f64(ma, dpp_f64<0xB1, 0xf>(INFINITY, ma));
+  mj = vmin_f64(mj, dpp_f64<0x4E, 0xf>(INFINITY, mj));  // quad_perm [2, 3, 0, 1]
+  ma = vmin_f64(ma, dpp_f64<0x4E, 0xf>(INFINITY, ma));
+  const float tj = (float)(mj < INFINITY ? mj : 0.0), ta = (float)(ma < INFINITY ? ma : 0.0);
+  const float ml = fmaxf(tv, fmaxf(ta, tj));
+  const int mli = __float_as_int(ml);
+  const float mx = fmaxf(fmaxf(0.f, __int_as_float(__builtin_amdgcn_readlane(mli, 0))),
+                         fmaxf(__int_as_float(__builtin_amdgcn_readlane(mli, 4)), __int_as_float(__builtin_amdgcn_readlane(mli, 8))));
+  double dt0 = (double)(mx / (float)pr.n_seg);  // :751  (float / int)
+  if (dt0 > 10000) dt0 = 0;                     // :752-756
+  return dt0;
+#endif
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -385,7 +506,6 @@ struct Solver {
   int K, zc0;             // Z = columns zc0 .. zc0 + K - 1 of Zm (zc0 = 2 safe, 3 whole; K = max(N - zc0, 0))
   int qe;                 // equality rows in the factorisation: always 0 (they are eliminated; kept in the frame header layout)
   bool eq_ok;             // the final-state equalities of this trial are consistent (always, unless N < 3)
-  bool early_inf;         // setup_trial: the trial is refuted at y = 0 by the jerk box (|xp|^2 > 3N j_max^2) — nothing else was set up
   double c0;              // |xp|^2: cost of the trial at y = 0
   double box_ub;          // 3N j_max^2 (1 + 1e-9): no feasible trajectory costs more
   double gx2;             // |normal in jerk space|^2 of the row build_g built last
@@ -586,8 +706,9 @@ struct Solver {
   }
 
   // ---- per trial (step h): states for y = 0 and the inverse row norms.  bt: the basis table of this N (fh_basis.hip.hpp) ----
+  // Returns true when the trial is refuted at y = 0 by the jerk box (only if may_end_early): nothing else was set up then.
   template <class PR>
-  __device__ void setup_trial(const PR& pr, const double* __restrict__ bt, bool may_end_early = false) {
+  __device__ bool setup_trial(const PR& pr, const double* __restrict__ bt, bool may_end_early = false) {
     // Inlined twice — the trial loop, and the worker that writes the result of a shared problem — and results must not depend on
     // which copy ran: no contraction into fused multiply-adds left to the optimiser's choice per site.
 #pragma clang fp contract(off)
@@ -671,8 +792,9 @@ struct Solver {
     // (|x|^2 <= 3N j_max^2, setMaxConstraints :403-405): the root of this trial is infeasible before its first active-set iteration —
     // what qp_loop finds at y = 0 with the same comparison.  Most failed trials of a whole problem (94 % on C4) and a third of a safe
     // problem's end here: the states, the row norms, the screening and the root's set-up are skipped (run_problem counts the node).
-    early_inf = may_end_early && eq_ok && !(c0 <= box_ub);
-    if (early_inf) return;
+#ifndef FH_EARLY_IN_SEARCH
+    if (may_end_early && eq_ok && !(c0 <= box_ub)) return true;
+#endif
 #endif
     {
       double dp, dv, da;
@@ -688,6 +810,7 @@ struct Solver {
       wcp = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
     }
     FH_SYNC();  // (xs and z are rewritten in full before they are read again)
+    return false;
   }
 
   // Bezier control point k of a segment from the state (P, V, A) at its start and the position Pn at its end (getCP0..3, :833-862)
@@ -1701,7 +1824,7 @@ struct Solver {
   // returns 0: leave / nothing; 1: a stack frame of a tree; 2: the remaining trials of a problem (tb[]: TB_TRIALS - 1 = first
   // trial, TB_F its factor).  idle: this workgroup has no fresh problem to draw (it waits for a frame); otherwise it only takes a
   // frame that is pending right now (one compare-and-swap, only when there is one) and returns 0 at once if there is none.
-  __device__ int take_task(const ShareArgs& sa, double* __restrict__ ws, bool idle) {
+  __device__ __forceinline__ int take_task(const ShareArgs& sa, double* __restrict__ ws, bool idle) {
    for (;;) {  // (an empty frame — its donor found no share record — sends the taker back for a new ticket)
     unsigned long long pos = ~0ull;
     int state = 0;  // 1: got a frame, 2: leave
@@ -1920,6 +2043,12 @@ struct Solver {
       if (lane < NSEG) assign[lane] = -1;
       // jerk-independent rows of the box: |v0| <= v_max, |a0| <= a_max (setMaxConstraints t = 0, :397-401)
       if (x0_outside_box(pr)) return FH_ST_INFEASIBLE;
+#ifdef FH_EARLY_IN_SEARCH  // (A/B: the same refutation, after the complete set-up of the trial)
+      if (eq_ok && !(c0 <= box_ub) && par.max_nodes > 0 && !(par.max_work > 0 && iters >= par.max_work)) {
+        nodes += 1;
+        return FH_ST_INFEASIBLE;
+      }
+#endif
       {
         FH_T0();
         screen_constant_rows(pr);
@@ -2197,7 +2326,7 @@ __device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
 // from the queue (entry 1), until its final result is written (returns true) or until the tree this worker contributed to is
 // still being explored elsewhere (returns false: the worker that finishes the last part continues the problem).
 template <int NSEG, class PR>
-__device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
+__device__ __forceinline__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
                             const fh_params& par, const ShareArgs& sa, const double* __restrict__ basis, double* __restrict__ ws, int entry,
                             bool interrupted, fh_result& res) {
   const int lane = sv.lane;
@@ -2335,7 +2464,8 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     last_trial = !(f + pr.f_inc <= pr.f_final);
     sv.h = dt;
     if (lane == 0) sv.tb_put64(sv.TB_F, sv.f64_bits(f));  // (what a frame given away by this trial has to say about it)
-    { FH_T0(); sv.setup_trial(pr, bt, entry != 1);
+    bool early_inf;
+    { FH_T0(); early_inf = sv.setup_trial(pr, bt, entry != 1);
 #ifdef FH_PROFILE
       sv.prof[1] += __builtin_readcyclecounter() - t0__; sv.cnt[1] += 1;
 #endif
@@ -2354,7 +2484,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
     int st;
 #ifndef FH_NO_EARLY_OUT
     // (the limits that search() tests before it opens a node keep their say: a node cap of zero, a work cap already used up)
-    if (sv.early_inf && !sv.x0_outside_box(pr) && par.max_nodes > 0 && !(par.max_work > 0 && iters >= par.max_work)) {  // the root node, refuted without an iteration
+    if (early_inf && !sv.x0_outside_box(pr) && par.max_nodes > 0 && !(par.max_work > 0 && iters >= par.max_work)) {  // the root node, refuted without an iteration
       st = FH_ST_INFEASIBLE;
       nodes += 1;
     } else  // (x0 outside the v / a box: search() says so before it touches what setup_trial skipped, and counts no node)
@@ -2406,7 +2536,7 @@ __device__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __res
       if (lane < sv.n) sv.bestx_r = cc_load(&R_->x[lane]);
       if (lane < NSEG) sv.bestassign[lane] = sv.unpack_byte(alo, ahi, lane);
       sv.h = dt;
-      sv.setup_trial(pr, bt);  // the y = 0 states of the winning step (this worker may have been exploring another trial)
+      (void)sv.setup_trial(pr, bt);  // the y = 0 states of the winning step (this worker may have been exploring another trial)
     } else {  // no factor of the window is feasible (or the search was cut short): trials_ and dt_ of the last trial of the window
       // (a limit in the winning trial disqualifies its leaves — the sequential search would have gone on to the next factor, which
       // cannot be reconstructed here: reported as not solved.  Otherwise the status of the last trial, as the sequential loop leaves it.)
@@ -2516,6 +2646,7 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
   double r_frac, shrink, r_margin;
   int max_safe_poly, pad;
   fh_pair_rule rule;  // which sample of the whole trajectory becomes R (fh_set_pair_rule)
+  UnknownGrid unknown; // rule mode 2: the caller's unknown voxels (fh_set_unknown_grid_device), read by the UNK instantiations only
   // launch order: ticket t works on unit order[t] (null: t).  Results do not depend on it; the hardest corridors go first so that
   // their trees are not what the launch ends on (order_kernel)
   const int* order;
@@ -2533,7 +2664,10 @@ struct SolveArgs {  // (the problem / face / result arrays are separate `__restr
 // WPS: wavefronts per SIMD the kernel is compiled for.  3 (168 registers, some spilled: 11 resident solves per CU at N = 10) is the
 // throughput build; 2 (193 registers at N = 10, nothing spilled, no scratch: 8 per CU) solves a batch that is alone on the device
 // 13 % sooner and many batches in flight 14 % slower — fh_sched.workgroups_per_cu <= 8 selects it.  The same arithmetic: the same bits.
-template <int NSEG, bool PAIRS, int WPS = FH_WAVES_PER_SIMD>
+// UNK: the hand-off of a pair asks the caller's unknown voxels (fh_pair_rule mode 2: findIndexH as the reference decides it,
+// faster.cpp:218-251 with kdtree_unk_.nearestKSearch :236).  An instantiation of its own, built for two wavefronts per SIMD, so that
+// the lookup's registers are not the throughput build's problem; modes 0 and 1 run the same kernels as before.
+template <int NSEG, bool PAIRS, int WPS = FH_WAVES_PER_SIMD, bool UNK = false>
 __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
                                                    fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2703,14 +2837,14 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
 #ifdef FH_PROFILE
             unsigned long long probe[4] = {0ull, 0ull, 0ull, 0ull};
             pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
-                                opaque((int)threadIdx.x), probe);
+                                opaque((int)threadIdx.x), probe, UNK ? &ka.unknown : nullptr);
             if (probe[0]) {
               sv.glue_parts[0] = probe[0] - tglue__; sv.glue_parts[1] = probe[1] - probe[0]; sv.glue_parts[2] = probe[2] - probe[1];
               sv.glue_parts[3] = probe[3] - probe[2];
             }
 #else
             pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
-                                opaque((int)threadIdx.x));
+                                opaque((int)threadIdx.x), nullptr, UNK ? &ka.unknown : nullptr);
 #endif
           }
           // the safe problem went out write-through and is drained: this wavefront reads its own stores back (a CU's L1 follows

@@ -221,6 +221,14 @@ int fh_share_profile_read(fh_ctx* ctx, unsigned long long* out16);
 int fh_fp64_peak(fh_ctx* ctx, double* tflops);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
+/* SolverGurobi::getDTInitial (solverGurobi.cpp:659-759) for a batch: the lower bound of the segment time from which genNewTraj's
+ * factor loop starts (dt = factor * max(dt_initial, 2 DC), findDT :494-497) — per axis the time to cover |xf - x0| at v_max and the
+ * smallest positive real roots of the constant-jerk cubic and the constant-acceleration quadratic, with the reference's float casts
+ * and float / int division; > 10000 -> 0.  Reads x0, xf (positions), v_max, a_max, j_max and n_seg of each problem record; the same
+ * device function the solve kernels call (their fh_result.dt = factor * max(this, 2 dc)).  dt [n] doubles. */
+int fh_dt_initial_batch(fh_ctx* ctx, const fh_problem* problems, int n, double* dt);
+int fh_dt_initial_batch_device(fh_ctx* ctx, const fh_problem* d_problems, int n, double* d_dt);
+
 /* Batch of genNewTraj() calls, inputs/outputs in HOST memory (copies in/out, synchronous).
  * Replaces SolverGurobi::genNewTraj() (solverGurobi.cpp:426-477) incl. every callOptimizer()
  * (:549-657) it issues.  `faces` holds n_faces rows addressed through fh_problem.face_begin. */
@@ -284,8 +292,12 @@ int fh_set_pair_margin(fh_ctx* ctx, double r_margin);
  * mode 2: the same two functions against unknown space AS AN INPUT — the mapper's unknown voxels, given once per context with
  *   fh_set_unknown_grid_device: a sample is near unknown space iff an unknown voxel centre is closer than drone_radius to it, which is
  *   what the reference's `kdtree_unk_.nearestKSearch(p, 1, ...)` + `sqrt(d2) < drone_radius` decides (faster.cpp:236-240).  r_known
- *   is not used.  Mode 2 is for the staged entry points (fh_pair_glue_device, fh_safe_corridor_batch_device, fh_append_plans_device);
- *   fh_solve_pairs_device refuses it.
+ *   is not used.  Every entry point that chooses R takes it: the staged ones (fh_pair_glue_device, fh_safe_corridor_batch_device,
+ *   fh_append_plans_device) and, since round 5, the fused pair kernel (fh_solve_pairs_device, fh_pool_solve_pairs with
+ *   fh_pool_set_unknown_grid): H, R and "is a safe trajectory needed" are then the reference's decisions inside the one launch; the
+ *   safe corridor of the fused kernel stays the run of polytopes of the WHOLE corridor from the one that holds R — the corridor
+ *   decomposed around R against unknown + occupied space, as FASTER builds it, is fh_safe_corridor_batch_device (the staged path).
+ *   The fused mode-2 launch runs kernel instantiations of its own, built for two wavefronts per SIMD (<= 8 solves per CU).
  * r_frac of the calls is ignored in modes 1 and 2.  The safe corridor is built from R as described above in every mode. */
 typedef struct fh_pair_rule {
   int32_t mode, reserved;
@@ -420,6 +432,10 @@ const char* fh_pool_last_error(const fh_pool* pool);
 int fh_pool_set_params(fh_pool* pool, const fh_params* p);
 int fh_pool_set_pair_margin(fh_pool* pool, double r_margin);
 int fh_pool_set_pair_rule(fh_pool* pool, const fh_pair_rule* rule);
+/* fh_set_unknown_grid_device for every device of the pool: `flags` is HOST memory here (dims[0] * dims[1] * dims[2] bytes, x fastest);
+ * each device gets its own copy (synchronous).  flags = NULL: no unknown grid. */
+struct fh_voxel_grid;
+int fh_pool_set_unknown_grid(fh_pool* pool, const struct fh_voxel_grid* grid, const unsigned char* flags);
 /* fh_solve_batch over the pool (host pointers, synchronous).  The result blocks are gathered into `results` (host, may be NULL)
  * and/or into `d_results_root`, n records in the memory of pool device number `root`, with peer copies over xGMI
  * (hipMemcpyPeerAsync) — for a consumer that lives on that GPU.  At least one destination must be given. */

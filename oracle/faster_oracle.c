@@ -976,6 +976,11 @@ void orc_control_points(const fh_result* res, int n, int n_seg, double* cp) {
   for (int i = 0; i < n; i++) control_points_one(res + i, n_seg, cp + (size_t)i * n_seg * 12);
 }
 
+void orc_dt_initial_batch(const fh_problem* pr, int n, double* dt) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) dt[i] = orc_dt_initial(pr + i);
+}
+
 void orc_default_params(fh_params* p) {
   p->feas_tol = 1e-9;
   p->dep_tol = 1e-10;

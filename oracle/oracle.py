@@ -44,6 +44,7 @@ def lib():
         L.orc_bruteforce_dt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
         L.orc_sample.restype = ctypes.c_int
         L.orc_sample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_dt_initial_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_control_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.orc_sizeof_problem.restype = ctypes.c_size_t
         L.orc_sizeof_result.restype = ctypes.c_size_t
@@ -58,6 +59,13 @@ def _params(params):
 def dt_initial(problem):
     pr = np.ascontiguousarray(problem).reshape(1)
     return lib().orc_dt_initial(abi.ptr(pr))
+
+
+def dt_initial_batch(problems):
+    pr = np.ascontiguousarray(problems)
+    dt = np.zeros(pr.shape[0], dtype=np.float64)
+    lib().orc_dt_initial_batch(abi.ptr(pr), pr.shape[0], abi.ptr(dt))
+    return dt
 
 
 def solve_batch(problems, faces, params=None, threads=None):

@@ -99,14 +99,24 @@ def device_replans(cloud, cells, center, starts, vels, goals, flags, origin, dim
                "counts": d_counts.cpu().numpy(), "k": d_k.cpu().numpy(),
                "plans": d_plans.cpu().numpy().view(abi.state_dtype).reshape(B, max_states).copy(), "snp": d_snp.cpu().numpy(),
                "spaths": d_spaths.cpu().numpy(), "paths": d_paths.cpu().numpy(), "sfaces": d_sf.cpu().numpy().view(abi.face_dtype).reshape(B, fpp).copy()}
-        # rule mode 2 without a grid, and in the fused kernel, is refused loudly
+        # rule mode 2 without a grid is refused loudly, by the staged entry points and by the fused pair kernel
+        d_wr2, d_sr2, d_sf2, d_safe2 = torch.zeros_like(d_wr), torch.zeros_like(d_sr), torch.zeros_like(d_sf), _dev(tmpl)
         ctx.set_unknown_grid_device(None)
         with pytest.raises(capi.FasterHipError):
             ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5, max_states, d_plans.data_ptr(),
                                     d_counts.data_ptr(), d_k.data_ptr())
-        ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, P["res"], dims)
         with pytest.raises(capi.FasterHipError):
-            ctx.solve_pairs_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, 0.5, 0.0, 3, d_wr.data_ptr(), d_safe.data_ptr(), d_sf.data_ptr(), d_sr.data_ptr())
+            ctx.solve_pairs_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, 0.5, 0.0, 3, d_wr2.data_ptr(), d_safe2.data_ptr(), d_sf2.data_ptr(), d_sr2.data_ptr())
+        # [r5] the FUSED pair kernel with the same unknown voxels (rule mode 2 inside the one launch: whole solve -> H, R, "is a safe
+        # trajectory needed" as the reference decides them -> safe solve in the polytopes of the whole corridor from the one that holds R)
+        ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, P["res"], dims)
+        ctx.set_pair_margin(0.0)
+        ctx.solve_pairs_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, 0.5, 0.0, max_poly, d_wr2.data_ptr(), d_safe2.data_ptr(), d_sf2.data_ptr(), d_sr2.data_ptr())
+        ctx.sync()
+        ctx.set_pair_margin(-1.0)
+        out.update({"fused_wres": d_wr2.cpu().numpy().view(abi.result_dtype).copy(), "fused_sres": d_sr2.cpu().numpy().view(abi.result_dtype).copy(),
+                    "fused_safe": d_safe2.cpu().numpy().view(abi.problem_dtype).copy(), "fused_sfaces": d_sf2.cpu().numpy().view(abi.face_dtype).copy(),
+                    "fused_kernel": ctx.last_launch()[1]})
         dm, og = vmap.dims()
     finally:
         vmap.close()
@@ -246,6 +256,41 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
         mine = np.concatenate([got["pos"], got["vel"], got["accel"], got["jerk"]], axis=1)
         worst = max(worst, float(np.abs(mine - s["plan"]).max()))
     assert worst < 1e-9, worst
+    # [r5] the fused pair kernel with unknown space as an input: the whole results of the staged launch bit for bit; per pair the
+    # reference's decisions as the caller's restatement takes them — a safe trajectory is needed (H exists) exactly where the stub says so,
+    # and R (the state that becomes x0 of the safe problem: pos, vel, accel) is the staged chain's R (to 1e-12), which the committed
+    # plans above tie to the stub's k_safe — and the safe solves equal the oracle on the problems the kernel wrote
+    from oracle import oracle as orc
+
+    fw, fs, fsafe = dv["fused_wres"], dv["fused_sres"], dv["fused_safe"]
+    assert dv["fused_kernel"] == "fh::solve_kernel<6, true, 2>", dv["fused_kernel"]
+    for f in (n for n in abi.result_dtype.names if n not in ("nodes", "qp_iters", "kflops")):
+        assert np.array_equal(fw[f], dv["wres"][f]), f
+    fused_need = fsafe["n_seg"] > 0
+    n_need = n_same_r = 0
+    for i, s in enumerate(st):
+        if s["stage"] in (1, 2):
+            assert not fused_need[i], i                       # no whole trajectory: nothing to hand over
+            continue
+        if not s["needed_safe"]:
+            assert not fused_need[i], (i, "the stub needs no safe trajectory here")
+            continue
+        n_need += 1
+        if need_safe[i]:                                      # (the staged chain wrote a safe problem: its x0 is R)
+            assert fused_need[i], (i, "the stub needs a safe trajectory here")
+            # (1e-12: another sample k would move R by a whole step of the trajectory; the two kernels may contract multiply-adds differently)
+            assert np.allclose(fsafe["x0"][i], dv["safe"]["x0"][i], rtol=0, atol=1e-12), (i, fsafe["x0"][i], dv["safe"]["x0"][i])
+            n_same_r += 1
+    assert n_need > 0.15 * B and n_same_r > 0.9 * n_need, (n_need, n_same_r)
+    orc.build()
+    live = np.nonzero(fused_need)[0]
+    ref = orc.solve_batch(fsafe[live], dv["fused_sfaces"])
+    for f in ("solved", "trials", "factor", "dt", "status"):
+        assert np.array_equal(fs[f][live], ref[f]), f
+    oks = ref["solved"] == 1
+    np.testing.assert_allclose(fs["cost"][live][oks], ref["cost"][oks], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(fs["coeff"][live][oks], ref["coeff"][oks], rtol=0, atol=1e-6)
+    print("fused pair kernel, rule mode 2: %d pairs need a safe trajectory, R identical in %d, %d safe problems solved" % (n_need, n_same_r, int(oks.sum())))
     # getNextGoal on the committed plans (faster.cpp:699-723: front(), pop_front() while more than one state is left): calls 1, 8 and 5008
     called = 0
     for (g, cur, okg), ticks in zip(dv["next_goals"], (1, 7, 5000)):

@@ -1,0 +1,83 @@
+"""GPU tests added in round 5 (all through the C ABI): the time allocation on its own entry point at a scale where the single-precision
+starting points of its root finder would show (fh_dt_initial_batch), trials refuted at y = 0 by the jerk box, rule mode 2 inside the
+fused pair kernel."""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (before libfasterhip.so is loaded: one HIP runtime per process)
+
+from faster_amd import abi, capi, corridor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _dt_problems(n, rng, kind):
+    pr = np.zeros(n, dtype=abi.problem_dtype)
+    pr["n_seg"] = rng.choice([3, 6, 10, 15, 16], n)
+    pr["dc"] = 0.01
+    pr["v_max"] = rng.choice([1.5, 3.0, 5.0, 20.0], n)
+    pr["a_max"] = rng.choice([2.0, 3.0, 5.0, 9.0], n)
+    pr["j_max"] = rng.choice([1.0, 5.0, 8.0, 30.0], n)
+    pr["f_init"], pr["f_final"], pr["f_inc"] = 1.0, 10.0, 1.0
+    x0 = np.zeros((n, 9))
+    xf = np.zeros((n, 9))
+    x0[:, :3] = rng.uniform(-20, 20, (n, 3))
+    xf[:, :3] = x0[:, :3] + rng.uniform(-12, 12, (n, 3)) * rng.choice([1.0, 1.0, 0.1, 1e-3], (n, 1))
+    x0[:, 3:6] = rng.uniform(-1, 1, (n, 3)) * pr["v_max"][:, None]
+    x0[:, 6:9] = rng.uniform(-1, 1, (n, 3)) * pr["a_max"][:, None]
+    if kind == "rest":          # FASTER's usual start of a mission and every goal: zero velocity and acceleration
+        x0[:, 3:] = 0.0
+    elif kind == "axis":        # nothing to do on some axes (dx = 0 exactly), or only a velocity / only an acceleration
+        m = rng.random((n, 3)) < 0.5
+        xf[:, :3] = np.where(m, x0[:, :3], xf[:, :3])
+        x0[:, 3:6] *= rng.random((n, 3)) < 0.5
+        x0[:, 6:9] *= rng.random((n, 3)) < 0.5
+    elif kind == "scale":       # kilometres and millimetres
+        s = rng.choice([1e3, 1e-3, 1e-6], (n, 1))
+        xf[:, :3] = x0[:, :3] + (xf[:, :3] - x0[:, :3]) * s
+    elif kind == "close":       # cubics with two roots at a relative distance eps (and a third one elsewhere): the constant-jerk cubic
+        j = pr["j_max"].astype(np.float32).astype(np.float64) / 6.0   # (j / 6)(t - t1)(t - t2)(t - t3) with dx > 0
+        t1 = rng.uniform(0.2, 4.0, (n, 3))
+        eps = 10.0 ** rng.uniform(-9, -2, (n, 3))
+        t2 = t1 * (1.0 + eps)
+        t3 = rng.uniform(0.2, 6.0, (n, 3)) * rng.choice([1.0, -1.0], (n, 3))
+        neg = t3 < 0                                 # dx = (j / 6) t1 t2 t3 must be positive: flip the pair with the third root
+        t1, t2 = np.where(neg, -t1, t1), np.where(neg, -t2, t2)
+        x0[:, 6:9] = -2.0 * j[:, None] * (t1 + t2 + t3)
+        x0[:, 3:6] = j[:, None] * (t1 * t2 + t1 * t3 + t2 * t3)
+        xf[:, :3] = x0[:, :3] + j[:, None] * (t1 * t2 * t3)
+    pr["x0"], pr["xf"] = x0, xf
+    return pr
+
+
+def test_time_allocation_alone_on_two_million_problems(ctx, oracle):
+    """Row a5 — getDTInitial (solverGurobi.cpp:659-759) through its own entry point, where a difference could not hide behind a solve:
+    the device finds the roots from single-precision starting points polished in double (fh_solve.hip.hpp: dt_initial) and falls back
+    to the oracle's closed forms when two roots are close; the value is stored as a float by the reference.  Bit-identical to the
+    oracle on 2 M problems of four kinds (generic states, at rest, idle axes, kilometres / micrometres).  Cubics BUILT with two roots
+    at relative distances 1e-9 .. 1e-2 — where the root itself is only defined to ~1e-8 by either library's cbrt / acos — must agree to
+    the float the reference stores (2 ulp), and nearly all of them exactly."""
+    rng = np.random.default_rng(505)
+    n = 1 << 19
+    for kind in ("generic", "rest", "axis", "scale"):
+        pr = _dt_problems(n, rng, kind)
+        got, ref = ctx.dt_initial_batch(pr), oracle.dt_initial_batch(pr)
+        bad = np.nonzero(got != ref)[0]
+        assert len(bad) == 0, (kind, len(bad), got[bad[:4]], ref[bad[:4]], pr["x0"][bad[:2]], pr["xf"][bad[:2]])
+        assert (ref > 0).mean() > 0.9
+    pr = _dt_problems(n, rng, "close")
+    got, ref = ctx.dt_initial_batch(pr), oracle.dt_initial_batch(pr)
+    np.testing.assert_allclose(got, ref, rtol=2.5e-7, atol=0)
+    assert (got == ref).mean() > 0.999, (got != ref).sum()
+    # and inside a solve: dt = factor * max(dt_initial, 2 dc) of the first trial, bit for bit
+    w, faces, _ = corridor.whole_batch(512, seed=11, n_seg=10, p_choices=(2, 3))
+    res = ctx.solve_batch(w, faces)
+    d0 = np.maximum(oracle.dt_initial_batch(w), 2 * w["dc"])
+    ok = res["solved"] == 1
+    assert ok.sum() > 400 and np.array_equal(res["dt"][ok], res["factor"][ok] * d0[ok])
