@@ -510,6 +510,7 @@ struct Solver {
   double box_ub;          // 3N j_max^2 (1 + 1e-9): no feasible trajectory costs more
   double gx2;             // |normal in jerk space|^2 of the row build_g built last
   int maxF;  // max faces of one polytope of this problem (wave-uniform trip count of the face sweeps)
+  int scan_trip;  // max faces of a polytope that a segment is ASSIGNED to in this active-set run (bind_assignment): the scan's trip count
   unsigned poly_ok;  // polytopes without a violated zero-normal face (such a polytope can never hold a segment)
 #ifdef FH_PROFILE
   unsigned long long prof[24];   // 0-15: see scripts/phase_profile.py; 16 look-around + donations, 17 result write, 18 hand-off of the pair (charged to
@@ -884,6 +885,20 @@ struct Solver {
       v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xf, 0xf, true);
       rows4 = __builtin_amdgcn_readlane(v, 63);
     }
+#ifndef FH_NO_SCAN_TRIP  // the trip count of this run's face sweeps: the longest row list any lane scans (0 at a root with no segment assigned)
+    {
+      int m = scan_F;
+      m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, true));
+      m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, true));
+      m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, true));
+      m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, true));
+      m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xf, 0xf, true));
+      m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xf, 0xf, true));
+      scan_trip = __builtin_amdgcn_readlane(m, 63);
+    }
+#else
+    scan_trip = maxF;
+#endif
   }
 
   // ---- most violated inactive inequality row; violation relative to the row norm. id<0: none. ----
@@ -925,7 +940,7 @@ struct Solver {
       double bvt = (F > 0) ? 0.0 : INFINITY;  // dead lanes never take
       const int fl = F > 0 ? F - 1 : 0;        // rows beyond the lane's polytope re-read its last row: never a strict improvement
       const fh_face* fp = faces + f0;
-      for (int fb = 0; fb < maxF; fb += 4) {
+      for (int fb = 0; fb < scan_trip; fb += 4) {
         fh_face fc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) fc[j] = fp[min(fb + j, fl)];  // the four loads in flight before the first use
