@@ -422,6 +422,43 @@ int fh_map_plan_batch(fh_map* m, const double* starts, const double* goals, int 
   FM_HIP(hipMemcpyAsync(n_points, m->d_stage[3], 4 * (size_t)n, hipMemcpyDeviceToHost, m->stream));
   if (expansions) FM_HIP(hipMemcpyAsync(expansions, m->d_stage[4], 8 * (size_t)n, hipMemcpyDeviceToHost, m->stream));
   FM_HIP(hipStreamSynchronize(m->stream));
+  // Records chosen by the size of the map (fh_map_set_records -1) may be a hashed table, and a query that reaches more cells than the
+  // table holds — an unreachable goal on a big map — ends at that limit (-2) where per-cell records would have answered "no path" or
+  // found one.  This entry point is synchronous anyway: such queries are run again with one record per cell (fewer wavefronts; the
+  // workspace is rebuilt, which costs far more than the queries — it is the rare case).  The device-pointer entry point reports -2.
+  if (m->record_slots < 0 && m->search_mode == 1 && m->ws_slots > 0) {
+    std::vector<int> again;
+    for (int i = 0; i < n; i++)
+      if (n_points[i] == -2) again.push_back(i);
+    if (!again.empty()) {
+      const int k = (int)again.size();
+      std::vector<double> q((size_t)6 * k);
+      for (int j = 0; j < k; j++)
+        for (int c = 0; c < 3; c++) {
+          q[(size_t)3 * j + c] = starts[(size_t)3 * again[j] + c];
+          q[(size_t)3 * (k + j) + c] = goals[(size_t)3 * again[j] + c];
+        }
+      m->record_slots = 0;
+      FM_HIP(hipMemcpyAsync(d_q, q.data(), sizeof(double) * 6 * (size_t)k, hipMemcpyHostToDevice, m->stream));
+      rc = fh_map_plan_batch_device(m, d_q, d_q + 3 * (size_t)k, k, max_points, max_vertex_dist, max_poly, (double*)m->d_stage[2],
+                                    (int32_t*)m->d_stage[3], (int64_t*)m->d_stage[4]);
+      m->record_slots = -1;
+      if (rc != FH_OK) return rc;
+      std::vector<double> pp((size_t)3 * k * max_points);
+      std::vector<int32_t> np((size_t)k);
+      std::vector<int64_t> ex((size_t)k);
+      FM_HIP(hipMemcpyAsync(pp.data(), m->d_stage[2], sizeof(double) * pp.size(), hipMemcpyDeviceToHost, m->stream));
+      FM_HIP(hipMemcpyAsync(np.data(), m->d_stage[3], 4 * (size_t)k, hipMemcpyDeviceToHost, m->stream));
+      FM_HIP(hipMemcpyAsync(ex.data(), m->d_stage[4], 8 * (size_t)k, hipMemcpyDeviceToHost, m->stream));
+      FM_HIP(hipStreamSynchronize(m->stream));
+      for (int j = 0; j < k; j++) {
+        const int i = again[j];
+        std::memcpy(paths + (size_t)3 * i * max_points, pp.data() + (size_t)3 * j * max_points, sizeof(double) * 3 * (size_t)max_points);
+        n_points[i] = np[j];
+        if (expansions) expansions[i] = ex[j];
+      }
+    }
+  }
   return FH_OK;
 }
 

@@ -52,11 +52,15 @@ __device__ inline P3 sphere_crossing(P3 a_in, P3 b_in, double r, P3 c) {
 constexpr int SAFE_PATH_CAP = 40;
 
 // Distance from p to the nearest unknown voxel centre of the caller's grid (rule mode 2) — what `kdtree_unk_.nearestKSearch(p, 1, ...)`
-// returns in getFirstCollisionJPS (faster.cpp:806-812), exactly: the minimum of dx^2 + dy^2 + dz^2 over the unknown voxels, then the
-// square root.  The whole wavefront searches cubes of cells around p's cell, lane = cell; a cube of half-width w has seen every voxel
+// returns in getFirstCollisionJPS (faster.cpp:806-812): the minimum of dx^2 + dy^2 + dz^2 over the unknown voxels, then the square
+// root — exact in DOUBLE precision; the reference's kd-tree holds pcl::PointXYZ, i.e. single-precision points and a float d2 (:797-812).  The whole wavefront searches cubes of cells around p's cell, lane = cell; a cube of half-width w has seen every voxel
 // closer than (w + 1/2) res, so the search ends when the best distance found is inside that bound (or the cube covers the grid).
 // INFINITY: the grid has no unknown voxel (the reference's kd-tree is empty: the path is returned as it was).
-__device__ inline double nearest_unknown(const UnknownGrid& ug, P3 p, int lane) {
+// cap: the caller only asks whether the distance is below `cap` and, if so, what it is (the march of getFirstCollisionJPS: a clear
+// sphere that holds every remaining vertex of the path ends it whatever its radius).  Once a cube proves that every unknown voxel is
+// farther than cap, a value above cap is returned instead of the exact distance — a sparse or empty unknown grid no longer makes every
+// vertex of every pair scan the whole lattice.
+__device__ inline double nearest_unknown(const UnknownGrid& ug, P3 p, int lane, double cap = INFINITY) {
   if (!ug.flags) return INFINITY;
   const int cx = (int)floor((p.x - ug.ox) / ug.res), cy = (int)floor((p.y - ug.oy) / ug.res), cz = (int)floor((p.z - ug.oz) / ug.res);
   const int wmax = max(max(max(cx, ug.nx - 1 - cx), max(cy, ug.ny - 1 - cy)), max(max(cz, ug.nz - 1 - cz), 0));  // covers the grid
@@ -81,6 +85,7 @@ __device__ inline double nearest_unknown(const UnknownGrid& ug, P3 p, int lane) 
     for (int o = 32; o > 0; o >>= 1) best = fmin(best, __shfl_xor(best, o));
     const double d = sqrt(best);
     if (w >= wmax || d <= ((double)w + 0.5) * ug.res) return d;
+    if (((double)w + 0.5) * ug.res > cap) return fmin(d, 1e300);  // every unknown voxel is farther than cap: all the caller asks
     // next cube: wide enough to prove the candidate (or twice as wide when there is none yet)
     const int need = best < INFINITY ? (int)ceil(d / ug.res) : 2 * w + 1;
     w = min(max(need, w + 1), wmax);
@@ -173,7 +178,10 @@ __global__ void __launch_bounds__(64) safe_path_kernel(const fh_problem* __restr
         while (nc > 0) {
           double r;
           if (rule.mode == 2) {
-            r = nearest_unknown(ug, cur[0], lane);
+            double cap = rule.drone_radius;  // below drone_radius the distance decides the cut; beyond the farthest remaining vertex a
+                                             // clear sphere holds them all and ends the march (sphere_exit: none_outside)
+            for (int i = 1; i < nc; i++) cap = fmax(cap, dist3(cur[i], cur[0]));
+            r = nearest_unknown(ug, cur[0], lane, cap);
             if (!(r < INFINITY)) break;
           } else {
             r = rule.r_known - dist3(cur[0], A);

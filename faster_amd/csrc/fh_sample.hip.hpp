@@ -139,7 +139,10 @@ struct UnknownGrid {
   int nx, ny, nz, pad;
 };
 // Is an unknown voxel centre closer than `radius` to p?  What `kdtree_unk_.nearestKSearch(p, 1, ...)` followed by `sqrt(d2) < radius`
-// decides in findIndexH (faster.cpp:236-240).  One lane, the cells around p's own.
+// decides in findIndexH (faster.cpp:236-240) — evaluated in DOUBLE precision against double voxel centres.  The reference searches a
+// pcl::PointXYZ cloud: its query point, its voxel centres and d2 are single precision (faster.cpp:233-238); for a sample within float
+// rounding (~1e-7 relative) of `radius` from a voxel centre the two can decide differently.  oracle/pair_glue.py shares the double model.
+// One lane, the cells around p's own.
 __device__ inline bool unknown_within(const UnknownGrid& ug, double px, double py, double pz, double radius) {
 #pragma clang fp contract(off)
   if (!ug.flags || !(radius > 0)) return false;

@@ -488,7 +488,11 @@ int fh_map_set_search(fh_map* map, int mode);
  * n_points = -2 (raise slots, or use 0).  The same reads and writes in the same order either way: identical paths.
  * slots = -1 (default): per-cell records while the 48 GB workspace budget holds them for at least half of the wavefronts (faster on
  * small maps: 54 vs 66 ms for 65536 queries in 181 500 cells — and without a limit on the cells a query may reach), else 131072
- * hashed slots (1 452 000 cells: 298 ms and 6.5 GB with 32768 slots against 476 ms and 51.5 GB).
+ * hashed slots (1 452 000 cells: 298 ms and 6.5 GB with 32768 slots against 476 ms and 51.5 GB).  With the default, a query that ends
+ * at the table's limit (an unreachable goal on a big map reaches more cells than 3/4 of 131072) is run AGAIN with per-cell records by
+ * the host-pointer entry point fh_map_plan_batch (synchronous anyway; the workspace is rebuilt twice: the rare case), so that "no path"
+ * (0) and a path come out as with slots = 0; fh_map_plan_batch_device is asynchronous and reports -2 for such a query — the caller
+ * decides (fh_map_set_records(map, 0) and plan those queries again).
  * The A* search (mode 0) always uses per-cell records.
  * fh_map_workspace_bytes: size of the search workspace as allocated by the last search (0 before the first). */
 int fh_map_set_records(fh_map* map, int slots);

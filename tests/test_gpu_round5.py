@@ -94,3 +94,56 @@ def test_time_allocation_alone_on_two_million_problems(ctx, oracle):
     d0 = np.maximum(oracle.dt_initial_batch(w), 2 * w["dc"])
     ok = res["solved"] == 1
     assert ok.sum() > 400 and np.array_equal(res["dt"][ok], res["factor"][ok] * d0[ok])
+
+
+def test_unreachable_goals_on_a_big_map_with_the_default_records():
+    """with the records chosen by the size of the map (fh_map_set_records -1) a 1.4 M-cell map searches with a hashed table of
+    131072 slots per wavefront, and a query that reaches more cells than the table holds ends at that limit (n_points -2).  A goal sealed
+    inside a shell of obstacle points is such a query: the jump point search has to exhaust the forest.  The host-pointer entry point
+    runs those queries again with one record per cell, so that its answers are those of fh_map_set_records(0) — "no path" (0), as jps3d
+    answers (graph_search.cpp:219-221: the open set runs empty) — and every other query is untouched; the asynchronous device-pointer
+    entry point reports -2 for them."""
+    import torch
+
+    from faster_amd import frontend
+
+    res, infl, zmax = 0.2, 0.3, 20.0                   # a forest 20 m tall: 110 x 110 x 100 cells, and three dimensions to exhaust
+    cloud, cells, center, starts, goals, rng = frontend.forest_queries(48, 29, size=(20.0, 20.0, zmax), res=res, inflation=infl, return_rng=True)
+    sealed = np.arange(0, 48, 8)                        # six goals inside a closed shell (radius 1.1 m, far outside the cube freed around a goal)
+    shell = []
+    for i in sealed:
+        goals[i] = [10.0 + 0.5 * (i // 8), 10.0, 10.0]
+        v = rng.normal(size=(6000, 3))
+        shell.append(goals[i] + 1.1 * v / np.linalg.norm(v, axis=1, keepdims=True))
+    cloud = np.concatenate([cloud] + shell)
+    far = np.linalg.norm(starts[:, None, :] - goals[sealed][None, :, :], axis=2).min(axis=1) > 2.5
+    starts[~far] = [1.0, 1.0, 15.0]                     # no start inside a shell
+    m = capi.Map(0)
+    try:
+        m.set_search("jps")
+        m.read(cloud, cells, res, center, 0.0, zmax, infl)
+        assert np.prod(m.dims()[0]) > 1_000_000
+        m.set_records(0)
+        want = m.plan_batch(starts, goals)              # one record per cell: no limit on the cells a query reaches
+        assert np.all(want[1][sealed] == 0) and (want[1] >= 2).sum() >= 36, want[1]
+        dense_bytes = m.workspace_bytes()
+        m.set_records(-1)                               # the default
+        d_s, d_g = torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda()
+        d_p = torch.zeros((48, 64, 3), dtype=torch.float64, device="cuda:0")
+        d_n = torch.zeros(48, dtype=torch.int32, device="cuda:0")
+        d_e = torch.zeros(48, dtype=torch.int64, device="cuda:0")
+        m.plan_batch_device(d_s.data_ptr(), d_g.data_ptr(), 48, 64, d_p.data_ptr(), d_n.data_ptr(), d_e.data_ptr())
+        m.sync()
+        dev_n = d_n.cpu().numpy()
+        hashed = m.workspace_bytes() < 0.8 * dense_bytes
+        if not (hashed and (dev_n == -2).any()):
+            pytest.skip("the default did not choose a hashed table that these queries overflow (workspace %.1f GB, n_points of the sealed goals %s)"
+                        % (m.workspace_bytes() / 1e9, dev_n[sealed]))
+        assert set(np.nonzero(dev_n == -2)[0]) <= set(sealed)
+        got = m.plan_batch(starts, goals)               # host pointers: the queries at the limit are run again with per-cell records
+        assert np.array_equal(got[1], want[1]), (got[1], want[1])
+        assert np.array_equal(got[2], want[2])          # the same nodes popped
+        for i in np.nonzero(want[1] > 0)[0]:
+            assert np.array_equal(got[0][i, :want[1][i]], want[0][i, :want[1][i]]), i
+    finally:
+        m.close()
