@@ -74,7 +74,7 @@ sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("ba
 assert sched_dtype.itemsize == 32
 
 launch_info_dtype = np.dtype([("n_seg", "<i4"), ("pairs", "<i4"), ("waves_per_simd", "<i4"), ("grid", "<i4"), ("workgroups_per_cu", "<i4"),
-                              ("lds_bytes", "<i4")])
+                              ("lds_bytes", "<i4"), ("unknown_space", "<i4"), ("reserved", "<i4")])
 
 
 voxel_grid_dtype = np.dtype([("origin", "<f8", (3,)), ("res", "<f8"), ("dims", "<i4", (3,)), ("reserved", "<i4")])

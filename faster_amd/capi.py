@@ -519,7 +519,8 @@ class Context:
         info = np.zeros(1, dtype=abi.launch_info_dtype)
         self._check(lib().fh_last_launch(self._h, abi.ptr(info)), "fh_last_launch")
         d = {k: int(info[0][k]) for k in info.dtype.names}
-        return d, "fh::solve_kernel<%d, %s, %d>" % (d["n_seg"], "true" if d["pairs"] else "false", d["waves_per_simd"])
+        return d, "fh::solve_kernel<%d, %s, %d, %s>" % (d["n_seg"], "true" if d["pairs"] else "false", d["waves_per_simd"],
+                                                      "true" if d["unknown_space"] else "false")
 
     # ---- host-pointer entry points (numpy in, numpy out) ----
     def dt_initial_batch(self, problems):

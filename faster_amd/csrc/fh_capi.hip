@@ -49,7 +49,7 @@ struct fh_ctx {
   bool ctl_ready = false;                   // the device-side control block is in its initial state (left so by the previous launch)
   bool launched = false;                    // a solve launch has been issued since the control block was last checked
   int last_grid = 0;
-  fh_launch_info last_launch = {0, 0, 0, 0, 0, 0};  // fh_last_launch
+  fh_launch_info last_launch = {0, 0, 0, 0, 0, 0, 0, 0};  // fh_last_launch
   bool order_ready = false;                 // the launch-order counters are zero (left so by the previous scatter kernel)
 };
 
@@ -129,7 +129,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     lds_launch = std::max(lds, (size_t)(160 * 1024) / (size_t)per_cu / 1280 * 1280 - 16);
   }
   const int resident = ctx->n_cu * per_cu;
-  ctx->last_launch = {NSEG, PAIRS ? 1 : 0, two_waves ? 2 : FH_WAVES_PER_SIMD, 0, per_cu, (int32_t)lds_launch};
+  ctx->last_launch = {NSEG, PAIRS ? 1 : 0, two_waves ? 2 : FH_WAVES_PER_SIMD, 0, per_cu, (int32_t)lds_launch, unk ? 1 : 0, 0};
   const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;
   // small batches get helper workgroups (one per CU) that take over subtrees of hard problems
   const int grid = share ? std::min(resident, std::max(n, ctx->n_cu)) : std::min(resident, n);

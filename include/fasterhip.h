@@ -523,12 +523,12 @@ int fh_timing_read(fh_ctx* ctx, double* ms, int cap);
 double fh_last_kernel_ms(fh_ctx* ctx);
 
 /* Which solve kernel the most recent solve launch of the context ran, as the profiler names it:
- * fh::solve_kernel<n_seg, pairs, waves_per_simd> — the instantiation (6 / 10 / 15 / 16 segments), the fused pair form, and the build
- * (3 = three wavefronts per SIMD, 168 registers; 2 = two, all registers: fh_sched.workgroups_per_cu) — with its grid, the resident
- * solves per CU and the LDS bytes per workgroup.  Measurement only (bench.py matches its rocprofv3 summaries by this name);
+ * fh::solve_kernel<n_seg, pairs, waves_per_simd, unknown_space> — the instantiation (6 / 10 / 15 / 16 segments), the fused pair form, the
+ * build (3 = three wavefronts per SIMD, 168 registers; 2 = two, all registers: fh_sched.workgroups_per_cu) and whether the hand-off asks
+ * the caller's unknown voxels (fh_pair_rule mode 2) — with its grid, the resident solves per CU and the LDS bytes per workgroup.  Measurement only (bench.py matches its rocprofv3 summaries by this name);
  * returns FH_ERR_ARG before the first launch. */
 typedef struct fh_launch_info {
-  int32_t n_seg, pairs, waves_per_simd, grid, workgroups_per_cu, lds_bytes;
+  int32_t n_seg, pairs, waves_per_simd, grid, workgroups_per_cu, lds_bytes, unknown_space, reserved;
 } fh_launch_info;
 int fh_last_launch(const fh_ctx* ctx, fh_launch_info* out);
 

@@ -263,7 +263,7 @@ def test_device_replan_chain_equals_the_stub_with_unknown_space_as_an_input(tmp_
     from oracle import oracle as orc
 
     fw, fs, fsafe = dv["fused_wres"], dv["fused_sres"], dv["fused_safe"]
-    assert dv["fused_kernel"] == "fh::solve_kernel<6, true, 2>", dv["fused_kernel"]
+    assert dv["fused_kernel"] == "fh::solve_kernel<6, true, 2, true>", dv["fused_kernel"]
     for f in (n for n in abi.result_dtype.names if n not in ("nodes", "qp_iters", "kflops")):
         assert np.array_equal(fw[f], dv["wres"][f]), f
     fused_need = fsafe["n_seg"] > 0
