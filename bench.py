@@ -790,13 +790,34 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
             timed("safe_solve", lambda: ctx.solve_batch_device(d_safe.data_ptr(), d_sf2.data_ptr(), B, N, fpp2, d_sr.data_ptr()), ctx.sync)
             timed("append_plans", lambda: ctx.append_plans_device(d_whole.data_ptr(), d_wr.data_ptr(), d_safe.data_ptr(), d_sr.data_ptr(), B, 0.5,
                                                                   max_states, d_plans.data_ptr(), d_counts.data_ptr(), d_k.data_ptr()), ctx.sync)
-        stages = stages_sphere
-        sres2, safe2, counts2 = d_sr.cpu().numpy().view(abi.result_dtype), d_safe.cpu().numpy().view(abi.problem_dtype), d_counts.cpu().numpy()
+        sres2, safe2, counts2 = d_sr.cpu().numpy().view(abi.result_dtype).copy(), d_safe.cpu().numpy().view(abi.problem_dtype).copy(), d_counts.cpu().numpy().copy()
         need2 = safe2["n_seg"] > 0
+        # [r5] the same decisions inside ONE launch: the fused pair kernel with rule mode 2 (whole solve -> H, R and "is a safe trajectory
+        # needed" against the unknown voxels -> safe solve in the polytopes of the whole corridor from the one that holds R; the corridor
+        # decomposed around R stays the staged path above)
+        stages2["fused_whole_handoff_safe"] = []
+        d_wr3, d_sr3, d_safe3, d_sf3 = torch.zeros_like(d_wr), torch.zeros_like(d_sr), torch.zeros_like(d_tmpl), torch.zeros_like(d_wf)
+        ctx.set_pair_margin(0.0)
+        for _ in range(reps + 1):
+            d_safe3.copy_(d_tmpl)
+            timed("fused_whole_handoff_safe", lambda: ctx.solve_pairs_device(d_whole.data_ptr(), d_wf.data_ptr(), B, N, fpp, 0.5, 0.0, max_poly, d_wr3.data_ptr(),
+                                                                             d_safe3.data_ptr(), d_sf3.data_ptr(), d_sr3.data_ptr()), ctx.sync)
+        ctx.set_pair_margin(-1.0)
+        fused_kernel = ctx.last_launch()[1]
+        safe3, sres3 = d_safe3.cpu().numpy().view(abi.problem_dtype), d_sr3.cpu().numpy().view(abi.result_dtype)
+        need3 = safe3["n_seg"] > 0
+        both = need2 & need3
+        stages = stages_sphere
         med2 = {k: float(np.median(v[1:])) for k, v in stages2.items()}
         unknown_input = {"unknown_voxel_frac": float((~seen).mean()), "stages_ms": med2, "pairs_needing_a_safe_trajectory": int(need2.sum()),
                          "safe_solved_frac": float(sres2["solved"][need2].mean()) if need2.any() else None,
                          "plans_committed_frac": float((counts2 > 0).mean()),
+                         "fused": {"kernel": fused_kernel, "ms": med2["fused_whole_handoff_safe"], "pairs_needing_a_safe_trajectory": int(need3.sum()),
+                                   "same_r_as_the_staged_chain": float(np.all(np.abs(safe3["x0"][both] - safe2["x0"][both]) <= 1e-12, axis=1).mean()) if both.any() else None,
+                                   "safe_solved_frac": float(sres3["solved"][need3].mean()) if need3.any() else None,
+                                   "note": "fh_solve_pairs_device with rule mode 2: whole solve + hand-off + safe solve of all pairs in one launch "
+                                           "(stages_ms.fused_whole_handoff_safe) — against whole_solve above + safe_corridor + safe_solve of the staged "
+                                           "chain; its safe corridor is the run of polytopes of the whole corridor from the one that holds R"},
                          "note": "fh_set_unknown_grid_device + fh_pair_rule mode 2: findIndexH and the march of getFirstCollisionJPS ask for the "
                                  "nearest unknown voxel of the grid (exact, as the reference's kd-tree), the safe corridor is decomposed against "
                                  "[unknown voxels | occupied points]; map, paths and whole solves as above"}
