@@ -495,6 +495,33 @@ struct Solver {
                           //   contribution of xp (per trial)
   double xpr;             // lane = (s, i) < 3 N: jerk xp of the minimum-norm solution of the final-state equalities (per trial)
   double xj;              // lane = (s, i) < 3 N: current jerk xp + (Z y) (compute_states -> scan)
+// [r5] The inverse row norms of a lane's rows are re-read from the basis table (L1 / L2 resident) by every scan instead of living in 8
+// registers across the whole search: same values, same throughput (A/B: 19.96 / 20.00 M pairs/s), but 112 instead of 160 B of scratch
+// and 0.58 instead of 0.80 GB of HBM traffic per launch — the registers freed are registers not spilled at the scope of a problem.
+// (-DFH_NORMS_IN_REGISTERS: round 4's form.)
+#ifndef FH_NORMS_IN_REGISTERS
+#define FH_NORMS_FROM_TABLE 1
+#endif
+#ifdef FH_NORMS_FROM_TABLE
+  const double* btab;     // the basis table of this N (uniform)
+  double ih_trial;        // 1 / h of the trial (uniform)
+  // the inverse row norms of this lane's rows (reduced space) from the table, as setup_trial computes them
+  __device__ __forceinline__ void row_norms(double& wbj_, double& wbv_, double& wba_, double& wcp_) const {
+#pragma clang fp contract(off)
+    const int lane = opaque(this->lane);
+    const double* C = btab + BT_C + (force_final ? BT_C_WORDS : 0);
+    const double* CJ = btab + BT_CJ + (force_final ? BT_CJ_WORDS : 0);
+    const int t = lane < nx ? lane / 3 : 0;
+    const int tc = lane < 4 * N ? (lane >> 2) : 0, k = lane & 3;
+    const double cj_ = CJ[t], cv_ = C[W_V * BT_C_TT + t], ca_ = C[W_A * BT_C_TT + t], cc_ = C[(k == 3 ? W_P : k) * BT_C_TT + tc + (k == 3 ? 1 : 0)];
+    const double ih = ih_trial;
+    const bool box = lane < nx;
+    wbj_ = box ? cj_ : 0.0;
+    wbv_ = box ? cv_ * (ih * ih) : 0.0;
+    wba_ = box ? ca_ * ih : 0.0;
+    wcp_ = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
+  }
+#endif
   double wbj, wbv, wba, wcp;  // inverse row norms IN THE REDUCED SPACE of this lane's box rows (lane = (t, i)) and corridor rows
                           //   (lane = (t, k)); 0: the row does not depend on y (per trial)
   double bestx_r;         // lane < n: incumbent y
@@ -804,11 +831,17 @@ struct Solver {
     }
     {  // each lane keeps the inverse norms (reduced space) of the rows it scans; they scale with h^-3 (positions), h^-2, h^-1
       const double ih = 1.0 / h;
+#ifdef FH_NORMS_FROM_TABLE
+      btab = bt;
+      ih_trial = ih;
+      (void)cj_; (void)cv_; (void)ca_; (void)cc_;
+#else
       const bool box = lane < nx;
       wbj = box ? cj_ : 0.0;
       wbv = box ? cv_ * (ih * ih) : 0.0;
       wba = box ? ca_ * ih : 0.0;
       wcp = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
+#endif
     }
     FH_SYNC();  // (xs and z are rewritten in full before they are read again)
     return false;
@@ -912,6 +945,10 @@ struct Solver {
     int bid = -1;
     bool bad = false;
     bool badb = false;  // a violated box row that does not depend on y (N < 4 only; the t = 0 rows are checked before the search)
+#ifdef FH_NORMS_FROM_TABLE
+    double wbj, wbv, wba, wcp;
+    row_norms(wbj, wbv, wba, wcp);
+#endif
     if (lane < nx) {
       const int t = lane / 3, i = lane - 3 * t;
       const double xv = xj;
@@ -2266,6 +2303,10 @@ struct Solver {
                 m = (f < Fb && vt > m) ? vt : m;
               }
               double w = 0.0;
+#ifdef FH_NORMS_FROM_TABLE
+              double wcp;
+              { double a_, b_, c_; row_norms(a_, b_, c_, wcp); }
+#endif
 #pragma unroll
               for (int k2 = 0; k2 < 4; k2++) {
                 const double wk = readlane_f64(wcp, 4 * sb + k2);
