@@ -445,7 +445,10 @@ __device__ __forceinline__ double dt_initial(const PR& pr, int lane) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-template <int NSEG>
+// NORMS_TABLE: the per-lane inverse row norms are re-read from the basis table by every scan (the build for three wavefronts per SIMD:
+// eight registers that are not spilled) instead of being kept in registers from setup_trial on (the build for two: nothing spills there,
+// and the extra loads cost the N = 15 kernel 2.4 %).  The same doubles either way.
+template <int NSEG, bool NORMS_TABLE = false>
 struct Solver {
   static constexpr int NX = 3 * NSEG;        // jerks of the trajectory (x space)
   static constexpr int NXP = (NX + 7) & ~7;
@@ -495,14 +498,10 @@ struct Solver {
                           //   contribution of xp (per trial)
   double xpr;             // lane = (s, i) < 3 N: jerk xp of the minimum-norm solution of the final-state equalities (per trial)
   double xj;              // lane = (s, i) < 3 N: current jerk xp + (Z y) (compute_states -> scan)
-// [r5] The inverse row norms of a lane's rows are re-read from the basis table (L1 / L2 resident) by every scan instead of living in 8
-// registers across the whole search: same values, same throughput (A/B: 19.96 / 20.00 M pairs/s), but 112 instead of 160 B of scratch
-// and 0.58 instead of 0.80 GB of HBM traffic per launch — the registers freed are registers not spilled at the scope of a problem.
-// (-DFH_NORMS_IN_REGISTERS: round 4's form.)
-#ifndef FH_NORMS_IN_REGISTERS
-#define FH_NORMS_FROM_TABLE 1
-#endif
-#ifdef FH_NORMS_FROM_TABLE
+  // [r5] NORMS_TABLE: the inverse row norms of a lane's rows are re-read from the basis table (L1 / L2 resident) by every scan instead of
+  // living in 8 registers across the whole search: same values, same throughput in the three-wavefront build (A/B: 19.96 / 20.00 M
+  // pairs/s), but 112 instead of 160 B of scratch and 0.58 instead of 0.80 GB of HBM traffic per launch — the registers freed are
+  // registers not spilled at the scope of a problem.
   const double* btab;     // the basis table of this N (uniform)
   double ih_trial;        // 1 / h of the trial (uniform)
   // the inverse row norms of this lane's rows (reduced space) from the table, as setup_trial computes them
@@ -521,7 +520,6 @@ struct Solver {
     wba_ = box ? ca_ * ih : 0.0;
     wcp_ = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
   }
-#endif
   double wbj, wbv, wba, wcp;  // inverse row norms IN THE REDUCED SPACE of this lane's box rows (lane = (t, i)) and corridor rows
                           //   (lane = (t, k)); 0: the row does not depend on y (per trial)
   double bestx_r;         // lane < n: incumbent y
@@ -831,17 +829,16 @@ struct Solver {
     }
     {  // each lane keeps the inverse norms (reduced space) of the rows it scans; they scale with h^-3 (positions), h^-2, h^-1
       const double ih = 1.0 / h;
-#ifdef FH_NORMS_FROM_TABLE
-      btab = bt;
-      ih_trial = ih;
-      (void)cj_; (void)cv_; (void)ca_; (void)cc_;
-#else
-      const bool box = lane < nx;
-      wbj = box ? cj_ : 0.0;
-      wbv = box ? cv_ * (ih * ih) : 0.0;
-      wba = box ? ca_ * ih : 0.0;
-      wcp = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
-#endif
+      if constexpr (NORMS_TABLE) {
+        btab = bt;
+        ih_trial = ih;
+      } else {
+        const bool box = lane < nx;
+        wbj = box ? cj_ : 0.0;
+        wbv = box ? cv_ * (ih * ih) : 0.0;
+        wba = box ? ca_ * ih : 0.0;
+        wcp = (lane < 4 * N) ? cc_ * (ih * ih * ih) : 0.0;
+      }
     }
     FH_SYNC();  // (xs and z are rewritten in full before they are read again)
     return false;
@@ -945,10 +942,8 @@ struct Solver {
     int bid = -1;
     bool bad = false;
     bool badb = false;  // a violated box row that does not depend on y (N < 4 only; the t = 0 rows are checked before the search)
-#ifdef FH_NORMS_FROM_TABLE
-    double wbj, wbv, wba, wcp;
-    row_norms(wbj, wbv, wba, wcp);
-#endif
+    double wbj = this->wbj, wbv = this->wbv, wba = this->wba, wcp = this->wcp;
+    if constexpr (NORMS_TABLE) row_norms(wbj, wbv, wba, wcp);
     if (lane < nx) {
       const int t = lane / 3, i = lane - 3 * t;
       const double xv = xj;
@@ -2303,10 +2298,8 @@ struct Solver {
                 m = (f < Fb && vt > m) ? vt : m;
               }
               double w = 0.0;
-#ifdef FH_NORMS_FROM_TABLE
-              double wcp;
-              { double a_, b_, c_; row_norms(a_, b_, c_, wcp); }
-#endif
+              double wcp = this->wcp;
+              if constexpr (NORMS_TABLE) { double a_, b_, c_; row_norms(a_, b_, c_, wcp); }
 #pragma unroll
               for (int k2 = 0; k2 < 4; k2++) {
                 const double wk = readlane_f64(wcp, 4 * sb + k2);
@@ -2382,8 +2375,8 @@ __device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
 // One problem (= one genNewTraj call), from the root of its first trial (entry 0) or from a frame of one of its trees taken
 // from the queue (entry 1), until its final result is written (returns true) or until the tree this worker contributed to is
 // still being explored elsewhere (returns false: the worker that finishes the last part continues the problem).
-template <int NSEG, class PR>
-__device__ __forceinline__ bool run_problem(Solver<NSEG>& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
+template <int NSEG, class SV, class PR>
+__device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
                             const fh_params& par, const ShareArgs& sa, const double* __restrict__ basis, double* __restrict__ ws, int entry,
                             bool interrupted, fh_result& res) {
   const int lane = sv.lane;
@@ -2728,7 +2721,8 @@ template <int NSEG, bool PAIRS, int WPS = FH_WAVES_PER_SIMD, bool UNK = false>
 __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
                                                    fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Solver<NSEG> sv;
+  typedef Solver<NSEG, (WPS > 2)> SolverT;  // (three wavefronts per SIMD: the row norms from the table, see Solver)
+  SolverT sv;
   sv.carve(smem, ka.max_faces);
   sv.lane = threadIdx.x;
   sv.q = 0;
@@ -2847,7 +2841,7 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(phase ? &ka.safe[unit] : &problems[unit]));
         const fh_face* fcs = reinterpret_cast<const fh_face*>(sv.uniform_u64((unsigned long long)(phase ? ka.sfaces : faces)));
         fh_result* out = reinterpret_cast<fh_result*>(sv.uniform_u64((unsigned long long)(phase ? &ka.sres[unit] : &results[unit])));
-        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out);
+        finished = run_problem<NSEG, SolverT, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out);
       }
       else {
         // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
@@ -2855,7 +2849,7 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
         // compiler no longer treats `const __restrict__` global memory as unclobbered (132 vector loads instead of 28 scalar ones).
         typedef const __attribute__((address_space(4))) fh_problem const_problem;
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(problems + unit));  // (provably wave-uniform)
-        finished = run_problem<NSEG, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
+        finished = run_problem<NSEG, SolverT, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
                                                     results[unit]);
       }
       if (!finished) break;  // the unit continues in another workgroup
