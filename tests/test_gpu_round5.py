@@ -147,3 +147,56 @@ def test_unreachable_goals_on_a_big_map_with_the_default_records():
             assert np.array_equal(got[0][i, :want[1][i]], want[0][i, :want[1][i]]), i
     finally:
         m.close()
+
+
+def test_pool_with_unknown_space_as_an_input_equals_one_context(ctx):
+    """fh_pool_set_unknown_grid + fh_pool_set_pair_rule(mode 2): one batch of pairs over a pool (the device named three times: three
+    contexts, three copies of the unknown voxels, three shards) equals the fused pair kernel of ONE context with the same grid, record for
+    record — whole and safe results; and the pool refuses mode 2 until it has a grid."""
+    rng = np.random.default_rng(77)
+    B = 301
+    whole, faces, _ = corridor.whole_batch(B, seed=21, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    tmpl = corridor.safe_templates(whole)
+    res, dims = 0.25, (96, 96, 16)
+    origin = np.array([whole["x0"][:, 0].min() - 2.0, whole["x0"][:, 1].min() - 2.0, -0.5])
+    flags = (rng.random(dims[::-1]) < 0.0008).astype(np.uint8)          # [nz][ny][nx]: a few scattered unknown voxels
+    rule = dict(mode=2, drone_radius=0.3, delta_h=1.0, delta_a=0.5)
+    fields = [n for n in abi.result_dtype.names if n not in ("nodes", "qp_iters", "kflops")]
+    # one context: the fused pair kernel
+    d_flags = torch.from_numpy(flags.reshape(-1).copy()).cuda()
+    ctx.set_pair_rule(**rule)
+    ctx.set_unknown_grid_device(d_flags.data_ptr(), origin, res, dims)
+    ctx.set_pair_margin(0.0)
+    try:
+        mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+        to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).cuda()
+        d_w, d_f, d_s = to_dev(whole), to_dev(faces), to_dev(tmpl)
+        d_sf = torch.zeros_like(d_f)
+        d_wr = torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0")
+        d_sr = torch.zeros_like(d_wr)
+        ctx.solve_pairs_device(d_w.data_ptr(), d_f.data_ptr(), B, 10, mf, 0.5, 0.0, 3, d_wr.data_ptr(), d_s.data_ptr(), d_sf.data_ptr(), d_sr.data_ptr())
+        ctx.sync()
+        assert ctx.last_launch()[1] == "fh::solve_kernel<10, true, 2, true>"
+        w1, s1 = d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype)
+        safe1 = d_s.cpu().numpy().view(abi.problem_dtype)
+    finally:
+        ctx.set_pair_rule(mode=0)
+        ctx.set_pair_margin(-1.0)
+        ctx.set_unknown_grid_device(None)
+    need = safe1["n_seg"] > 0
+    assert 0.05 * B < need.sum() < B and w1["solved"].sum() > 0.9 * B       # some trajectories come near an unknown voxel, some do not
+    # the pool
+    pool = capi.Pool([0, 0, 0])
+    try:
+        pool.set_pair_margin(0.0)
+        pool.set_pair_rule(**rule)
+        with pytest.raises(capi.FasterHipError):
+            pool.solve_pairs(whole, faces, tmpl, 0.5, 0.0, 3)              # mode 2 without the unknown voxels
+        pool.set_unknown_grid(flags, origin, res, dims)
+        w3, s3 = pool.solve_pairs(whole, faces, tmpl, 0.5, 0.0, 3)
+        for f in fields:
+            assert np.array_equal(w3[f], w1[f]), f
+            assert np.array_equal(s3[f][need], s1[f][need]), ("safe", f)
+        assert not np.any(s3["solved"][~need])
+    finally:
+        pool.close()
