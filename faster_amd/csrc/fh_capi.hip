@@ -193,15 +193,15 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // big batches are started hardest corridors first (order_kernel); results do not depend on the order
   ka.order = nullptr;
   if (n >= 2048 && ctx->sched.launch_order) {
-    const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 64) || !ctx->order_ready;
+    const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 128) || !ctx->order_ready;
     ctx->order_ready = false;  // (true again once all three launches below have been issued: a failed launch must not leave dirty counters behind)
-    if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 64))) != FH_OK) return rc;
+    if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 128))) != FH_OK) return rc;
     int* counters = (int*)ctx->d_buf[13];
-    int* order = counters + 64;
-    if (fresh) FH_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 64, ctx->stream));  // afterwards the scatter kernel leaves them zeroed
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(fh::order_hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters);
-    hipLaunchKernelGGL(fh::order_scatter_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_problems, n, counters, order);
+    int* order = counters + 128;  // (2 * FH_ORDER_CLASSES + 1 = 73 counters)
+    if (fresh) FH_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 128, ctx->stream));  // afterwards the scatter kernel leaves them zeroed
+    const unsigned blocks = (unsigned)((n + FH_ORDER_BLOCK - 1) / FH_ORDER_BLOCK);
+    hipLaunchKernelGGL(fh::order_hist_kernel, dim3(blocks), dim3(FH_ORDER_BLOCK), 0, ctx->stream, d_problems, n, counters);
+    hipLaunchKernelGGL(fh::order_scatter_kernel, dim3(blocks), dim3(FH_ORDER_BLOCK), 0, ctx->stream, d_problems, n, counters, order);
     FH_HIP(hipGetLastError());
     ka.order = order;
   }

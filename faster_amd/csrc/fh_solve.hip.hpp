@@ -2963,44 +2963,73 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
 // number of polytopes (C4: 52 active-set iterations per pair with 2, 320 with 6; 34 of the 41 hardest pairs in 4096 have 6), and a
 // hard tree that is started late is what a launch ends on.  The order inside a class is whatever the atomics give: no result
 // depends on it.
-__global__ void __launch_bounds__(256) order_hist_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters) {
-  __shared__ int cnt[FH_MAX_POLY + 1];
-  if (threadIdx.x <= FH_MAX_POLY) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (i < n) atomicAdd(&cnt[min(max(problems[i].n_poly, 0), FH_MAX_POLY)], 1);
-  __syncthreads();
-  if (threadIdx.x <= FH_MAX_POLY && cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]);
+// [r5] Within a class of equal polytope count the corridors that are SHORT for their number of polytopes go first: on the C4 batch the
+// 1 % of the problems with most active-set iterations are 6-polytope corridors whose start and goal are 9.6 m apart on average
+// (all 6-polytope corridors: 13.9 m) — a corridor that curls needs the late segments decided against the early ones — and with
+// metres-per-polytope as the second key 19 of the 20 longest problems of 32768 are among the first 380 tickets (by polytope count alone
+// they are spread over the first 6200: two rounds of the resident grid later).  A scheduling hint in four buckets; no result depends on it.
+#define FH_ORDER_CLASSES (4 * (FH_MAX_POLY + 1))
+__device__ __forceinline__ int order_class(const fh_problem& p) {
+  const int k = min(max(p.n_poly, 0), FH_MAX_POLY);
+  float d2 = 0.f;  // one axis at a time (the fences keep the six loads from being issued together: these kernels live on 8 registers)
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float d = (float)(p.xf[a] - p.x0[a]);
+    d2 = fmaf(d, d, d2);
+    asm volatile("" : "+v"(d2)::"memory");
+  }
+  const float kk = (float)max(k * k, 1);  // (metres per polytope)^2 against 1.5^2, 2.2^2, 3^2 — without a division
+  return 4 * k + (d2 < 2.25f * kk ? 3 : (d2 < 4.84f * kk ? 2 : (d2 < 9.0f * kk ? 1 : 0)));
 }
-// (Both order kernels fit into 8 vector registers: with three 168-register solve wavefronts on a SIMD that is exactly what is left, so
-// they slip in beside the persistent solve kernels of the other streams.  A version of the first one that also computed dt_initial of
-// every problem — 87 registers — had to wait for a solve wavefront to leave: the timed region of bench.py lost 12 %.)
-__global__ void __launch_bounds__(256) order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters,
-                                                            int* __restrict__ order) {
-  __shared__ int cnt[FH_MAX_POLY + 1], base[FH_MAX_POLY + 1];
-  __shared__ int last_block;
-  if (threadIdx.x <= FH_MAX_POLY) cnt[threadIdx.x] = 0;
+#define FH_ORDER_BLOCK 64  // one wavefront per workgroup: it is placed on whichever SIMD has room (see below)
+__global__ void __launch_bounds__(FH_ORDER_BLOCK) order_hist_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters) {
+  __shared__ int cnt[FH_ORDER_CLASSES];
+  if (threadIdx.x < FH_ORDER_CLASSES) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  const int i = (int)(blockIdx.x * FH_ORDER_BLOCK + threadIdx.x);
+  if (i < n) atomicAdd(&cnt[order_class(problems[i])], 1);
+  __syncthreads();
+  if (threadIdx.x < FH_ORDER_CLASSES && cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], cnt[threadIdx.x]);
+}
+// (Round 4's order kernels fit into 8 vector registers: with three 168-register solve wavefronts on a SIMD that is exactly what is left,
+// so they slipped in beside the persistent solve kernels of the other streams; a version that also computed dt_initial of every problem
+// — 87 registers, 256 threads — had to wait for a solve wavefront to leave: the timed region of bench.py lost 12 %.  With the second key
+// they need 11 / 14 registers.  They are single-wavefront workgroups now: a CU holds 11 solves, i.e. one of its four SIMDs has a free
+// wavefront slot and 176 free registers, and a one-wavefront workgroup is placed there, where a 256-thread one wanted a slot on every SIMD.)
+__global__ void __launch_bounds__(FH_ORDER_BLOCK)
+order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters, int* __restrict__ order) {
+  __shared__ int cnt[FH_ORDER_CLASSES], base[FH_ORDER_CLASSES];
+  __shared__ int last_block;
+  if (threadIdx.x < FH_ORDER_CLASSES) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int i = (int)(blockIdx.x * FH_ORDER_BLOCK + threadIdx.x);
   int k = 0, mine = 0;
   if (i < n) {
-    k = min(max(problems[i].n_poly, 0), FH_MAX_POLY);
+    k = order_class(problems[i]);
     mine = atomicAdd(&cnt[k], 1);
   }
   __syncthreads();
-  if (threadIdx.x <= FH_MAX_POLY) {  // where this block's members of class threadIdx.x go: classes in descending order, blocks as they come
+  if (threadIdx.x < FH_ORDER_CLASSES) {  // where this block's members of class threadIdx.x go: classes in descending order, blocks as they come
     int before = 0;
-    for (int c = FH_MAX_POLY; c > (int)threadIdx.x; c--) before += counters[c];
-    base[threadIdx.x] = before + (cnt[threadIdx.x] ? atomicAdd(&counters[FH_MAX_POLY + 1 + threadIdx.x], cnt[threadIdx.x]) : 0);
+    for (int c = FH_ORDER_CLASSES - 1; c > (int)threadIdx.x; c--) before += counters[c];
+    base[threadIdx.x] = before + (cnt[threadIdx.x] ? atomicAdd(&counters[FH_ORDER_CLASSES + threadIdx.x], cnt[threadIdx.x]) : 0);
   }
   __syncthreads();
-  if (i < n) order[base[k] + mine] = i;
+  if (i < n) {
+    // Rank r in the hardness order -> ticket.  Tickets are drawn FH_TICKET_CHUNK at a time by one workgroup: neighbours in rank must not
+    // be neighbours in ticket, or the first workgroups would each hold four of the hardest problems one behind the other (measured: one
+    // launch alone 3.6 -> 4.3 ms).  Ticket 4 w + j is rank j Q + w: a chunk holds one problem of each quarter of the ranking, and the
+    // hardest Q problems are the first ticket of every chunk.
+    const int r = base[k] + mine, n4 = n & ~(FH_TICKET_CHUNK - 1), Q = n4 / FH_TICKET_CHUNK;
+    order[r < n4 ? FH_TICKET_CHUNK * (r % Q) + r / Q : r] = i;
+  }
   // the last block to finish leaves the counters zeroed for the next launch (no memset in the stream: on a chip whose registers are
   // all held by persistent workgroups every extra stream operation waits milliseconds for a slot)
   __syncthreads();
-  if (threadIdx.x == 0) last_block = atomicAdd(&counters[2 * (FH_MAX_POLY + 1)], 1) == (int)gridDim.x - 1;
+  if (threadIdx.x == 0) last_block = atomicAdd(&counters[2 * FH_ORDER_CLASSES], 1) == (int)gridDim.x - 1;
   __syncthreads();
-  if (last_block && threadIdx.x <= 2 * (FH_MAX_POLY + 1)) counters[threadIdx.x] = 0;
+  if (last_block)
+    for (int c = (int)threadIdx.x; c <= 2 * FH_ORDER_CLASSES; c += FH_ORDER_BLOCK) counters[c] = 0;
 }
 
 // FP64 vector peak of the device as this code can reach it: independent v_fma_f64 chains, 8 per lane, no memory traffic
