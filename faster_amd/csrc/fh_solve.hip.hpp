@@ -2997,7 +2997,7 @@ __global__ void __launch_bounds__(FH_ORDER_BLOCK) order_hist_kernel(const fh_pro
 // they need 11 / 14 registers.  They are single-wavefront workgroups now: a CU holds 11 solves, i.e. one of its four SIMDs has a free
 // wavefront slot and 176 free registers, and a one-wavefront workgroup is placed there, where a 256-thread one wanted a slot on every SIMD.)
 __global__ void __launch_bounds__(FH_ORDER_BLOCK)
-order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __restrict__ counters, int* __restrict__ order) {
+order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int window, int* __restrict__ counters, int* __restrict__ order) {
   __shared__ int cnt[FH_ORDER_CLASSES], base[FH_ORDER_CLASSES];
   __shared__ int last_block;
   if (threadIdx.x < FH_ORDER_CLASSES) cnt[threadIdx.x] = 0;
@@ -3018,10 +3018,14 @@ order_scatter_kernel(const fh_problem* __restrict__ problems, int n, int* __rest
   if (i < n) {
     // Rank r in the hardness order -> ticket.  Tickets are drawn FH_TICKET_CHUNK at a time by one workgroup: neighbours in rank must not
     // be neighbours in ticket, or the first workgroups would each hold four of the hardest problems one behind the other (measured: one
-    // launch alone 3.6 -> 4.3 ms).  Ticket 4 w + j is rank j Q + w: a chunk holds one problem of each quarter of the ranking, and the
-    // hardest Q problems are the first ticket of every chunk.
-    const int r = base[k] + mine, n4 = n & ~(FH_TICKET_CHUNK - 1), Q = n4 / FH_TICKET_CHUNK;
-    order[r < n4 ? FH_TICKET_CHUNK * (r % Q) + r / Q : r] = i;
+    // launch alone 3.6 -> 4.3 ms).  Inside every window of `window` ranks (a multiple of the resident grid, fh_capi.hip) ticket 4 w + j is
+    // rank j Q + w, Q = a quarter of the window: a chunk holds one problem of each quarter of its window, the Q hardest are the first
+    // tickets of Q different chunks, and the windows keep the order hardest first (ONE window over a batch with a large hard class — C5:
+    // a quarter of 65536 problems — would start the last of that class at 80 % of the launch: 12.2 -> 13.1 ms).  The last window is as
+    // long as what is left.
+    const int r = base[k] + mine, w0 = r - r % window, wsize = min(window, n - w0) & ~(FH_TICKET_CHUNK - 1), rr = r - w0;
+    const int Q = wsize / FH_TICKET_CHUNK;
+    order[rr < wsize ? w0 + FH_TICKET_CHUNK * (rr % Q) + rr / Q : r] = i;
   }
   // the last block to finish leaves the counters zeroed for the next launch (no memset in the stream: on a chip whose registers are
   // all held by persistent workgroups every extra stream operation waits milliseconds for a slot)
