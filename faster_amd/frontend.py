@@ -239,7 +239,10 @@ def corridor_batch_device(ctx, vmap, cloud, cells, res, center, z_max, inflation
                               d_faces.data_ptr(), d_off.data_ptr(), d_npoly.data_ptr(), d_goal.data_ptr(), drone_radius, z_ground)
     ctx.sync()
     t3 = time.perf_counter()
-    timing = {"map_s": t1 - t0, "path_search_s": t2 - t1, "decomposition_s": t3 - t2, "expansions": int(d_ex.sum().item())}
+    n_points = d_np.cpu().numpy()   # what the asynchronous planner reported per query: -2 = a limit of the device search
+    corridor_batch_device.last_n_points = n_points
+    timing = {"map_s": t1 - t0, "path_search_s": t2 - t1, "decomposition_s": t3 - t2, "expansions": int(d_ex.sum().item()),
+              "queries_at_a_limit": int((n_points <= -2).sum())}
     goal = d_goal.cpu().numpy()
     goal[np.isnan(goal)] = 0.0
     return d_faces.cpu().numpy(), d_off.cpu().numpy(), d_npoly.cpu().numpy(), goal, timing
