@@ -1338,7 +1338,16 @@ struct Solver {
            // mistaken for an independent one and answered with a step of 1e24.  (NaN-safe: !(cost <= ub).)
           const double xl = (lane < n) ? x[lane] : 0.0;
           cost = c0 + wave_sum(xl * xl);
+#ifndef FH_NO_L1_NODE_BOUND
+          // [r5] The same certificate in the 1-norm (setup_trial has it for y = 0): the current point x* = xp + Z y* is the cheapest one that
+          // satisfies the ACTIVE rows, x* = xp - sum mu_k a_k with mu >= 0 (the invariant of the dual method), so every feasible x has
+          // x* . x >= |x*|^2 = cost; inside the jerk box x* . x <= |x*|_1 (j_max + tol).  cost > |x*|_1 (j_max + tol) is therefore
+          // infeasible with the same conflict as the 2-norm bound, and never later (Cauchy-Schwarz): a refuted node ends iterations sooner.
+          const double l1x = wave_sum(fabs(xj));
+          if (!(cost <= box_ub) || cost > l1x * (jmax + tol) * (1.0 + 1e-9)) {
+#else
           if (!(cost <= box_ub)) {
+#endif
             // Infeasible, with a certificate: the current point is the cheapest one that satisfies the ACTIVE rows (the invariant of
             // the dual method), so the active rows and the jerk box exclude each other — the conflict is the segments whose corridor
             // rows are active (box rows do not depend on any decision).
