@@ -578,7 +578,8 @@ def compute_leg(torch, dev, pp, whole, faces, solo_res, N, max_faces, solo_step_
             "measured_peak_tflops": peak, "spec_peak_tflops": FP64_VECTOR_SPEC_TFLOPS, "frac": ach_steady / peak if peak else None,
             "frac_solo": ach_solo / peak if peak else None, "unit": "TFLOP/s",
             "note": "executed: FP64 flops of all active-set iterations (useful lanes; a wave64 FP64 instruction occupies the SIMD for the full "
-                    "wavefront, so lane utilisation — 30 of 64 lanes for N=10 — is not in this figure); useful: one fixed-assignment QP per trial"}
+                    "wavefront, so lane utilisation — 30 of 64 lanes for N=10 — is not in this figure); useful: one fixed-assignment QP per trial — SURVEY 8(d)'s definition; since round 5 about two of five trials are "
+                    "refuted at y = 0 without any QP, so executed can be BELOW this figure (useful_over_executed > 1)"}
 
 
 def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batches=6):
