@@ -70,8 +70,9 @@ assert params_dtype.itemsize == 48
 
 
 sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("backlog", "<i4"), ("waiting_workgroups", "<i4"),
-                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("no_child_bound", "<i4")])
-assert sched_dtype.itemsize == 32
+                        ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("no_child_bound", "<i4"), ("struct_size", "<i4")])
+assert sched_dtype.itemsize == 36
+FH_ABI_VERSION = 6   # include/fasterhip.h: the layout generation of its structs (checked against fh_abi_version() when the library is loaded)
 
 launch_info_dtype = np.dtype([("n_seg", "<i4"), ("pairs", "<i4"), ("waves_per_simd", "<i4"), ("grid", "<i4"), ("workgroups_per_cu", "<i4"),
                               ("lds_bytes", "<i4"), ("unknown_space", "<i4"), ("reserved", "<i4")])
@@ -89,6 +90,7 @@ assert pair_rule_dtype.itemsize == 40
 def default_sched():
     s = np.zeros((), dtype=sched_dtype)
     s["launch_order"], s["publish_factor"], s["backlog"], s["min_nodes"], s["cloud_blocks"], s["no_child_bound"] = 1, 4, 32, 2, 1, 0
+    s["struct_size"] = sched_dtype.itemsize
     return s
 
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "fh_pool_solve_batch", "fh_pool_solve_pairs",
     "fh_map_create", "fh_map_destroy", "fh_map_last_error", "fh_map_set_stream", "fh_map_set_sched", "fh_map_set_search", "fh_map_set_records", "fh_map_workspace_bytes", "fh_map_set_sphere", "fh_map_sync", "fh_map_read", "fh_map_read_device",
     "fh_map_dims", "fh_map_occupancy", "fh_map_plan_batch", "fh_map_plan_batch_device",
-    "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_last_launch", "fh_version",
+    "fh_sync", "fh_timing_reset", "fh_timing_read", "fh_last_kernel_ms", "fh_last_launch", "fh_version", "fh_abi_version",
     "fh_packed_result_size", "fh_pack_results_device", "fh_pack_results", "fh_unpack_results", "fh_control_points",
 ]
 
@@ -222,6 +222,11 @@ def lib():
         L.fh_last_launch.restype = i32
         L.fh_last_launch.argtypes = [vp, vp]
         L.fh_version.restype = ctypes.c_char_p
+        L.fh_abi_version.restype = i32
+        L.fh_abi_version.argtypes = []
+        if L.fh_abi_version() != abi.FH_ABI_VERSION:
+            raise FasterHipError("%s has struct layout generation %d, faster_amd/abi.py describes %d: rebuild (python -m faster_amd.build)"
+                                 % (SO_PATH, L.fh_abi_version(), abi.FH_ABI_VERSION))
         _LIB = L
     return _LIB
 

@@ -133,7 +133,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     lds_launch = std::max(lds, (size_t)(160 * 1024) / (size_t)per_cu / 1280 * 1280 - 16);
   }
   const int resident = ctx->n_cu * per_cu;
-  ctx->last_launch = {NSEG, PAIRS ? 1 : 0, two_waves ? 2 : FH_WAVES_PER_SIMD, 0, per_cu, (int32_t)lds_launch, unk ? 1 : 0, 0};
+  ctx->last_launch = {NSEG, PAIRS ? 1 : 0, (two_waves || unk) ? 2 : FH_WAVES_PER_SIMD, 0, per_cu, (int32_t)lds_launch, unk ? 1 : 0, 0};  // (the UNK instantiation is always the two-wavefront one)
   const bool share = ctx->par.share != 0 && ctx->par.max_work == 0 && ctx->par.mip_gap == 0.0;
   // small batches get helper workgroups (one per CU) that take over subtrees of hard problems
   const int grid = share ? std::min(resident, std::max(n, ctx->n_cu)) : std::min(resident, n);
@@ -315,7 +315,8 @@ int fh_control_points(const fh_result* results, int n, int n_seg, double* cp) {
   return FH_OK;
 }
 
-const char* fh_version(void) { return "fasterhip 0.3 gfx950"; }
+const char* fh_version(void) { return "fasterhip 0.4 gfx950"; }
+int fh_abi_version(void) { return FH_ABI_VERSION; }
 
 void fh_default_sched(fh_sched* s) {
   if (!s) return;
@@ -327,10 +328,16 @@ void fh_default_sched(fh_sched* s) {
   s->min_nodes = 2;
   s->no_child_bound = 0;
   s->cloud_blocks = 1;
+  s->struct_size = (int32_t)sizeof(fh_sched);
 }
 
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s) {
   if (!ctx || !s) return FH_ERR_ARG;
+  if (s->struct_size != 0 && s->struct_size != (int32_t)sizeof(fh_sched)) {
+    ctx->err = "fh_set_sched: fh_sched.struct_size " + std::to_string(s->struct_size) + " is not this library's " + std::to_string(sizeof(fh_sched)) +
+               " (built against another round's fasterhip.h?)";
+    return FH_ERR_ARG;
+  }
   if (s->publish_factor < 0 || s->backlog < 0 || s->backlog > 512 || s->waiting_workgroups < 0 || s->min_nodes < 0 || s->workgroups_per_cu < 0) return FH_ERR_ARG;
   ctx->sched = *s;
   return FH_OK;

@@ -38,6 +38,20 @@ struct fh_map {
   size_t chunk_words = 0;                 // words of d_chunks per wavefront
   unsigned* d_chunks = nullptr;
   unsigned* d_serials = nullptr;
+  // [r6] A second search workspace, parked: the dense (one record per cell) workspace of the host-pointer entry point's retry of queries
+  // that overflowed the hashed records.  The retry swaps it with the fields above for the duration of its launch (swap_workspaces) instead
+  // of freeing and rebuilding the main workspace twice per call (up to 48 GB of memset each time: unreachable goals are common in replanning).
+  struct ParkedWorkspace {
+    int waves = 0;
+    size_t ws_total = 0;
+    fhp::CellState* d_cells = nullptr;
+    unsigned long long* d_hkeys = nullptr;
+    int ws_slots = -1;
+    size_t ws_bytes = 0, chunk_words = 0;
+    unsigned* d_chunks = nullptr;
+    unsigned* d_serials = nullptr;
+  } parked;
+  int wave_cap = 0;                       // > 0: ensure_workspace sizes for at most this many wavefronts (the retry: a handful of queries)
   int* d_ticket = nullptr;
   int sched_waves_per_cu = 0, sched_launch_order = 1;  // fh_map_set_sched (0: 12 wavefronts per CU for A*, 20 for the jump point search)
   int* d_order = nullptr;  // 128 counters + launch order
@@ -109,6 +123,7 @@ int ensure_workspace(fh_map* m) {
   // cell has one heap entry at most, so 3/4 of the slots), and the clean-up lists of the finished path (3 x MAXRAW ints)
   const size_t chunk_words = slots > 0 ? std::max<size_t>((size_t)(slots / 4 * 3) * 5, (size_t)3 * fhp::MAXRAW) + 16 : (size_t)fhp::NCHUNK * fhp::CHUNK_WORDS;
   const size_t per_wave = records * sizeof(fhp::CellState) + (slots > 0 ? (size_t)slots * 8 : 0) + chunk_words * 4;
+  if (m->wave_cap > 0) waves = std::min(waves, m->wave_cap);
   if ((size_t)waves * per_wave > budget) waves = (int)std::max<size_t>(1, budget / per_wave);
   if (m->d_cells && m->ws_total == total && m->ws_slots == slots && m->waves >= 1) return FH_OK;  // (another grid size: other strides, stale stamps)
   FM_HIP(hipStreamSynchronize(m->stream));
@@ -137,6 +152,33 @@ int ensure_workspace(fh_map* m) {
   m->ws_bytes = (size_t)waves * per_wave;
   return FH_OK;
 }
+// exchanges the active search workspace with the parked one
+void swap_workspaces(fh_map* m) {
+  std::swap(m->waves, m->parked.waves);
+  std::swap(m->ws_total, m->parked.ws_total);
+  std::swap(m->d_cells, m->parked.d_cells);
+  std::swap(m->d_hkeys, m->parked.d_hkeys);
+  std::swap(m->ws_slots, m->parked.ws_slots);
+  std::swap(m->ws_bytes, m->parked.ws_bytes);
+  std::swap(m->chunk_words, m->parked.chunk_words);
+  std::swap(m->d_chunks, m->parked.d_chunks);
+  std::swap(m->d_serials, m->parked.d_serials);
+}
+// the retry of fh_map_plan_batch runs with per-cell records on the parked workspace; whatever way it ends, the map is back as it was
+struct DenseRetryScope {
+  fh_map* m;
+  int saved_slots;
+  explicit DenseRetryScope(fh_map* m_, int cap) : m(m_), saved_slots(m_->record_slots) {
+    swap_workspaces(m);
+    m->record_slots = 0;
+    m->wave_cap = cap;
+  }
+  ~DenseRetryScope() {
+    swap_workspaces(m);
+    m->record_slots = saved_slots;
+    m->wave_cap = 0;
+  }
+};
 }  // namespace
 
 extern "C" {
@@ -165,7 +207,8 @@ void fh_map_destroy(fh_map* m) {
   if (!m) return;
   MapDeviceScope scope(m);
   (void)hipStreamSynchronize(m->stream);
-  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_hkeys, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables, (void*)m->d_jps_entries})
+  for (void* p : {(void*)m->d_bits, (void*)m->d_cells, (void*)m->d_hkeys, (void*)m->d_chunks, (void*)m->d_serials, (void*)m->d_ticket, (void*)m->d_order, (void*)m->d_jps_tables, (void*)m->d_jps_entries,
+                  (void*)m->parked.d_cells, (void*)m->parked.d_hkeys, (void*)m->parked.d_chunks, (void*)m->parked.d_serials})
     if (p) (void)hipFree(p);
   for (void* p : m->d_stage)
     if (p) (void)hipFree(p);
@@ -185,7 +228,7 @@ int fh_map_set_stream(fh_map* m, void* stream) {
 
 int fh_map_set_sched(fh_map* m, int waves_per_cu, int launch_order) {
   if (!m || waves_per_cu < 0 || waves_per_cu > 20) return FH_ERR_ARG;
-  if (waves_per_cu != m->sched_waves_per_cu) m->ws_total = 0;  // the search workspace is sized by the number of wavefronts: reallocated by the next search
+  if (waves_per_cu != m->sched_waves_per_cu) m->ws_total = m->parked.ws_total = 0;  // the search workspace is sized by the number of wavefronts: reallocated by the next search
   m->sched_waves_per_cu = waves_per_cu;
   m->sched_launch_order = launch_order ? 1 : 0;
   return FH_OK;
@@ -212,7 +255,7 @@ int fh_map_set_search(fh_map* m, int mode) {
     FM_HIP(hipMalloc(&m->d_jps_tables, tab.size()));
     FM_HIP(hipMemcpy(m->d_jps_tables, tab.data(), tab.size(), hipMemcpyHostToDevice));
   }
-  if (mode != m->search_mode) m->ws_total = 0;  // the two searches stamp the cell states differently: the workspace starts over
+  if (mode != m->search_mode) m->ws_total = m->parked.ws_total = 0;  // the two searches stamp the cell states differently: the workspace starts over
   m->search_mode = mode;
   return FH_OK;
 }
@@ -438,11 +481,16 @@ int fh_map_plan_batch(fh_map* m, const double* starts, const double* goals, int 
           q[(size_t)3 * j + c] = starts[(size_t)3 * again[j] + c];
           q[(size_t)3 * (k + j) + c] = goals[(size_t)3 * again[j] + c];
         }
-      m->record_slots = 0;
-      FM_HIP(hipMemcpyAsync(d_q, q.data(), sizeof(double) * 6 * (size_t)k, hipMemcpyHostToDevice, m->stream));
-      rc = fh_map_plan_batch_device(m, d_q, d_q + 3 * (size_t)k, k, max_points, max_vertex_dist, max_poly, (double*)m->d_stage[2],
-                                    (int32_t*)m->d_stage[3], (int64_t*)m->d_stage[4]);
-      m->record_slots = -1;
+      FM_HIP(hipStreamSynchronize(m->stream));  // (the main workspace is parked while nothing of this map is running)
+      {
+        // per-cell records on the parked workspace (kept from call to call: a handful of wavefronts, sized once), every field restored on
+        // every way out — an early return must not leave record_slots at 0 (the next call would rebuild the main workspace twice)
+        DenseRetryScope retry(m, std::max(64, std::min(k, 4 * m->n_cu)));
+        FM_HIP(hipMemcpyAsync(d_q, q.data(), sizeof(double) * 6 * (size_t)k, hipMemcpyHostToDevice, m->stream));
+        rc = fh_map_plan_batch_device(m, d_q, d_q + 3 * (size_t)k, k, max_points, max_vertex_dist, max_poly, (double*)m->d_stage[2],
+                                      (int32_t*)m->d_stage[3], (int64_t*)m->d_stage[4]);
+        if (rc == FH_OK) FM_HIP(hipStreamSynchronize(m->stream));
+      }
       if (rc != FH_OK) return rc;
       std::vector<double> pp((size_t)3 * k * max_points);
       std::vector<int32_t> np((size_t)k);

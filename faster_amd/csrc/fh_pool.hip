@@ -284,7 +284,11 @@ int fh_pool_set_unknown_grid(fh_pool* pool, const fh_voxel_grid* grid, const uns
       rc = fh_set_unknown_grid_device(d.ctx, nullptr, nullptr);
     } else {
       const size_t bytes = (size_t)grid->dims[0] * (size_t)grid->dims[1] * (size_t)grid->dims[2];
-      (void)hipStreamSynchronize(d.stream);  // (a launch that still reads the old flags)
+      // the context must not keep pointing at a buffer that grow() may free: no launch of it is running (fh_sync waits for the CONTEXT's
+      // stream, whichever it is), it forgets the old flags first, and learns the new ones only once they are in place
+      (void)fh_sync(d.ctx);
+      (void)hipStreamSynchronize(d.stream);
+      (void)fh_set_unknown_grid_device(d.ctx, nullptr, nullptr);
       if (!grow(d, 6, bytes) || hipMemcpy(d.buf[6], flags, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = FH_ERR_DEVICE;
       else rc = fh_set_unknown_grid_device(d.ctx, grid, (const unsigned char*)d.buf[6]);
     }

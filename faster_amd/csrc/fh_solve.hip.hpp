@@ -60,9 +60,14 @@ __device__ __forceinline__ unsigned long long pinned_clock() {
 #ifdef FH_PROFILE
 #define FH_T0() const unsigned long long t0__ = __builtin_readcyclecounter()
 #define FH_T1(slot) do { prof[slot] += __builtin_readcyclecounter() - t0__; cnt[slot] += 1; } while (0)
+// finer slots of round 6 (cycles only; row FH_MAX_SEG - 6 of the result): what search() and run_problem spend OUTSIDE the slots above
+#define FH_U0() const unsigned long long u0__ = __builtin_readcyclecounter()
+#define FH_U1(slot) do { prof2[slot] += __builtin_readcyclecounter() - u0__; } while (0)
 #else
 #define FH_T0()
 #define FH_T1(slot)
+#define FH_U0()
+#define FH_U1(slot)
 #endif
 #define FH_MAX_TRIALS 4096
 // Wavefronts per SIMD the solve kernels are compiled for (launch bounds: 512 / this many vector registers per lane, granule 8)
@@ -248,6 +253,7 @@ __device__ __forceinline__ double wcoef(int kind, int m, double h) {
 
 // ---- time allocation: getDTInitial (solverGurobi.cpp:659-759); same closed forms as the oracle ------------------
 __device__ inline double polish3(double c3, double c2, double c1, double c0, double t) {
+#pragma clang fp contract(off)  // (the exact path rounds as the oracle does: oracle/Makefile builds with -ffp-contract=off)
   for (int it = 0; it < 3; it++) {
     double f = ((c3 * t + c2) * t + c1) * t + c0;
     double df = (3 * c3 * t + 2 * c2) * t + c1;
@@ -262,7 +268,21 @@ __device__ inline double polish3(double c3, double c2, double c1, double c0, dou
 // the CPU oracle's sequential loops; the minimum over the positive roots and the maximum over the axes do not depend on the
 // order).  The double-precision cbrt / acos / cos behind a cubic are hundreds of instructions each: done once per wavefront
 // instead of once per axis and root, they are ~4 % instead of ~25 % of a typical problem.  0: no positive root.
+__device__ inline double quad_root_of_lane(double c2, double c1, double c0, int j) {
+#pragma clang fp contract(off)
+  const double disc = c1 * c1 - 4.0 * c2 * c0;
+  if (disc < 0) return (j == 0 && sqrt(-disc) / fabs(2.0 * c2) < 1e-12) ? -c1 / (2.0 * c2) : 0.0;
+  const double s = sqrt(disc);
+  const double qq = -0.5 * (c1 + (c1 >= 0 ? s : -s));
+  if (qq == 0) return 0.0;
+  return j == 0 ? qq / c2 : (j == 1 ? c0 / qq : 0.0);
+}
 __device__ inline double cubic_root_of_lane(double c3, double c2, double c1, double c0, int j) {
+  // [r6] c0 == 0 exactly (start and goal coincide on this axis): the cubic is t (c3 t^2 + c2 t + c1) — one root EXACTLY zero (lane j = 0;
+  // MinPositiveElement drops it) and the quadratic's roots by the quadratic's closed form (lanes 1, 2).  A chosen convention, the same as
+  // the oracle's (oracle/faster_oracle.c: real_roots_cubic): the general closed form returns the zero root as +-1e-17 by the last bit of cbrt / acos.
+#pragma clang fp contract(off)
+  if (c0 == 0.0) return j == 0 ? 0.0 : quad_root_of_lane(c3, c2, c1, j - 1);
   const double B = c2 / c3, C = c1 / c3, D = c0 / c3;
   const double p = C - B * B / 3.0;
   const double q = 2.0 * B * B * B / 27.0 - B * C / 3.0 + D;
@@ -283,14 +303,6 @@ __device__ inline double cubic_root_of_lane(double c3, double c2, double c1, dou
     cand = polish3(c3, c2, c1, c0, m * cos(phi - 2.0 * 3.14159265358979323846 * (double)j / 3.0) - B / 3.0);
   }
   return cand;
-}
-__device__ inline double quad_root_of_lane(double c2, double c1, double c0, int j) {
-  const double disc = c1 * c1 - 4.0 * c2 * c0;
-  if (disc < 0) return (j == 0 && sqrt(-disc) / fabs(2.0 * c2) < 1e-12) ? -c1 / (2.0 * c2) : 0.0;
-  const double s = sqrt(disc);
-  const double qq = -0.5 * (c1 + (c1 >= 0 ? s : -s));
-  if (qq == 0) return 0.0;
-  return j == 0 ? qq / c2 : (j == 1 ? c0 / qq : 0.0);
 }
 // getDTInitial as the oracle evaluates it, one candidate root per lane (lane = 3 * axis + j; the exact path: closed forms with the
 // double-precision cbrt / acos / cos of the device library, ~1100 vector instructions on nine useful lanes).
@@ -330,12 +342,17 @@ __device__ __attribute__((noinline)) double dt_initial_exact(const PR& pr, int l
 // a start that is good to 1e-5 ends on the same rounding-level neighbourhood of the root as one that is good to 1e-16 — and the
 // result is stored as a float (:662-670).  The starts below are therefore computed with the hardware's single-precision
 // transcendentals (v_log / v_exp for the cube roots, a 7th-degree polynomial for acos, v_cos) on quantities brought into their range
-// first, the double-precision square root by v_sqrt_f64 without its correction steps.  Everything that DECIDES something is still the
-// oracle's double arithmetic: B, C, D, p, q and the discriminant with their divisions, which roots are real, MinPositiveElement, and
-// the quadratic's roots, which are used as they come (no polish: correctly rounded sqrt and divisions).  Where the polish could not
-// repair a poor start — two roots closer than a thousandth of their size: |disc| below 1e-6 of its terms, or terms so small that the
-// 1e-12 test for an imaginary part decides; or a root at zero (dx = 0), whose sign is rounding noise — any lane says so and the whole
-// wavefront takes the exact path.
+// first, the double-precision square root by v_sqrt_f64 without its correction steps.  The depressed cubic (B, C, D, p, q, the discriminant)
+// only CHOOSES the case and the starting points here: its divisions are multiplications by a corrected reciprocal (v_rcp_f64 + one Newton
+// step, an ulp or two) and its products are re-associated (B * B/3, (p/3)^3, (q/2)^2) — not the oracle's roundings.  That is safe where
+// the case does not hang on those last bits, and the guards below send everything else to the exact path: |disc| below 1e-6 of its terms
+// (two roots closer than a thousandth of their size), terms so small that the 1e-12 test for an imaginary part decides, a triple root
+// with B != 0, a start or goal within 1e-30 on an axis.  What DECIDES a value is the oracle's arithmetic: MinPositiveElement, the float
+// casts, and the quadratic's roots, which are used as they come (correctly rounded sqrt and divisions, no polish).  The polished cubic
+// root can still differ from the exact path's by an ulp of the double, i.e. the float the reference stores can land on the other side
+// of a rounding boundary about once in 1e8 roots: fh_dt_initial_batch against orc_dt_initial_batch on 2.1 M problems (tests/test_gpu_round5.py)
+// and the A/B test against the FH_DT_EXACT_ONLY build (tests/test_gpu_round6.py) are statistical evidence, not a proof of bit equality —
+// include/fasterhip.h says so.  dx = 0 exactly takes the exact path, where the convention of cubic_root_of_lane applies.
 // Lane = 4 * axis + j (an axis' candidates share a quad: their minimum is two quad permutes), nine useful lanes.
 __device__ __forceinline__ double cbrt_start(double a) {  // relative error ~1e-6
   const int e = __builtin_amdgcn_frexp_exp(a);              // a = m 2^e, |m| in [0.5, 1)
@@ -390,8 +407,8 @@ __device__ __forceinline__ double dt_initial(const PR& pr, int lane) {
   const double qc2 = 0.5 * (double)acc;
   const double qdisc = c1 * c1 - 4.0 * qc2 * c0;
   const bool triple = !(disc > 0) && p == 0;  // (B = C = D = 0 — at rest on this axis with nowhere to go — is the case that occurs)
-  // (dx = 0 — same height at start and goal, say — puts a root of the cubic AT zero: whether it comes out as +1e-17, 0 or -1e-17, and
-  // with that whether MinPositiveElement sees it, is decided by the last bit of the closed form: only the oracle's own arithmetic follows it)
+  // (dx = 0 — same height at start and goal, say — puts a root of the cubic AT zero: the exact path factors it out, cubic_root_of_lane;
+  // a |dx| below 1e-30 that is not zero goes there too and takes the general closed form)
   const bool ill = !(fabs(disc) >= 1e-6 * scale) || (scale > 0.0 && scale < 1e-40) || !(scale < 1e280) || !(qdisc >= 0.0) || (triple && B != 0.0) ||
                    !(fabs(dx) >= 1e-30);
   if (wave_any(ill && lane < 12)) return dt_initial_exact(pr, opaque(lane));
@@ -543,6 +560,10 @@ struct Solver {
   unsigned long long take_cycles; unsigned int take_calls;  // take_task of a workgroup that still has tickets (is a frame pending?)
   unsigned long long glue_parts[4];  // of the hand-off: before the clock, the clock loop, R + the polytope test (first memory wait), the face copy
   unsigned long long pre_cycles, glue_cycles, drain_cycles;  // measured in the kernel loop, charged to the next problem
+  unsigned long long prof2[12];  // [r6] 0 search prologue, 1 backtrack blocks, 2 limits / look / incumbent poll before a node, 3 qp_run, 4 record + LDS init of
+                                 // the staging, 5 basis reload, 6 trial loop outside set-up and search, 7 between the trial loop and the result write,
+                                 // 8-10 of the ticket phase: up to take_task, the draw, the order fetch; 11 unit_done
+  unsigned long long pre_parts[3];
 #endif
   unsigned allowed_first, allowed_last;  // polytopes not excluded for segment 0 / N-1 by jerk-independent rows
   double h, tol, dep2;
@@ -2106,6 +2127,7 @@ struct Solver {
     unsigned carry = 0u;      // with this conflict
     allinf = 0u;              // (a frame taken from the queue had children tried elsewhere: bit 0 stays clear)
     if (entry == 0) {
+      FH_U0();
       best_cost = INFINITY;
       best_key = ~0ull;
       cur_key = 0ull;
@@ -2148,6 +2170,7 @@ struct Solver {
       reset_qp();  // y = 0: the minimum-norm point of the final-state equalities (setup_trial)
       qe = 0;
       if (lane == 0) tb[TB_QE] = 0;
+      FH_U1(0);
       if (!eq_ok) return FH_ST_INFEASIBLE;
     } else {
       depth = 1;
@@ -2156,6 +2179,7 @@ struct Solver {
     int local_nodes = 0;
     for (;;) {
       if (backtrack) {  // next untried sibling, deepest level first
+        FH_U0();
         bool have_node = false;
         while (depth > 0) {
           const int d_ = depth - 1;
@@ -2211,9 +2235,13 @@ struct Solver {
           depth--;
           FH_SYNC();
         }
+        FH_U1(1);
         if (!have_node) break;
       }
       backtrack = true;
+#ifdef FH_PROFILE
+      const unsigned long long u2__ = __builtin_readcyclecounter();
+#endif
       if (local_nodes >= par.max_nodes) { status_limit = FH_ST_NODE_LIMIT; break; }
       if (par.max_work > 0 && iters >= par.max_work) { status_limit = FH_ST_ITER_LIMIT; break; }
       local_nodes++;
@@ -2256,7 +2284,14 @@ struct Solver {
         }
       }
       double cost = 0;
+#ifdef FH_PROFILE
+      const unsigned long long u3__ = __builtin_readcyclecounter();
+      prof2[2] += u3__ - u2__;
+#endif
       const int st = qp_run(best_cost * (1.0 - par.mip_gap), cur_key > best_key, par.max_iters, iters, cost);  // mip_gap 0 (default): exact
+#ifdef FH_PROFILE
+      prof2[3] += __builtin_readcyclecounter() - u3__;
+#endif
       if (st == 3) { status_limit = FH_ST_ITER_LIMIT; break; }
       carry_inf = st == 1;
       carry = conflict;
@@ -2409,6 +2444,9 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
 #ifdef FH_PROFILE
   const unsigned long long tstart__ = pinned_clock();
   for (int i = 0; i < 24; i++) { sv.prof[i] = 0; sv.cnt[i] = 0; }
+  for (int i = 0; i < 8; i++) sv.prof2[i] = 0;
+  sv.prof2[8] = sv.pre_parts[0]; sv.prof2[9] = sv.pre_parts[1]; sv.prof2[10] = sv.pre_parts[2];
+  sv.pre_parts[0] = sv.pre_parts[1] = sv.pre_parts[2] = 0;
   sv.prof[18] = sv.glue_cycles; sv.cnt[18] = sv.glue_cycles ? 1 : 0; sv.glue_cycles = 0;
   sv.prof[19] = sv.pre_cycles; sv.cnt[19] = sv.pre_cycles ? 1 : 0; sv.pre_cycles = 0;
   sv.prof[23] = sv.drain_cycles; sv.cnt[23] = sv.drain_cycles ? 1 : 0; sv.drain_cycles = 0;
@@ -2450,6 +2488,9 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   FH_SYNC();  // the previous problem of this workgroup is completely done with LDS
   if (lane < 9) sv.xfl[lane] = pr.xf[lane];
   sv.init_problem();
+#ifdef FH_PROFILE
+  sv.prof2[4] = pinned_clock() - tstart__;
+#endif
   // the orthogonal basis of this N (fh_basis.hip.hpp) stays in LDS from problem to problem: reloaded only when N changes
   const double* bt = reinterpret_cast<const double*>(sv.uniform_u64((unsigned long long)(basis + (size_t)(pr.n_seg - 1) * BT_STRIDE)));
   if (uniform_i32(sv.tb[sv.TB_ZN]) != pr.n_seg) {
@@ -2460,6 +2501,9 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     }
     if (lane == 0) sv.tb[sv.TB_ZN] = pr.n_seg;
   }
+#ifdef FH_PROFILE
+  sv.prof2[5] = pinned_clock() - tstart__ - sv.prof2[4];
+#endif
 
   // stage the corridor once: coalesced 32-B face rows HBM -> LDS, and |a_f|
   const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
@@ -2523,6 +2567,9 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   if (lane == 0) sv.tb_put64(sv.TB_BASE, sv.f64_bits(base));
   unsigned limit = 0u;
   bool last_trial = false;
+#ifdef FH_PROFILE
+  const unsigned long long tloop__ = pinned_clock();
+#endif
   for (;;) {  // genNewTraj :445-446: for (f = f_init; f <= f_final && !solved; f = f + f_inc)
     if (entry != 1) {
       if (!(f <= pr.f_final) || trials >= sv.trial_end) break;
@@ -2558,7 +2605,23 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     // (the limits that search() tests before it opens a node keep their say: a node cap of zero, a work cap already used up)
     if (early_inf && !sv.x0_outside_box(pr) && par.max_nodes > 0 && !(par.max_work > 0 && iters >= par.max_work)) {  // the root node, refuted without an iteration
       st = FH_ST_INFEASIBLE;
-      nodes += 1;
+      nodes += 1;  // (search() would count this root too — unless its screening leaves segment 0 or N - 1 without a polytope, or a pin is
+                   //  excluded: then it answers INFEASIBLE before it opens a node, and `nodes` here is one larger than a search that screens
+                   //  first would report.  The screening is what this exit saves; fh_result.nodes counts work, it is not a parity field there.)
+      // a long window of refuted trials (up to FH_MAX_TRIALS) never enters search(), where the stop request and the deadline are polled:
+      // every 8th trial looks at the launch's own words (the host's word is relayed there by whoever draws a unit or walks a tree)
+      if ((trials & 7) == 0) {
+        unsigned int stop = 0u;
+        if (lane == 0) {
+          const unsigned long long ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
+          stop = (unsigned int)ei | (unsigned int)(ei >> 32);
+          if (!stop && sa.deadline_ticks) {
+            const unsigned long long t_start = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
+            if (wall_ticks() - t_start > sa.deadline_ticks) { stop = 2u; ast(&sa.ctl->interrupted, 2u); }
+          }
+        }
+        if (uniform_i32((int)stop) != 0) st = FH_ST_INTERRUPTED;
+      }
     } else  // (x0 outside the v / a box: search() says so before it touches what setup_trial skipped, and counts no node)
 #endif
     st = sv.search(pr, par, sa, ws, entry == 1 ? 1 : 0, best, nodes, iters);
@@ -2589,6 +2652,10 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     if (trials >= sv.trial_end || limit == FH_ST_INTERRUPTED || best < INFINITY) break;
     f = f + pr.f_inc;
   }
+#ifdef FH_PROFILE
+  sv.prof2[6] = pinned_clock() - tloop__;  // (the trial loop in total: set-up and search are slots 1 and 15)
+  const unsigned long long tpost__ = pinned_clock();
+#endif
   if (sv.rec >= 0) {
     if (!sv.finish_part(sa, nodes, iters, limit, last_trial)) return false;  // the problem's tree is still being explored elsewhere
     // the last part: the answer is the record's incumbent (first feasible factor, cheapest leaf, first in depth-first order)
@@ -2625,6 +2692,7 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
 
 #ifdef FH_PROFILE
   const unsigned long long tres__ = pinned_clock();
+  sv.prof2[7] = tres__ - tpost__;
 #endif
   if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
     FH_SYNC();
@@ -2678,6 +2746,11 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     res.coeff[FH_MAX_SEG - 3][lane] = (double)pw;
     res.coeff[FH_MAX_SEG - 4][lane] = (double)cw;
     if (lane < 4) res.coeff[FH_MAX_SEG - 5][lane] = (double)(lane == 0 ? gp0__ : (lane == 1 ? gp1__ : (lane == 2 ? gp2__ : gp3__)));
+    if (sv.N <= FH_MAX_SEG - 6) {
+      unsigned long long pu = 0;
+      for (int i = 0; i < 12; i++) pu = (i == lane) ? sv.prof2[i] : pu;
+      res.coeff[FH_MAX_SEG - 6][lane] = (double)pu;
+    }
   }
 #endif
 #ifdef FH_SHARE_PROFILE
@@ -2763,6 +2836,8 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
 #ifdef FH_PROFILE
   sv.pre_cycles = 0; sv.glue_cycles = 0; sv.drain_cycles = 0; sv.take_cycles = 0; sv.take_calls = 0;
   sv.glue_parts[0] = sv.glue_parts[1] = sv.glue_parts[2] = sv.glue_parts[3] = 0;
+  sv.pre_parts[0] = sv.pre_parts[1] = sv.pre_parts[2] = 0;
+  for (int i = 0; i < 12; i++) sv.prof2[i] = 0;
 #endif
   for (;;) {
     int entry = 0, unit = 0, phase = 0;
@@ -2792,6 +2867,10 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       if (tickets_left) { sv.take_cycles += pinned_clock() - ttake__; sv.take_calls += 1; }
 #endif
     }
+#ifdef FH_PROFILE
+    const unsigned long long tpre1__ = pinned_clock();
+    unsigned long long tpre2__ = tpre1__;
+#endif
     if (entry) {
       unit = uniform_i32(sv.tb[sv.TB_B]);
       phase = uniform_i32(sv.tb[sv.TB_PHASE]);
@@ -2829,6 +2908,9 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       }
       (void)fresh_words;
       interrupted = __builtin_amdgcn_readfirstlane((int)intr) != 0;
+#ifdef FH_PROFILE
+      tpre2__ = pinned_clock();
+#endif
       if (pool_next >= pool_end) {  // (the chunk lay beyond the batch)
         tickets_left = false;
 #ifdef FH_SHARE_PROFILE
@@ -2849,7 +2931,12 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
     phase = uniform_i32(phase);
     interrupted = uniform_i32(interrupted ? 1 : 0) != 0;
 #ifdef FH_PROFILE
-    if (!entry) sv.pre_cycles = pinned_clock() - tpre__;
+    if (!entry) {
+      asm volatile("" :: "s"(unit) : "memory");  // (the order word has arrived)
+      const unsigned long long tpre3__ = pinned_clock();
+      sv.pre_cycles = tpre3__ - tpre__;
+      sv.pre_parts[0] = tpre1__ - tpre__; sv.pre_parts[1] = tpre2__ - tpre1__; sv.pre_parts[2] = tpre3__ - tpre2__;
+    }
 #endif
     for (;;) {  // the problems of the unit (a pair has two)
       bool finished;

@@ -20,6 +20,13 @@ bool SolverHip::ensureContext() {
   // solver object for good, and a failed creation is not retried on every replan
   if (create_failed_) return false;
   if (ctx_) return true;
+  if (fh_abi_version() != FH_ABI_VERSION) {  // this object was compiled against another generation of fasterhip.h than the library that is loaded
+    create_failed_ = true;
+    device_rc_ = FH_ERR_ARG;
+    device_err_ = "libfasterhip.so has struct layout generation " + std::to_string(fh_abi_version()) + ", SolverHip was built for " + std::to_string(FH_ABI_VERSION);
+    std::fprintf(stderr, "SolverHip: %s\n", device_err_.c_str());
+    return false;
+  }
   const int rc = fh_create(&ctx_, -1);
   if (rc != FH_OK) {
     create_failed_ = true;

@@ -192,7 +192,15 @@ typedef struct fh_sched {
                                  the trees are half as large).  1: every child is visited, the tree of the CPU oracle.
                                  (Round 4 called this field child_bound with 1 = default; inverted so that a caller who fills a
                                  zero-initialised struct by hand keeps the default behaviour.)                                        */
+  int32_t struct_size;        /* sizeof(fh_sched) as the CALLER was compiled (fh_default_sched sets it), or 0 = not stated.  fh_set_sched
+                                 refuses any other value: the struct has changed between rounds (round 4's child_bound became
+                                 no_child_bound with the opposite meaning at the same offset), and a binary built against an older
+                                 header must fail loudly instead of silently switching a bound off.  See also fh_abi_version().         */
 } fh_sched;
+/* The layout generation of the structs in this header: bumped whenever a field changes its meaning, offset or size.  A caller compares
+ * FH_ABI_VERSION (its compile time) with fh_abi_version() (the loaded library) once; SolverHip does. */
+#define FH_ABI_VERSION 6
+int fh_abi_version(void);
 void fh_default_sched(fh_sched* s);
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s);
 
@@ -225,7 +233,15 @@ int fh_fp64_peak(fh_ctx* ctx, double* tflops);
  * factor loop starts (dt = factor * max(dt_initial, 2 DC), findDT :494-497) — per axis the time to cover |xf - x0| at v_max and the
  * smallest positive real roots of the constant-jerk cubic and the constant-acceleration quadratic, with the reference's float casts
  * and float / int division; > 10000 -> 0.  Reads x0, xf (positions), v_max, a_max, j_max and n_seg of each problem record; the same
- * device function the solve kernels call (their fh_result.dt = factor * max(this, 2 dc)).  dt [n] doubles. */
+ * device function the solve kernels call (their fh_result.dt = factor * max(this, 2 dc)).  dt [n] doubles.
+ * Two things a caller should know (Eigen's PolynomialSolver, which the reference calls at :700-746, is not part of this library):
+ *  - the roots come from single-precision starting points polished in double precision (closed forms in double where two roots are
+ *    close); the value is the FLOAT the reference stores, and against the closed forms it can differ by one float ulp about once in
+ *    1e8 roots (none in the 2.6 M problems of the test suite);
+ *  - CONVENTION for xf == x0 exactly on an axis: the constant term of that axis' cubic is zero, so one root is exactly 0 and is
+ *    NOT "the smallest positive root" (MinPositiveElement, solverGurobi_utils.hpp:19-32, tests v > 0); the candidates are the roots of
+ *    (j/6) t^2 + (a0/2) t + v0.  A floating-point root finder returns that zero as +-1e-17 depending on its last bit — the
+ *    reference's answer there is a property of the Eigen build it is linked against. */
 int fh_dt_initial_batch(fh_ctx* ctx, const fh_problem* problems, int n, double* dt);
 int fh_dt_initial_batch_device(fh_ctx* ctx, const fh_problem* d_problems, int n, double* d_dt);
 

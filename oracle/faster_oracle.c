@@ -92,8 +92,20 @@ static double polish3(double c3, double c2, double c1, double c0, double t) {
   return t;
 }
 
+static int real_roots_quad(double c2, double c1, double c0, double* out);
+
 /* real roots of c3 t^3 + c2 t^2 + c1 t + c0, c3 != 0; returns count */
 static int real_roots_cubic(double c3, double c2, double c1, double c0, double* out) {
+  /* [r6] CONVENTION (Eigen is absent, so its answer is not pinned): c0 == 0 exactly — start and goal coincide on this axis,
+   * solverGurobi.cpp:691-693 builds the constant term x0 - xf — factors the cubic as t (c3 t^2 + c2 t + c1): one root is EXACTLY zero, which
+   * MinPositiveElement (solverGurobi_utils.hpp:19-32: `v[i] > 0`) drops, and the others are the quadratic's roots by the quadratic's own
+   * closed form.  The general closed form below returns that zero root as +1e-17, 0 or -1e-17 depending on the last bit of cbrt / acos
+   * (two math libraries disagree on 0.025 % of such problems, and a companion-matrix eigenvalue solver would have a third opinion);
+   * "the smallest positive root" must not hinge on that. */
+  if (c0 == 0.0) {
+    out[0] = 0.0;
+    return 1 + real_roots_quad(c3, c2, c1, out + 1);
+  }
   double B = c2 / c3, C = c1 / c3, D = c0 / c3;
   double p = C - B * B / 3.0;
   double q = 2.0 * B * B * B / 27.0 - B * C / 3.0 + D;

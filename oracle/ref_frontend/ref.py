@@ -51,6 +51,29 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class _quiet_stdout:
+    """The reference's jps3d prints from inside the library (`ASTAR ERROR!` to stdout for every query without a path,
+    thirdparty/jps3d/src/jps_planner/graph_search.cpp:185; planner verbosity): file descriptor 1 points at /dev/null while the
+    compiled reference runs, so that its chatter does not bury pytest's summary.  Python-level sys.stdout is untouched."""
+
+    def __enter__(self):
+        import sys
+        try:
+            sys.stdout.flush()
+        except Exception:
+            pass
+        self._saved = os.dup(1)
+        self._null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self._null, 1)
+
+    def __exit__(self, *exc):
+        ctypes.CDLL(None).fflush(None)  # the C library's buffered stdout goes to /dev/null too, not to the terminal later
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        os.close(self._null)
+        return False
+
+
 def decompose(path, cloud, drone_radius=0.05, z_ground=0.0, max_rows=256):
     """JPS_Manager::cvxEllipsoidDecomp through the reference's EllipsoidDecomp3D: [(A, b)] per leg of the path (ground row last)."""
     path = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, 3)
@@ -93,7 +116,8 @@ class Map:
         out = np.zeros((max_pts, 3))
         cost = ctypes.c_double(0.0)
         nraw = ctypes.c_int(0)
-        k = lib().ref_map_plan(self._h, _p(s), _p(g), 1 if use_jps else 0, _p(out), max_pts, ctypes.byref(cost), ctypes.byref(nraw))
+        with _quiet_stdout():
+            k = lib().ref_map_plan(self._h, _p(s), _p(g), 1 if use_jps else 0, _p(out), max_pts, ctypes.byref(cost), ctypes.byref(nraw))
         if k < 0:
             raise RuntimeError("max_pts too small")
         return (out[:k].copy() if k > 0 else None), cost.value, nraw.value

@@ -49,6 +49,16 @@ def report(tag, res, min_nodes=0):
     outside = whole_problem - search_total - prof[:, 0] - prof[:, 1] - prof[:, 14] - prof[:, 17]
     print("   search() %.0f cyc/problem, of which outside its slots (stack bookkeeping, incumbent polls) %.0f; run_problem outside search / staging / dt / set-up / result write %.0f"
           % (search_total.mean(), (search_total - inner).mean(), outside.mean()))
+    p2 = res["coeff"][:, M - 6, :12].mean(axis=0)
+    if p2.sum() > 0:  # [r6] the finer slots (cycles per problem)
+        slot = lambda k: prof[:, k].mean()
+        print("   [r6] search(): prologue %.0f (of it screening %.0f) | backtrack blocks %.0f (of it restores %.0f) | before a node: limits, look, incumbent poll %.0f "
+              "(of it look-around %.0f) | qp_run %.0f (of it its slots 2-8: %.0f -> bind_assignment, cost + certificates outside scan, flop count %.0f)"
+              % (p2[0], slot(13), p2[1], slot(11), p2[2], slot(16), p2[3], prof[:, 2:9].sum(axis=1).mean(), p2[3] - prof[:, 2:9].sum(axis=1).mean()))
+        print("   [r6] staging: record + bad_input + LDS init %.0f | basis %.0f | faces %.0f ; trial loop %.0f (set-up %.0f + search %.0f + rest %.0f) ; "
+              "between the loop and the result write %.0f" % (p2[4], p2[5], slot(0) - p2[4] - p2[5], p2[6], slot(1), search_total.mean(),
+              p2[6] - slot(1) - search_total.mean(), p2[7]))
+        print("   [r6] ticket phase: up to take_task %.0f | pool / draw %.0f | order word %.0f" % (p2[8], p2[9], p2[10]))
     return denom / n
 
 

@@ -63,26 +63,21 @@ def test_time_allocation_alone_on_two_million_problems(ctx, oracle):
     oracle on 2 M problems of four kinds (generic states, at rest, idle axes, kilometres / micrometres).  Cubics BUILT with two roots
     at relative distances 1e-9 .. 1e-2 — where the root itself is only defined to ~1e-8 by either library's cbrt / acos — must agree to
     the float the reference stores (2 ulp), and nearly all of them exactly.
-    One class is chaotic in the REFERENCE's algorithm and is counted, not demanded: dx = 0 exactly on an axis puts a root of that axis'
-    cubic AT zero, and whether the closed form returns it as +1e-17 (then it is the "smallest positive root"), 0 or -1e-17 is the last bit
-    of cbrt / acos / cos — Eigen's companion-matrix eigenvalues have their own.  There the device runs the oracle's formulas with the
-    device library's transcendentals; what findDT makes of the value (max(dt_initial, 2 DC), solverGurobi.cpp:494-497) must agree for
-    more than 97 % of such problems, the count of the others is printed."""
+    [r6] dx = 0 exactly on an axis puts a root of that axis' cubic AT zero; the general closed form returns it as +1e-17, 0 or -1e-17 by
+    the last bit of cbrt / acos / cos (round 5 counted the disagreements between the device library and glibc: 0.025 %; Eigen's
+    companion-matrix eigenvalues would have their own).  Device and oracle now share a stated convention (fasterhip.h, faster_oracle.c:
+    real_roots_cubic): the cubic factors as t (c3 t^2 + c2 t + c1), the zero root is exactly zero — MinPositiveElement drops it — and
+    the others come from the quadratic's closed form.  That class is bit-identical too."""
     rng = np.random.default_rng(505)
     n = 1 << 19
     for kind in ("generic", "rest", "axis", "scale"):
         pr = _dt_problems(n, rng, kind)
         got, ref = ctx.dt_initial_batch(pr), oracle.dt_initial_batch(pr)
         at_zero = np.any(pr["xf"][:, :3] == pr["x0"][:, :3], axis=1)
-        bad = np.nonzero((got != ref) & ~at_zero)[0]
-        assert len(bad) == 0, (kind, len(bad), got[bad[:4]], ref[bad[:4]], pr["x0"][bad[:2]], pr["xf"][bad[:2]])
-        if at_zero.any():
-            floor = 2 * pr["dc"]
-            same = (got == ref)[at_zero]
-            same_dt = (np.maximum(got, floor) == np.maximum(ref, floor))[at_zero]
-            print("%s: %d problems with dx = 0 on an axis: dt_initial identical in %d, findDT's max(dt_initial, 2 DC) identical in %d"
-                  % (kind, at_zero.sum(), same.sum(), same_dt.sum()))
-            assert same_dt.mean() > 0.97, (kind, same_dt.mean())
+        bad = np.nonzero(got != ref)[0]
+        assert len(bad) == 0, (kind, len(bad), int(at_zero[bad].sum()), got[bad[:4]], ref[bad[:4]], pr["x0"][bad[:2]], pr["xf"][bad[:2]])
+        if kind == "axis":
+            assert at_zero.sum() > n // 2  # (the class the convention is about is really exercised)
         assert (ref > 0).mean() > 0.8
     pr = _dt_problems(n, rng, "close")
     got, ref = ctx.dt_initial_batch(pr), oracle.dt_initial_batch(pr)

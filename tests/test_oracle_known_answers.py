@@ -134,3 +134,58 @@ def test_control_points_two_routes_agree(oracle, fixture_corridor, known_answers
             assert np.max(faces["a"][f0:f1] @ a[0, t].T - faces["b"][f0:f1, None]) <= 1e-6
         if N > 1:
             np.testing.assert_allclose(a[0, :-1, 3], a[0, 1:, 0], rtol=0, atol=1e-9)   # C0: cp3 of a segment is cp0 of the next
+
+
+def test_time_allocation_when_start_and_goal_coincide_on_an_axis(oracle):
+    """[r6] getDTInitial (solverGurobi.cpp:659-759) with xf == x0 exactly on an axis: the constant term of that axis' cubic (:691-693)
+    is zero, one root is exactly 0 and is not positive (MinPositiveElement, solverGurobi_utils.hpp:19-32); what is left are the roots of
+    (j/6) t^2 + (a0/2) t + v0.  The oracle's convention (real_roots_cubic) against an independent evaluation: numpy's companion-matrix
+    roots of the QUADRATIC (the zero root divided out by hand), the reference's float casts, the maximum over the nine values."""
+    rng = np.random.default_rng(66)
+    n = 4096
+    pr = np.zeros(n, dtype=abi.problem_dtype)
+    pr["n_seg"] = rng.choice([6, 10, 15], n)
+    pr["dc"], pr["v_max"], pr["a_max"], pr["j_max"] = 0.01, 5.0, 5.0, 8.0
+    x0, xf = np.zeros((n, 9)), np.zeros((n, 9))
+    x0[:, :3] = rng.uniform(-10, 10, (n, 3))
+    xf[:, :3] = x0[:, :3] + rng.uniform(-6, 6, (n, 3))
+    same = rng.random((n, 3)) < 0.6
+    same[:, 0] |= ~same.any(axis=1)
+    xf[:, :3] = np.where(same, x0[:, :3], xf[:, :3])
+    x0[:, 3:6] = rng.uniform(-4, 4, (n, 3)) * (rng.random((n, 3)) < 0.8)
+    x0[:, 6:9] = rng.uniform(-4, 4, (n, 3)) * (rng.random((n, 3)) < 0.8)
+    pr["x0"], pr["xf"] = x0, xf
+    got = oracle.dt_initial_batch(pr)
+
+    def min_pos(roots):
+        r = [float(z.real) for z in roots if abs(z.imag) < 1e-12 and z.real > 0]
+        return min(r) if r else 0.0
+
+    worst = 0.0
+    for i in range(n):
+        vals = []
+        for a in range(3):
+            dx = xf[i, a] - x0[i, a]
+            sg = np.copysign(1.0, dx)
+            j, acc = float(np.float32(sg * 8.0)), float(np.float32(sg * 5.0))
+            v0, a0 = float(np.float32(x0[i, 3 + a])), float(np.float32(x0[i, 6 + a]))
+            vals.append(np.float32(abs(dx) / 5.0))
+            if dx == 0.0:
+                cub = min_pos(np.roots([j / 6.0, a0 / 2.0, v0])) if (a0 != 0 or v0 != 0) else 0.0
+            else:
+                cub = min_pos(np.roots([j / 6.0, a0 / 2.0, v0, -dx]))
+            vals.append(np.float32(cub))
+            vals.append(np.float32(min_pos(np.roots([0.5 * acc, v0, -dx]))))
+        want = float(np.float32(max(vals)) / np.float32(pr["n_seg"][i]))
+        worst = max(worst, abs(got[i] - want) / max(want, 1e-12))
+        assert got[i] == pytest.approx(want, rel=3e-7, abs=1e-12), (i, got[i], want, x0[i], xf[i])
+    # hand cases: at rest with nowhere to go -> 0; moving away on an idle axis: the positive root of the quadratic
+    p = pr[:2].copy()
+    p["x0"][:], p["xf"][:] = 0.0, 0.0
+    p["x0"][1, 3], p["x0"][1, 6] = 2.0, -3.0     # v0 = 2, a0 = -3, dx = 0 -> copysign(1, 0) = +1: (8/6) t^2 - 1.5 t + 2 has no real root
+    p["n_seg"] = 10
+    d = oracle.dt_initial_batch(p)
+    assert d[0] == 0.0 and d[1] == 0.0
+    p["x0"][1, 3] = -2.0                          # v0 = -2: (8/6) t^2 - 1.5 t - 2 = 0 -> t = (1.5 + sqrt(2.25 + 32/3)) / (8/3) = 1.9106...
+    d = oracle.dt_initial_batch(p)
+    assert d[1] == pytest.approx((1.5 + np.sqrt(2.25 + 32.0 / 3.0)) / (8.0 / 3.0) / 10.0, rel=2e-7)
