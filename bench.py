@@ -147,16 +147,24 @@ def dry_run(args, rank, world, local_rank):
         whole, faces = shard.shard_batch(whole, faces, rank, world)
     B = len(whole)
     per_rank = -(-pairs // world) if strong else B
-    PK = 64 + 96 * args.n_seg  # fh_pack_results record
-    wp, sp = torch.zeros(per_rank * PK, dtype=torch.uint8), torch.zeros(per_rank * PK, dtype=torch.uint8)
-    wp[: B * PK] = rank + 1
+    REC = 64 + 96 * args.n_seg  # fh_pack_results record
+    PK = shard.gather_bytes_per_problem(args.gather, args.n_seg)  # what the gather moves per problem: packed record / 48-byte head / nothing
+    wrec, srec = torch.zeros(per_rank * REC, dtype=torch.uint8), torch.zeros(per_rank * REC, dtype=torch.uint8)
+    wrec[: B * REC] = rank + 1
     gather = None
-    if world > 1:
+    if world > 1 and PK:
         gather = [torch.zeros(world * per_rank * PK, dtype=torch.uint8) for _ in range(2)] if strong else (
             [[torch.zeros(per_rank * PK, dtype=torch.uint8) for _ in range(world)] for _ in range(2)] if rank == 0 else None)
+    traffic = shard.gather_traffic(args.gather, args.n_seg, args.assume_pairs_per_s, world, strong)
+    if world > 1 and not traffic["within_budget"] and not args.allow_over_budget:
+        raise SystemExit("bench.py --dry-run: --gather %s at %.1f M pairs/s per GPU puts %.1f GB/s on every xGMI link (%.1f GB/s into one GPU); the stated "
+                         "budget is %.1f GB/s per link (%.0f %% of %.1f GB/s one way).  Use --gather summaries / none, or --allow-over-budget"
+                         % (args.gather, args.assume_pairs_per_s / 1e6, traffic["gather_GBps_per_link"], traffic["gather_GBps_into_busiest_gpu"],
+                            traffic["budget_GBps_per_link"], 100 * shard.XGMI_GATHER_BUDGET_FRACTION, shard.XGMI_LINK_ONE_WAY_GBPS))
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if world > 1:
+        if world > 1 and PK:
+            wp, sp = (wrec, srec) if args.gather == "records" else (shard.result_heads(wrec, per_rank, REC), shard.result_heads(srec, per_rank, REC))
             shard.gather_result_blocks(dist, wp, sp, gather, strong, rank)
     if world > 1:
         dist.barrier()
@@ -166,7 +174,9 @@ def dry_run(args, rank, world, local_rank):
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        if strong:
+        if not PK:
+            ok = True
+        elif strong:
             for r in range(world):
                 lo, hi = shard.shard_range(pairs, r, world)
                 ok &= bool((gather[0][r * per_rank * PK: (r * per_rank + hi - lo) * PK] == r + 1).all())
@@ -175,7 +185,9 @@ def dry_run(args, rank, world, local_rank):
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": "trajectory solves/sec (whole+safe pairs) at N=%d, deg=3" % args.n_seg, "value": None,
                           "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "strong" if strong else "weak",
-                          "backend": args.backend if world > 1 else None, "devices": devices, "pairs_per_rank": B, "gather_ok": bool(ok),
+                          "backend": args.backend if world > 1 else None, "devices": devices, "pairs_per_rank": B, "gather_ok": bool(ok), "gather": args.gather,
+                          "gather_bytes_per_problem": PK, **{k: traffic[k] for k in ("gather_GBps_per_link", "gather_GBps_into_busiest_gpu",
+                                                                                     "budget_GBps_per_link", "within_budget", "pairs_per_s_per_rank")},
                           "ms_per_step": 1e3 * elapsed / max(args.steps, 1)}))
     if world > 1:
         dist.barrier()
@@ -218,6 +230,14 @@ def main():
     ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N>1 run: nccl (= RCCL over xGMI, default); gloo only with --dry-run")
+    ap.add_argument("--gather", choices=["records", "summaries", "none"], default="summaries",
+                    help="what the per-step batch gather of an N>1 run moves over RCCL/xGMI: summaries (default) — the 48-byte head of every "
+                         "fh_result (solved, trials, status, counters, factor, dt, cost): what a planner that keeps its trajectories where they "
+                         "were solved needs; records — every packed fh_result (64 + 96 N bytes): at 20 M pairs/s that is 42 GB/s per rank, the "
+                         "same order as an xGMI link, so the N>1 number would measure the gather; none — results are consumed on their GPU")
+    ap.add_argument("--assume-pairs-per-s", type=float, default=21.4e6,
+                    help="--dry-run only: the per-GPU solve rate the gather's xGMI traffic is priced at (default: the measured 1-GPU C4 rate)")
+    ap.add_argument("--allow-over-budget", action="store_true", help="--dry-run only: report a gather above the stated xGMI budget instead of failing")
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, shard the batch and run the per-step gather of (zeroed) packed result records, but solve nothing: "
                          "checks the launcher and the N>1 plumbing where there is no GPU (tests/test_distributed_gloo.py); prints no `value`")
@@ -292,6 +312,7 @@ def main():
     d_whole, d_faces = to_dev(whole), to_dev(faces)
     RES = abi.result_dtype.itemsize
     PACKED = capi.packed_result_size(N)
+    GB = shard.gather_bytes_per_problem(args.gather, N)   # bytes per problem that the per-step gather moves (0: none)
     par = abi.default_params()
     if args.no_share:
         par["share"] = 0
@@ -318,13 +339,14 @@ def main():
         pp.d_wres = torch.zeros(per_rank * RES, dtype=torch.uint8, device=dev)  # (strong: padded to the largest shard)
         pp.d_sres = torch.zeros_like(pp.d_wres)
         pp.gather = None
-        if world > 1:  # what crosses xGMI: PACKED records (fh_pack_results_device: no dead coefficient rows, 64 + 96 N bytes each)
-            pp.d_wpack = torch.zeros(per_rank * PACKED, dtype=torch.uint8, device=dev)
-            pp.d_spack = torch.zeros_like(pp.d_wpack)
+        if world > 1 and GB:  # what crosses xGMI: PACKED records (fh_pack_results_device: no dead coefficient rows, 64 + 96 N bytes each) or their 48-byte heads
+            if args.gather == "records":
+                pp.d_wpack = torch.zeros(per_rank * PACKED, dtype=torch.uint8, device=dev)
+                pp.d_spack = torch.zeros_like(pp.d_wpack)
             if strong:
-                pp.gather = [torch.zeros(world * per_rank * PACKED, dtype=torch.uint8, device=dev) for _ in range(2)]
+                pp.gather = [torch.zeros(world * per_rank * GB, dtype=torch.uint8, device=dev) for _ in range(2)]
             elif rank == 0:
-                pp.gather = [[torch.zeros(per_rank * PACKED, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
+                pp.gather = [[torch.zeros(per_rank * GB, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
         return pp
 
     pipes = [make_pipe(args.r_margin) for _ in range(max(1, args.inflight))]
@@ -350,11 +372,16 @@ def main():
         pp = pipes[step_no[0] % len(pipes)]
         step_no[0] += 1
         run_step(pp, args.pipeline == "fused")
-        if world > 1:  # the batch gather: every result record (packed) of the step over RCCL/xGMI
-            pp.ctx.pack_results_device(pp.d_wres.data_ptr(), per_rank, N, pp.d_wpack.data_ptr())
-            pp.ctx.pack_results_device(pp.d_sres.data_ptr(), per_rank, N, pp.d_spack.data_ptr())
-            with torch.cuda.stream(pp.stream):
-                shard.gather_result_blocks(dist, pp.d_wpack, pp.d_spack, pp.gather, strong, rank)
+        if world > 1 and GB:  # the batch gather over RCCL/xGMI: the packed record of every result of the step, or its 48-byte head
+            if args.gather == "records":
+                pp.ctx.pack_results_device(pp.d_wres.data_ptr(), per_rank, N, pp.d_wpack.data_ptr())
+                pp.ctx.pack_results_device(pp.d_sres.data_ptr(), per_rank, N, pp.d_spack.data_ptr())
+                with torch.cuda.stream(pp.stream):
+                    shard.gather_result_blocks(dist, pp.d_wpack, pp.d_spack, pp.gather, strong, rank)
+            else:
+                with torch.cuda.stream(pp.stream):  # (the context launches on pp.stream: the strided copy is ordered behind the solve)
+                    shard.gather_result_blocks(dist, shard.result_heads(pp.d_wres, per_rank, RES), shard.result_heads(pp.d_sres, per_rank, RES),
+                                               pp.gather, strong, rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -427,9 +454,13 @@ def main():
                 "pipeline": args.pipeline,
                 "pipelines_in_flight": len(pipes),
                 "work_sharing": bool(par["share"]),
-                "parallelism": ("one batch sharded x%d (contiguous blocks), RCCL all_gather of the packed result records (%d B each)" % (world, PACKED)
-                                if strong else "batch per GPU x%d, RCCL gather of the packed result records (%d B each, %.1f MB per rank per step) on rank 0"
-                                % (world, PACKED, 2 * B * PACKED / 1e6)) if world > 1 else "single GPU",
+                "parallelism": (("one batch sharded x%d (contiguous blocks), RCCL all_gather of " % world if strong else "batch per GPU x%d, RCCL gather on rank 0 of " % world)
+                                + {"records": "the packed result records (%d B each)" % PACKED, "summaries": "the 48-byte result heads (flags, counters, factor, dt, cost)",
+                                   "none": "nothing (results stay on their GPU)"}[args.gather]
+                                + ": %.2f GB/s per xGMI link, %.2f GB/s into the busiest GPU at the measured rate (budget %.1f GB/s per link)"
+                                % tuple(shard.gather_traffic(args.gather, N, value / world, world, strong)[k] for k in
+                                        ("gather_GBps_per_link", "gather_GBps_into_busiest_gpu", "budget_GBps_per_link"))) if world > 1 else "single GPU",
+                **({"gather": shard.gather_traffic(args.gather, N, value / world, world, strong)} if world > 1 else {}),
                 "whole_solved_frac": float(wres["solved"].mean()),
                 "safe_solved_frac": float(sres["solved"].mean()),
                 "mean_bnb_nodes_whole": float(wres["nodes"].mean()),

@@ -49,6 +49,48 @@ def all_gather_rows(dist, local, per_rank):
     return out
 
 
+# ---- what the per-step gather moves, and what that costs on xGMI (SURVEY.md 8(e) priced the gather at 10 k solves/s) ----
+# One xGMI link of an MI355X: ~153.6 GB/s both directions together, i.e. ~76.8 GB/s one way, point to point between two GPUs (7 links
+# per GPU).  In the weak-scaling gather every rank sends to rank 0 over ITS link to rank 0; in the all_gather of a sharded batch every
+# rank sends its block to each of the other ranks over the link to that rank.  The stated budget: a gather may use a quarter of a
+# link's one-way rate — beyond that the 8-GPU number would measure the gather, not the solver.
+XGMI_LINK_ONE_WAY_GBPS = 76.8
+XGMI_GATHER_BUDGET_FRACTION = 0.25
+HEAD_BYTES = 48   # the head of an fh_result: solved, trials, status, nodes, qp_iters, kflops, factor, dt, cost
+GATHER_MODES = ("records", "summaries", "none")
+
+
+def gather_bytes_per_problem(mode, n_seg):
+    """records: the packed fh_result (64 + 96 N bytes, fh_pack_results); summaries: its 48-byte head (flags, counters, factor, dt, cost);
+    none: results are consumed where they are produced."""
+    if mode == "records":
+        return 64 + 96 * int(n_seg)
+    if mode == "summaries":
+        return HEAD_BYTES
+    if mode == "none":
+        return 0
+    raise ValueError(mode)
+
+
+def gather_traffic(mode, n_seg, pairs_per_s_per_rank, world, strong):
+    """GB/s the per-step gather puts on xGMI at a given solve rate (two problems per pair): what one rank sends, what one link carries,
+    what the busiest GPU receives — against the stated budget per link."""
+    per_rank = 2.0 * gather_bytes_per_problem(mode, n_seg) * float(pairs_per_s_per_rank) / 1e9
+    peers = max(int(world) - 1, 0)
+    budget = XGMI_LINK_ONE_WAY_GBPS * XGMI_GATHER_BUDGET_FRACTION
+    return {"mode": mode, "bytes_per_pair": 2 * gather_bytes_per_problem(mode, n_seg), "pairs_per_s_per_rank": float(pairs_per_s_per_rank),
+            "gather_GBps_sent_per_rank": per_rank * (peers if strong else (1 if peers else 0)),
+            "gather_GBps_per_link": per_rank if peers else 0.0,
+            "gather_GBps_into_busiest_gpu": per_rank * peers,
+            "link_one_way_GBps": XGMI_LINK_ONE_WAY_GBPS, "budget_GBps_per_link": budget, "within_budget": bool(per_rank <= budget)}
+
+
+def result_heads(results_u8, n, record_bytes):
+    """[n * record_bytes] uint8 tensor of fh_result (or packed) records -> [n * HEAD_BYTES]: the 48-byte heads, contiguous (a strided copy on
+    the current stream: plumbing, the solver is not involved)."""
+    return results_u8.view(n, record_bytes)[:, :HEAD_BYTES].contiguous().view(-1)
+
+
 def gather_result_blocks(dist, whole_results, safe_results, gather, strong, rank):
     """The per-step "batch gather" of bench.py: complete `fh_result` blocks, not summaries.
     whole_results / safe_results: uint8 tensors of this rank's per_rank records (a shorter shard is padded to per_rank).

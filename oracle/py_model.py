@@ -144,11 +144,14 @@ def enumerate_miqp(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, candidat
     return best, barg, nfeas
 
 
-def milp_feasible(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, big_m=1.0e3, time_limit=60.0):
+def milp_feasible(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, big_m=1.0e3, time_limit=60.0, ineq_slack=0.0):
     """Feasibility of the reference's mixed-integer constraint set at one dt, decided by an independent third-party
     branch-and-cut code (HiGHS through scipy.optimize.milp): 12N coefficients + one binary per (segment, polytope),
     sum_p b[t][p] == 1, and the indicator rows of setPolytopesConstraints (:283-286) written with a big-M.
-    Returns True / False (None if HiGHS hits its limits).  Objective: none (feasibility only)."""
+    Returns True / False (None if HiGHS hits its limits).  Objective: none (feasibility only).
+    ineq_slack: added to the right-hand side of every inequality row (box and corridor): > 0 relaxes, < 0 tightens — HiGHS decides with its
+    own primal feasibility tolerance (1e-7), the kernels with feas_tol = 1e-9; a caller that finds the two disagreeing asks again with
+    +-1e-6 to tell a marginal instance (the verdict flips with the slack) from a real disagreement."""
     from scipy.optimize import Bounds, LinearConstraint, milp
 
     P = len(polys)
@@ -159,7 +162,7 @@ def milp_feasible(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, big_m=1.0
     for a, b in zip(Aeq, beq):
         rows.append(np.concatenate([a, np.zeros(N * P)])); lo.append(b); hi.append(b)
     for a, b in zip(Ain, bin_):
-        rows.append(np.concatenate([a, np.zeros(N * P)])); lo.append(-np.inf); hi.append(b)
+        rows.append(np.concatenate([a, np.zeros(N * P)])); lo.append(-np.inf); hi.append(b + ineq_slack)
     for t in range(N):
         r = np.zeros(nv)
         r[nc + t * P: nc + (t + 1) * P] = 1.0
@@ -170,7 +173,7 @@ def milp_feasible(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, big_m=1.0
                     r = np.zeros(nv)
                     r[:nc] = sum(A[f][i] * _cp(t, k, i, N, dt) for i in range(3))
                     r[nc + t * P + p] = big_m          # a.cp <= b + M (1 - b_tp)
-                    rows.append(r); lo.append(-np.inf); hi.append(b[f] + big_m)
+                    rows.append(r); lo.append(-np.inf); hi.append(b[f] + big_m + ineq_slack)
     cons = LinearConstraint(np.array(rows), np.array(lo), np.array(hi))
     integrality = np.concatenate([np.zeros(nc), np.ones(N * P)])
     bounds = Bounds(np.concatenate([np.full(nc, -1e4), np.zeros(N * P)]), np.concatenate([np.full(nc, 1e4), np.ones(N * P)]))

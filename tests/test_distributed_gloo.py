@@ -153,6 +153,49 @@ def test_bench_launches_its_own_ranks_dry_run():
         assert out["pairs_per_rank"] == (19 if scaling == "strong" else 37)
 
 
+def test_bench_gather_modes_and_the_xgmi_budget():
+    """at 21 M pairs/s a rank emits 42 GB/s of packed records, so the gather is a choice with a price.  --gather records |
+    summaries | none: the dry run moves exactly those bytes over gloo, prices them per xGMI link at the assumed solve rate, and refuses a
+    gather above the stated budget (a quarter of a link's one-way rate) unless told otherwise."""
+    import json
+
+    def run(extra):
+        p = _bench(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "2", "--pairs", "37"] + extra)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return p, (json.loads(line[0]) if len(line) == 1 else None)
+
+    for scaling in ("weak", "strong"):
+        p, out = run(["--scaling", scaling])  # default: summaries
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert out["gather"] == "summaries" and out["gather_bytes_per_problem"] == 48 and out["gather_ok"] and out["within_budget"]
+        assert abs(out["gather_GBps_per_link"] - 2 * 48 * 21.4e6 / 1e9) < 1e-9
+        p, out = run(["--scaling", scaling, "--gather", "none"])
+        assert p.returncode == 0 and out["gather_bytes_per_problem"] == 0 and out["gather_GBps_per_link"] == 0.0 and out["within_budget"]
+        p, out = run(["--scaling", scaling, "--gather", "records"])  # 2 * 1024 B * 21.4 M/s = 43.8 GB/s per link > 19.2
+        assert p.returncode != 0 and "budget" in p.stderr, (p.stdout, p.stderr[-500:])
+        p, out = run(["--scaling", scaling, "--gather", "records", "--allow-over-budget"])
+        assert p.returncode == 0 and out["gather_ok"] and not out["within_budget"] and out["gather_bytes_per_problem"] == 64 + 96 * 10
+        assert abs(out["gather_GBps_into_busiest_gpu"] - out["gather_GBps_per_link"]) < 1e-9  # world 2: one peer
+        p, out = run(["--scaling", scaling, "--gather", "records", "--assume-pairs-per-s", "1e6"])  # 2 GB/s per link: inside
+        assert p.returncode == 0 and out["within_budget"]
+
+
+def test_gather_traffic_arithmetic():
+    from faster_amd import shard
+
+    t = shard.gather_traffic("records", 10, 20.4e6, 8, False)
+    assert abs(t["gather_GBps_per_link"] - 41.78) < 0.01 and abs(t["gather_GBps_into_busiest_gpu"] - 7 * t["gather_GBps_per_link"]) < 1e-9
+    assert not t["within_budget"]
+    t = shard.gather_traffic("summaries", 10, 20.4e6, 8, True)
+    assert abs(t["gather_GBps_per_link"] - 1.9584) < 1e-6 and t["within_budget"] and abs(t["gather_GBps_sent_per_rank"] - 7 * 1.9584) < 1e-6
+    assert shard.gather_traffic("none", 10, 20.4e6, 8, False)["gather_GBps_per_link"] == 0.0
+    import torch
+
+    rec = torch.arange(5 * 100, dtype=torch.uint8)
+    h = shard.result_heads(rec, 5, 100)
+    assert h.numel() == 5 * 48 and bool((h.view(5, 48) == rec.view(5, 100)[:, :48]).all())
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     """--gpus 8 inside a 1-rank environment must not print a 1-GPU number; and without devices the launcher fails loudly."""
     p = _bench(["--gpus", "8", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})

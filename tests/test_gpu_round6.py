@@ -1,0 +1,202 @@
+"""GPU tests added in round 6 (all through the C ABI).
+
+Third-party parity AT THE BASELINE SIZES, ON GPU OUTPUT: Gurobi is absent, so `m.optimize()` (solverGurobi.cpp:566) cannot be
+run here; what CAN be had from software the builder did not write is
+  * HiGHS (scipy.optimize.milp) deciding the reference's mixed-integer constraint set — the unreduced 12 N coefficients, one binary per
+    (segment, polytope), big-M indicator rows, oracle/py_model.py:milp_feasible — at the dt the GPU reports: feasible at
+    factor_that_worked_ (solverGurobi.cpp:445-446, :580-581), infeasible at every earlier factor of the window, and infeasible at ALL ten
+    factors for safe problems the GPU reports unsolved;
+  * the global optimum over every one of the P^N assignments at N = 10 (59 049 pure QPs per problem through fh_problem.pin — the GPU
+    solves them in a fraction of a second), with SciPy's SLSQP on the unreduced model confirming the winner's cost.
+"""
+import itertools
+import multiprocessing
+import os
+
+import numpy as np
+import pytest
+
+from faster_amd import abi, capi, corridor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch  # noqa: F401  (torch first: one HIP runtime in the process)
+
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _polys_of(p, faces):
+    fb = int(p["face_begin"])
+    return [(faces["a"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy(), faces["b"][fb + p["face_off"][q]: fb + p["face_off"][q + 1]].copy())
+            for q in range(int(p["n_poly"]))]
+
+
+def _highs_job(job):
+    """(tag, expect_feasible, N, dt, x0, xf, v, a, j, force, polys) -> (tag, expect, verdict, marginal)"""
+    from oracle import py_model
+
+    tag, expect, N, dt, x0, xf, v, a, j, force, polys = job
+    got = py_model.milp_feasible(N, dt, x0, xf, v, a, j, force, polys)
+    marginal = False
+    if got is not None and got != expect:
+        # HiGHS decides with a primal tolerance of 1e-7, the kernel with 1e-9: ask again with every inequality moved by 1e-6 TOWARDS the
+        # kernel's answer.  If HiGHS then agrees the instance is marginal (its verdict hangs on 1e-6 of slack); if not, it is a real
+        # disagreement.
+        again = py_model.milp_feasible(N, dt, x0, xf, v, a, j, force, polys, ineq_slack=1e-6 if expect else -1e-6)
+        marginal = again == expect
+    return tag, expect, got, marginal
+
+
+def _run_highs(jobs):
+    workers = max(1, min(16, (os.cpu_count() or 2) - 1))
+    try:
+        with multiprocessing.get_context("fork").Pool(workers) as pool:  # (the children run SciPy only: nothing of HIP is touched after the fork)
+            return pool.map(_highs_job, jobs, chunksize=4)
+    except Exception:
+        return [_highs_job(j) for j in jobs]
+
+
+def _factor_jobs(tag, p, faces, r, base, n_seg, force, all_factors_if_unsolved=True):
+    """The HiGHS questions one GPU result raises: feasible at its dt; infeasible at every earlier factor (or at every factor of the window)."""
+    polys = _polys_of(p, faces)
+    args = (n_seg, p["x0"].copy(), p["xf"].copy(), float(p["v_max"]), float(p["a_max"]), float(p["j_max"]), force, polys)
+    jobs = []
+    f, k = float(p["f_init"]), 0
+    while f <= float(p["f_final"]):
+        dt = f * base
+        k += 1
+        if r["solved"] and k == int(r["trials"]):
+            assert dt == r["dt"] and f == r["factor"], (tag, dt, r["dt"])
+            jobs.append(((tag, k), True, args[0], dt) + args[1:])
+            break
+        if r["solved"] or all_factors_if_unsolved:
+            jobs.append(((tag, k), False, args[0], dt) + args[1:])
+        f = f + float(p["f_inc"])
+    return jobs
+
+
+def _judge(results, what, min_checks):
+    bad = [(t, e, g) for t, e, g, m in results if g is not None and g != e and not m]
+    marginal = [t for t, e, g, m in results if m]
+    undecided = [t for t, e, g, m in results if g is None]
+    n = len(results)
+    print("%s: %d HiGHS verdicts (%d 'feasible', %d 'infeasible' expected), %d marginal (flip with 1e-6 of slack), %d undecided, %d disagree"
+          % (what, n, sum(1 for r in results if r[1]), sum(1 for r in results if not r[1]), len(marginal), len(undecided), len(bad)))
+    assert n >= min_checks, (what, n)
+    assert not bad, (what, bad[:8])
+    assert len(marginal) <= max(2, n // 100), (what, marginal[:8])
+    assert len(undecided) <= max(2, n // 100), (what, undecided[:8])
+
+
+def test_highs_confirms_flag_and_first_feasible_factor_of_c4_pairs(ctx):
+    """BASELINE config C4 (N = 10, <= 6 polytopes whole / <= 3 safe): 512 pairs of the bench batch (seed 3) through the fused pair
+    kernel.  For every whole result and every safe result HiGHS is asked about the reference's own mixed-integer constraint set
+    (solverGurobi.cpp:180-291, :332-407, :499-524) at the GPU's dt: feasible at the factor the GPU reports, infeasible at every
+    earlier factor of the window — and infeasible at all ten factors for (at least 64) safe problems the GPU reports unsolved.  This
+    pins `solved` and factor_that_worked_ (:445-446, :580-581) against a solver the builder did not write."""
+    from test_gpu_round3 import fused_pairs
+
+    B = 512
+    whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    wres, sres, safe, sfaces = fused_pairs(ctx, whole, faces, corridor.safe_templates(whole), 10, 0.05)
+    base_w = np.maximum(ctx.dt_initial_batch(whole), 2 * whole["dc"])
+    jobs = []
+    for i in range(B):
+        jobs += _factor_jobs(("whole", i), whole[i], faces, wres[i], float(base_w[i]), 10, True)
+    res = _run_highs(jobs)
+    _judge(res, "C4 whole problems", 512)
+    assert wres["solved"].mean() > 0.99
+    live = np.nonzero(safe["n_seg"] > 0)[0]
+    base_s = np.maximum(ctx.dt_initial_batch(safe), 2 * safe["dc"])
+    unsolved = [i for i in live if not sres[i]["solved"]]
+    assert len(unsolved) >= 64, len(unsolved)
+    jobs = []
+    for i in live:
+        if sres[i]["solved"] or i in unsolved[:64]:
+            jobs += _factor_jobs(("safe", int(i)), safe[i], sfaces, sres[i], float(base_s[i]), 10, False)
+    res = _run_highs(jobs)
+    _judge(res, "C4 safe problems (incl. 64 unsolved: all ten factors)", 1000)
+    all_ten = [t for t, e, g, m in res if t[0][1] in unsolved[:64]]
+    assert len(all_ten) == 64 * 10
+
+
+def test_highs_confirms_flag_and_first_feasible_factor_at_n15(ctx):
+    """The same at BASELINE config C5's size: N = 15, <= 8 polytopes (96 synthetic corridors, 64 of them checked)."""
+    pr, faces, _ = corridor.whole_batch(96, seed=615, n_seg=15, p_choices=(4, 5, 6, 7, 8))
+    res = ctx.solve_batch(pr, faces)
+    base = np.maximum(ctx.dt_initial_batch(pr), 2 * pr["dc"])
+    jobs = []
+    for i in range(64):
+        jobs += _factor_jobs(("n15", i), pr[i], faces, res[i], float(base[i]), 15, True)
+    _judge(_run_highs(jobs), "N = 15 whole problems", 64)
+    assert res["solved"][:64].mean() > 0.8
+
+
+def _pinned_copies(p, n_seg, P, factor):
+    """Every one of the P^N assignments of one problem as pinned copies solved at ONE factor (a pure QP each: BASELINE config 1's mechanism)."""
+    combos = np.array(list(itertools.product(range(P), repeat=n_seg)), dtype=np.uint64)  # [P^N, N]
+    w = np.zeros(len(combos), dtype=np.uint64)
+    for t in range(n_seg):
+        w |= (combos[:, t] + np.uint64(1)) << np.uint64(4 * t)
+    out = np.repeat(p.reshape(1), len(combos))
+    out["pin"][:, 0] = (w & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    out["pin"][:, 1] = (w >> np.uint64(32)).astype(np.uint32)
+    out["f_init"], out["f_final"], out["f_inc"] = factor, factor, 1.0
+    return out, combos
+
+
+def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ctx):
+    """Global optimality at N = 10 without trusting the tree search: for 24 whole problems with 3 polytopes (3^10 = 59 049 assignments
+    each) and 16 safe problems of fused C4 pairs (<= 3 polytopes), EVERY assignment is solved as a pure QP through fh_problem.pin at the
+    factor the branch and bound reported (the GPU does ~2 M QPs here).  The minimum over the feasible ones must be the branch and
+    bound's cost (1e-9 relative) under the same or an equally cheap assignment, the EARLIER factors must have no feasible assignment
+    at all, and SciPy's SLSQP on the reference's unreduced 12 N-coefficient model (oracle/py_model.py) must confirm the winner's cost.
+    The reference has no way to fix its binaries (they are private, solverGurobi.cpp:208-230); with a Gurobi licence the same
+    enumeration would be P = 1 corridors per assignment."""
+    from oracle import py_model
+    from test_gpu_round3 import fused_pairs
+
+    whole, faces, _ = corridor.whole_batch(24, seed=610, n_seg=10, p_choices=(3,))
+    wres = ctx.solve_batch(whole, faces)
+    w2, f2, _ = corridor.whole_batch(96, seed=611, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    w2res, sres, safe, sfaces = fused_pairs(ctx, w2, f2, corridor.safe_templates(w2), 10, 0.05)
+    pick = [j for j in np.nonzero((safe["n_seg"] > 0) & (sres["solved"] == 1) & (safe["n_poly"] >= 2))[0]][:16]
+    assert len(pick) == 16
+    cases = [("whole", whole[i], faces, wres[i], True) for i in range(len(whole)) if wres[i]["solved"]]
+    cases += [("safe", safe[j], sfaces, sres[j], False) for j in pick]
+    assert len(cases) >= 32
+    total_qps = 0
+    for kind, p, fcs, r, force in cases:
+        P = int(p["n_poly"])
+        # the winning factor: the minimum over all assignments
+        copies, combos = _pinned_copies(p, 10, P, float(r["factor"]))
+        got = ctx.solve_batch(copies, fcs)
+        total_qps += len(copies)
+        ok = got["solved"] == 1
+        assert ok.any(), kind
+        assert np.all(got["dt"][ok] == r["dt"])
+        best = int(np.argmin(np.where(ok, got["cost"], np.inf)))
+        assert got["cost"][best] == pytest.approx(r["cost"], rel=1e-9, abs=1e-12), (kind, got["cost"][best], r["cost"])
+        assert r["cost"] <= got["cost"][ok].min() * (1 + 1e-9) + 1e-12
+        if list(combos[best]) != [int(a) for a in r["assign"][:10]]:   # another assignment of the same cost (two polytopes hold the segment)
+            mine = np.nonzero((combos == np.array(r["assign"][:10], dtype=np.uint64)).all(axis=1))[0]
+            assert len(mine) == 1 and ok[mine[0]] and got["cost"][mine[0]] == pytest.approx(r["cost"], rel=1e-9, abs=1e-12)
+        # every earlier factor of the window: no assignment at all is feasible (factor_that_worked_ is the FIRST feasible one)
+        f = float(p["f_init"])
+        while f < float(r["factor"]):
+            earlier, _ = _pinned_copies(p, 10, P, f)
+            e = ctx.solve_batch(earlier, fcs)
+            total_qps += len(earlier)
+            assert e["solved"].sum() == 0, (kind, f, int(e["solved"].sum()))
+            f = f + float(p["f_inc"])
+        # SciPy on the unreduced model confirms the winner
+        s = py_model.solve_fixed(10, float(r["dt"]), p["x0"], p["xf"], float(p["v_max"]), float(p["a_max"]), float(p["j_max"]), force, _polys_of(p, fcs),
+                                 [int(a) for a in combos[best]])
+        assert s is not None and s[0] == pytest.approx(r["cost"], rel=1e-6, abs=1e-7), (kind, s and s[0], r["cost"])
+    print("%d problems, %d pinned QPs on the GPU" % (len(cases), total_qps))
+    assert total_qps > 1_500_000
