@@ -230,6 +230,12 @@ def main():
     ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N>1 run: nccl (= RCCL over xGMI, default); gloo only with --dry-run")
+    ap.add_argument("--pair-outputs", action="store_true",
+                    help="fh_sched.pair_outputs = 1 for the timed pipelines: the fused pair launch writes every safe problem (record + rows) to memory, as the "
+                         "staged hand-off does; default off = the library's default: a safe problem is built in LDS and written only if it is shared")
+    ap.add_argument("--full-results", action="store_true",
+                    help="fh_sched.compact_results = 0 for the timed pipelines: every word of every 1600-byte fh_result is written; default: only the "
+                         "coefficient rows the kernel is built for (1024 bytes at N = 10) — what a caller that streams batches sets")
     ap.add_argument("--gather", choices=["records", "summaries", "none"], default="summaries",
                     help="what the per-step batch gather of an N>1 run moves over RCCL/xGMI: summaries (default) — the 48-byte head of every "
                          "fh_result (solved, trials, status, counters, factor, dt, cost): what a planner that keeps its trajectories where they "
@@ -326,7 +332,7 @@ def main():
     def make_pipe(r_margin):
         pp = Pipe()
         pp.stream = torch.cuda.Stream(device=dev)
-        pp.ctx = capi.Context(local_rank)
+        pp.ctx = capi.Context(local_rank, pair_outputs=args.pair_outputs, compact_results=not args.full_results)  # (the library's defaults are lazy pair outputs, full records)
         pp.ctx.set_stream(pp.stream.cuda_stream)
         pp.ctx.set_params(par)
         pp.ctx.set_pair_margin(r_margin)
@@ -412,6 +418,16 @@ def main():
     share_stats = last.ctx.share_stats()
     wres = last.d_wres.cpu().numpy().view(abi.result_dtype)[:B]
     sres = last.d_sres.cpu().numpy().view(abi.result_dtype)[:B]
+    if args.pipeline == "fused" and not args.pair_outputs:
+        # the timed launches built the safe problems on chip; their records and rows (face counts for the algorithmic bytes, the pinned
+        # re-solve of the compute leg) come from ONE more launch, untimed, with complete pair outputs — the same results bit for bit
+        for pp in {id(last): last, id(pipes[0]): pipes[0]}.values():
+            pp.ctx.set_sched(pair_outputs=1, **({"workgroups_per_cu": args.wg_per_cu} if args.wg_per_cu else {}))
+            run_step(pp, True)
+            pp.ctx.sync()
+            pp.ctx.set_sched(pair_outputs=0, **({"workgroups_per_cu": args.wg_per_cu} if args.wg_per_cu else {}))
+        again = last.d_sres.cpu().numpy().view(abi.result_dtype)[:B]
+        assert all(np.array_equal(again[f], sres[f]) for f in ("solved", "trials", "status", "factor", "dt", "cost")), "pair_outputs changed a result"
     safe_h = last.d_safe.cpu().numpy().view(abi.problem_dtype)
     sfaces_h = last.d_sfaces.cpu().numpy().view(abi.face_dtype)
 
@@ -453,6 +469,8 @@ def main():
                 "pairs_per_gpu": B,
                 "pipeline": args.pipeline,
                 "pipelines_in_flight": len(pipes),
+                "pair_outputs": "complete (every safe problem written to memory)" if args.pair_outputs else "lazy (a safe problem is built on chip; written only when shared between workgroups)",
+                "result_rows": "all 16" if args.full_results else "compact (the %d rows of the kernel's segment bucket)" % (6 if N <= 6 else (10 if N <= 10 else (15 if N <= 15 else 16))),
                 "work_sharing": bool(par["share"]),
                 "parallelism": (("one batch sharded x%d (contiguous blocks), RCCL all_gather of " % world if strong else "batch per GPU x%d, RCCL gather on rank 0 of " % world)
                                 + {"records": "the packed result records (%d B each)" % PACKED, "summaries": "the 48-byte result heads (flags, counters, factor, dt, cost)",

@@ -407,7 +407,11 @@ class Map:
 class Context:
     """One solver context (one HIP stream). Mirrors one SolverGurobi object's GRBEnv/GRBModel."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, pair_outputs=True, compact_results=False):
+        """pair_outputs / compact_results: fh_sched.pair_outputs / .compact_results of this context, kept across set_sched calls.  The
+        LIBRARY's defaults are 0 / 0 (a fused pair launch writes the safe problems to memory only when it has to, every word of every
+        result is written); this wrapper — the tests and tools read d_safe / d_safe_faces back — asks for complete pair outputs unless
+        told otherwise.  bench.py's timed pipelines run pair_outputs=False, compact_results=True: what a streaming caller sets."""
         self._h = ctypes.c_void_p()
         rc = lib().fh_create(ctypes.byref(self._h), device)
         if rc != 0:
@@ -416,6 +420,9 @@ class Context:
                 lib().fh_destroy(self._h)
                 self._h = None
             raise FasterHipError("fh_create: rc=%d %s" % (rc, msg))
+        self._sticky = {"pair_outputs": 1 if pair_outputs else 0, "compact_results": 1 if compact_results else 0}
+        if pair_outputs or compact_results:
+            self.set_sched()
 
     def close(self):
         if self._h:
@@ -444,10 +451,14 @@ class Context:
         cloud_blocks, workgroups_per_cu, child_bound); unnamed fields keep their defaults.  No result field depends on them.
         workgroups_per_cu in 1..8 also selects the kernel build for two wavefronts per SIMD (a batch alone on the device is done sooner)."""
         s = abi.default_sched()
+        for k in ("pair_outputs", "compact_results"):
+            if k in kw:
+                self._sticky[k] = 1 if kw[k] else 0
+            s[k] = self._sticky[k]
         for k, v in kw.items():
             if k == "child_bound":   # the field is fh_sched.no_child_bound (0 = default: the bound is on)
                 s["no_child_bound"] = 0 if v else 1
-            else:
+            elif k not in self._sticky:
                 s[k] = v
         s = np.ascontiguousarray(s).reshape(1)
         self._check(lib().fh_set_sched(self._h, abi.ptr(s)), "fh_set_sched")

@@ -170,6 +170,15 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   sa.giant_nodes = 1 << 30;
   sa.giant_factor = ctx->sched.publish_factor;
   sa.child_bound = ctx->sched.no_child_bound ? 0 : 1;
+  sa.compact_results = ctx->sched.compact_results ? 1 : 0;
+  sa.pair_outputs = ctx->sched.pair_outputs ? 1 : 0;
+  sa.pad0 = 0;
+  sa.whole = PAIRS ? d_problems : nullptr;
+  sa.wfaces = d_faces;
+  sa.safe = PAIRS ? ka.safe : nullptr;
+  sa.sfaces = PAIRS ? ka.sfaces : nullptr;
+  sa.shrink = ka.shrink;
+  sa.r_margin = ka.r_margin;
   ka.par = ctx->par;
   ka.workspace = (double*)ctx->d_buf[5];
   ka.basis = (const double*)ctx->d_buf[15];
@@ -327,6 +336,8 @@ void fh_default_sched(fh_sched* s) {
   s->waiting_workgroups = 0;
   s->min_nodes = 2;
   s->no_child_bound = 0;
+  s->compact_results = 0;
+  s->pair_outputs = 0;
   s->cloud_blocks = 1;
   s->struct_size = (int32_t)sizeof(fh_sched);
 }
@@ -767,7 +778,7 @@ int fh_sample_batch(fh_ctx* ctx, const fh_problem* problems, const fh_result* re
 __global__ void __launch_bounds__(64) dt_initial_kernel(const fh_problem* __restrict__ problems, int n, double* __restrict__ dt) {
   const int lane = threadIdx.x;
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    const double v = fh::dt_initial(problems[i], lane);
+    const double v = fh::dt_initial(problems[i], fh::X0Rec<fh_problem>{problems[i]}, lane);
     if (lane == 0) dt[i] = v;
   }
 }

@@ -269,34 +269,121 @@ __device__ inline bool choose_r_index(const PW& pw, const RW& rw, double r_frac,
   return true;
 }
 
+// ---- pieces of the hand-off that its three users share — the staged kernel (pair_glue_kernel), the fused pair kernel's on-chip
+// hand-off (Solver::handoff_onchip, fh_solve.hip.hpp) and the write-back of a safe problem (write_safe_problem) —: ONE copy of every
+// formula, so that all of them round alike ----
+// (no contraction into fused multiply-adds left to the optimiser's choice per inline site: the three users must produce the same bits)
+__device__ __forceinline__ double glue_face_norm(const fh_face& fc) {
+#pragma clang fp contract(off)
+  return sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+}
+// how far R is outside row fc of the (shrunk) whole corridor: > slack means outside
+__device__ __forceinline__ double glue_face_test(const fh_face& fc, double nr, const double (&Rp)[3], double test_shrink) {
+#pragma clang fp contract(off)
+  return fc.a[0] * Rp[0] + fc.a[1] * Rp[1] + fc.a[2] * Rp[2] - (fc.b - test_shrink * nr);
+}
+// right-hand side of row fc in the safe corridor: shrunk by `shrink` metres; a row of the polytope that holds R (first) is not pulled
+// closer to R than r_margin, and never past R (keep_r: r_margin >= 0)
+__device__ __forceinline__ double glue_face_b(const fh_face& fc, double nr, const double (&Rp)[3], double shrink, bool keep_r, bool first, double r_margin) {
+#pragma clang fp contract(off)
+  double b = fc.b - shrink * nr;
+  if (keep_r && first) {
+    const double ar = fc.a[0] * Rp[0] + fc.a[1] * Rp[1] + fc.a[2] * Rp[2];
+    b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
+  }
+  return b;
+}
+// R = the state of the whole trajectory at the sample the rule picks (k).  false: the pair has no safe problem (no whole trajectory:
+// the reference returns from replan; or needToComputeSafePath == false).
+template <class PW, class RW>
+__device__ __forceinline__ bool glue_find_r(const PW& pw, const RW& rw, double r_frac, const fh_pair_rule& rule, int lane, const UnknownGrid* ug,
+                                            fh_state& R, unsigned long long* probe) {
+  // (R is evaluated on every path — at the start of the trajectory when there is nothing to hand off — so that a caller may run on
+  // unconditionally and decide at its end; rows of an unsolved result are zeros)
+  bool ok = rw.solved && pw.n_seg >= 1 && pw.n_seg <= FH_MAX_SEG;
+  const int N = pw.n_seg;
+  const double dt = rw.dt, DC = pw.dc;
+  int k = 0, size = 2;
+  if (ok) {
+    size = sample_count(pw, rw);
+    ok = choose_r_index(pw, rw, r_frac, rule, lane, k, ug);
+  }
+  if (probe) probe[0] = __builtin_readcyclecounter();
+  double t = 0;
+  int interval = 0;
+  if (ok) clock_at(k, DC, dt, N, t, interval);  // the reference's clock at sample k (solverGurobi.cpp:131-135) — its own double, not (k + 1) DC: fh_clock.hpp
+  if (probe) probe[1] = __builtin_readcyclecounter();
+  eval_state(rw.coeff[interval], t - interval * dt, ok && k == size - 1, R);
+  return ok;
+}
+// first polytope whose worst row lets R in (worst <= slack), else the least violated one
+__device__ __forceinline__ int glue_pick_start(const double (&worst_p)[FH_MAX_POLY], int P, double slack_ok) {
+  int start = 0;
+  double best = INFINITY;
+  bool found = false;
+#pragma unroll
+  for (int p = 0; p < FH_MAX_POLY; p++) {
+    if (p < P && !found) {
+      if (worst_p[p] <= slack_ok) { start = p; found = true; }
+      else if (worst_p[p] < best) { best = worst_p[p]; start = p; }
+    }
+  }
+  return start;
+}
+// The safe problem of a pair as a record + face rows in memory: x0 = R, the corridor = `cnt` polytopes of the whole corridor from
+// polytope `start` on (rows [src0, src0 + total) of the whole problem, the first first_end of them the polytope that holds R), written at
+// the whole problem's face_begin.  woff: the whole problem's face offsets.  WT: write-through stores (see glue_store).
+template <bool WT, class OFF>
+__device__ __forceinline__ void glue_write_safe(const fh_face* wfaces, int fb, const OFF& woff, int start, int cnt, const double (&x0)[9], double shrink,
+                                                double r_margin, fh_problem& ps, fh_face* sfaces, int lane, unsigned long long* probe) {
+  const bool keep_r = r_margin >= 0.0;
+  const double Rp[3] = {x0[0], x0[1], x0[2]};
+  if (lane < 9) {  // (selected, not indexed: an array indexed by the lane would live in scratch memory)
+    double v = x0[0];
+#pragma unroll
+    for (int j = 1; j < 9; j++) v = lane == j ? x0[j] : v;
+    glue_store<WT>(&ps.x0[lane], v);
+  }
+  const int src0 = cnt ? woff[start] : 0;
+  const int total = cnt ? woff[start + cnt] - src0 : 0;
+  const int first_end = cnt ? woff[start + 1] - src0 : 0;  // rows of the polytope that holds R
+  if (WT) {
+    // write-through stores are one fabric write per separate piece: lane = one DOUBLE of the output (4 per face row), so that an
+    // instruction writes 512 contiguous bytes (a lane per face row, 8 bytes at a stride of 32, cost 8x the HBM write traffic)
+    double* out = reinterpret_cast<double*>(sfaces + fb);
+    for (int j = lane; j < 4 * total; j += 64) {
+      const int f = j >> 2, c = j & 3;
+      const fh_face fc = wfaces[fb + src0 + f];
+      const double b = glue_face_b(fc, glue_face_norm(fc), Rp, shrink, keep_r, f < first_end, r_margin);
+      glue_store<true>(out + j, c == 0 ? fc.a[0] : (c == 1 ? fc.a[1] : (c == 2 ? fc.a[2] : b)));
+    }
+  } else {
+    for (int f = lane; f < total; f += 64) {
+      fh_face fc = wfaces[fb + src0 + f];
+      fc.b = glue_face_b(fc, glue_face_norm(fc), Rp, shrink, keep_r, f < first_end, r_margin);
+      sfaces[fb + f] = fc;
+    }
+  }
+  if (probe) probe[3] = __builtin_readcyclecounter();
+  if (lane <= FH_MAX_POLY) {
+    const int p = lane < cnt ? lane : cnt;
+    glue_store<WT>(&ps.face_off[lane], cnt ? woff[start + p] - src0 : 0);
+  }
+  if (lane == 0) {
+    glue_store<WT>(&ps.n_poly, (int32_t)cnt);
+    glue_store<WT>(&ps.face_begin, (int32_t)fb);
+  }
+}
+
 template <bool WT = false, class PW = fh_problem, class RW = fh_result>
 __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* wfaces, double r_frac, double shrink,
                                      int max_safe_poly, double r_margin, const fh_pair_rule& rule, fh_problem& ps, fh_face* sfaces, int lane,
                                      unsigned long long* probe = nullptr,  // probe: cycle stamps of a diagnostic build (null otherwise)
                                      const UnknownGrid* ug = nullptr) {    // the unknown voxels of rule mode 2
-  if (!rw.solved || pw.n_seg < 1 || pw.n_seg > FH_MAX_SEG) {  // no whole trajectory: the reference returns from replan
-    if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
-    return;
-  }
-  const int N = pw.n_seg;
-  const double dt = rw.dt, DC = pw.dc;
-  const int size = sample_count(pw, rw);
-  int k;
-  if (!choose_r_index(pw, rw, r_frac, rule, lane, k, ug)) {  // the pair ends with its whole trajectory
-    if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
-    return;
-  }
-  if (probe) probe[0] = __builtin_readcyclecounter();
-  double t = 0;
-  int interval = 0;
-  clock_at(k, DC, dt, N, t, interval);  // the reference's clock at sample k (solverGurobi.cpp:131-135) — its own double, not (k + 1) DC: fh_clock.hpp
-  if (probe) probe[1] = __builtin_readcyclecounter();
   fh_state R;
-  eval_state(rw.coeff[interval], t - interval * dt, k == size - 1, R);
-  if (lane < 3) {  // (selected, not indexed: an array indexed by the lane would live in scratch memory)
-    glue_store<WT>(&ps.x0[lane], lane == 0 ? R.pos[0] : (lane == 1 ? R.pos[1] : R.pos[2]));
-    glue_store<WT>(&ps.x0[3 + lane], lane == 0 ? R.vel[0] : (lane == 1 ? R.vel[1] : R.vel[2]));
-    glue_store<WT>(&ps.x0[6 + lane], lane == 0 ? R.accel[0] : (lane == 1 ? R.accel[1] : R.accel[2]));
+  if (!glue_find_r(pw, rw, r_frac, rule, lane, ug, R, probe)) {  // no whole trajectory, or the pair ends with its whole trajectory
+    if (lane == 0) glue_store<WT>(&ps.n_seg, 0);
+    return;
   }
   const bool keep_r = r_margin >= 0.0;
   const double test_shrink = keep_r ? 0.0 : shrink;  // which polytope holds R: the original one / the shrunk one
@@ -315,8 +402,7 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
     int pf = -1;
     if (f < nf) {
       const fh_face fc = wfaces[fb + f];
-      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      v = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2] - (fc.b - test_shrink * nr);
+      v = glue_face_test(fc, glue_face_norm(fc), R.pos, test_shrink);
       pf = 0;
       for (int p = 1; p < P; p++) pf += (f >= pw.face_off[p]) ? 1 : 0;
     }
@@ -325,59 +411,12 @@ __device__ inline void pair_glue_one(const PW& pw, const RW& rw, const fh_face* 
       if (p < P) worst_p[p] = fmax(worst_p[p], glue_wave_max(pf == p ? v : -INFINITY));
   }
   if (probe) probe[2] = __builtin_readcyclecounter();
-  int start = 0;
-  double best = INFINITY;
-  bool found = false;
-#pragma unroll
-  for (int p = 0; p < FH_MAX_POLY; p++) {
-    if (p < P && !found) {
-      if (worst_p[p] <= slack_ok) { start = p; found = true; }
-      else if (worst_p[p] < best) { best = worst_p[p]; start = p; }
-    }
-  }
+  const int start = glue_pick_start(worst_p, P, slack_ok);
   int cnt = P - start;
   if (cnt > max_safe_poly) cnt = max_safe_poly;
   if (P == 0) cnt = 0;
-  const int src0 = P ? pw.face_off[start] : 0;
-  const int total = P ? pw.face_off[start + cnt] - src0 : 0;
-  const int first_end = P ? pw.face_off[start + 1] - src0 : 0;  // rows of the polytope that holds R
-  if (WT) {
-    // write-through stores are one fabric write per separate piece: lane = one DOUBLE of the output (4 per face row), so that an
-    // instruction writes 512 contiguous bytes (a lane per face row, 8 bytes at a stride of 32, cost 8x the HBM write traffic)
-    double* out = reinterpret_cast<double*>(sfaces + fb);
-    for (int j = lane; j < 4 * total; j += 64) {
-      const int f = j >> 2, c = j & 3;
-      const fh_face fc = wfaces[fb + src0 + f];
-      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      double b = fc.b - shrink * nr;
-      if (keep_r && f < first_end) {
-        const double ar = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2];
-        b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
-      }
-      glue_store<true>(out + j, c == 0 ? fc.a[0] : (c == 1 ? fc.a[1] : (c == 2 ? fc.a[2] : b)));
-    }
-  } else {
-    for (int f = lane; f < total; f += 64) {
-      fh_face fc = wfaces[fb + src0 + f];
-      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      double b = fc.b - shrink * nr;
-      if (keep_r && f < first_end) {
-        const double ar = fc.a[0] * R.pos[0] + fc.a[1] * R.pos[1] + fc.a[2] * R.pos[2];
-        b = fmax(b, fmax(fmin(fc.b, ar + r_margin * nr), ar + 1e-6 * nr));
-      }
-      fc.b = b;
-      sfaces[fb + f] = fc;
-    }
-  }
-  if (probe) probe[3] = __builtin_readcyclecounter();
-  if (lane <= FH_MAX_POLY) {
-    const int p = lane < cnt ? lane : cnt;
-    glue_store<WT>(&ps.face_off[lane], pw.face_off[start + p] - src0);
-  }
-  if (lane == 0) {
-    glue_store<WT>(&ps.n_poly, (int32_t)cnt);
-    glue_store<WT>(&ps.face_begin, (int32_t)fb);
-  }
+  const double x0[9] = {R.pos[0], R.pos[1], R.pos[2], R.vel[0], R.vel[1], R.vel[2], R.accel[0], R.accel[1], R.accel[2]};
+  glue_write_safe<WT>(wfaces, fb, pw.face_off, start, cnt, x0, shrink, r_margin, ps, sfaces, lane, probe);
 }
 
 __global__ void __launch_bounds__(64) pair_glue_kernel(const fh_problem* __restrict__ whole, const fh_result* __restrict__ wres,

@@ -141,6 +141,16 @@ struct ShareArgs {
   int giant_nodes;            // ... but only a problem that has already needed this many nodes publishes ahead of the takers
   int giant_factor;           // ... or this many times the mean number of active-set iterations of the units finished so far (0: off)
   int child_bound;            // 1: a child whose one-row dual bound at the parent already loses against the incumbent is not visited (fh_sched.child_bound)
+  int compact_results;        // 1: only the coefficient rows the kernel is built for are written (fh_sched.compact_results)
+  // the fused pair kernel: the safe problem of a pair lives in the LDS of the wavefront that solves it; its record and rows are written to
+  // memory at the hand-off (pair_outputs: fh_sched.pair_outputs) or when the problem is first shared with another workgroup (otherwise)
+  int pair_outputs;
+  int pad0;
+  const fh_problem* whole;    // [n] the whole problems of the launch
+  const fh_face* wfaces;      // their rows
+  fh_problem* safe;           // [n] the safe problems: the caller's templates + (if written) x0, n_poly, face_off, face_begin
+  fh_face* sfaces;            // their rows, at the whole problem's face_begin
+  double shrink, r_margin;
 };
 
 #define FH_AGENT __HIP_MEMORY_SCOPE_AGENT

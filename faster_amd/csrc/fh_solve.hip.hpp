@@ -34,6 +34,7 @@
 #include "../../include/fasterhip.h"
 #include "fh_basis.hip.hpp"
 #include "fh_share.hip.hpp"
+#include "fh_sample.hip.hpp"  // the hand-off of a pair: ProblemView / ResultView, glue_* (shared with the staged pipeline)
 
 namespace fh {
 
@@ -70,6 +71,13 @@ __device__ __forceinline__ unsigned long long pinned_clock() {
 #define FH_U1(slot)
 #endif
 #define FH_MAX_TRIALS 4096
+// The fused pair kernel stores the whole problem's result AFTER the hand-off has issued its loads (a load waits for every store before it:
+// s_waitcnt vmcnt counts both).  The diagnostic build that stamps times into the result rows as it goes stores at once.
+#ifdef FH_SHARE_PROFILE
+#define FH_DEFER_RESULT false
+#else
+#define FH_DEFER_RESULT true
+#endif
 // Wavefronts per SIMD the solve kernels are compiled for (launch bounds: 512 / this many vector registers per lane, granule 8)
 #ifndef FH_WAVES_PER_SIMD
 #define FH_WAVES_PER_SIMD 3
@@ -306,13 +314,27 @@ __device__ inline double cubic_root_of_lane(double c3, double c2, double c1, dou
 }
 // getDTInitial as the oracle evaluates it, one candidate root per lane (lane = 3 * axis + j; the exact path: closed forms with the
 // double-precision cbrt / acos / cos of the device library, ~1100 vector instructions on nine useful lanes).
+// Where a solve reads x0 from: the record (X0Rec: the stand-alone time allocation), or the wavefront's LDS (X0Lds: the solve kernels keep x0
+// in the slots of the state arrays that belong to the start of segment 0 — the safe problem of a fused pair has no record to read it from).
 template <class PR>
-__device__ __attribute__((noinline)) double dt_initial_exact(const PR& pr, int lane) {  // (out of line: the rare path must not cost the kernels registers)
+struct X0Rec {
+  const PR& pr;
+  __device__ __forceinline__ double pos(int i) const { return i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2]); }
+  __device__ __forceinline__ double vel(int i) const { return i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5]); }
+  __device__ __forceinline__ double acc(int i) const { return i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8]); }
+};
+struct X0Lds {
+  const double* P;  // Pc of the Solver; Vc and Ac follow it at `stride` doubles each (entries 0..2 of the three arrays are x0)
+  int stride;
+  __device__ __forceinline__ double pos(int i) const { return P[i]; }
+  __device__ __forceinline__ double vel(int i) const { return P[stride + i]; }
+  __device__ __forceinline__ double acc(int i) const { return P[2 * stride + i]; }
+};
+// (x0p, x0v, x0a: x0 on the axis of this lane, lane = 3 * axis + j, lanes beyond 8 repeat axis 2)
+template <class PR>
+__device__ __attribute__((noinline)) double dt_initial_exact(const PR& pr, double x0p, double x0v, double x0a, int lane) {  // (out of line: the rare path must not cost the kernels registers)
   const int ax = lane / 3, j = lane - 3 * ax;
   const int i = ax < 3 ? ax : 2;  // (lanes beyond 8 repeat axis 2: harmless duplicates)
-  const double x0p = i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2]);
-  const double x0v = i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5]);
-  const double x0a = i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8]);
   const double xfp = i == 0 ? pr.xf[0] : (i == 1 ? pr.xf[1] : pr.xf[2]);
   const double dx = xfp - x0p;
   const float tv = (float)(fabs(dx) / pr.v_max);                     // :672-674
@@ -374,16 +396,20 @@ __device__ __forceinline__ float acos_start(float x) {  // |error| < 1e-6 on [-1
   const float r = __builtin_amdgcn_sqrtf(1.0f - ax) * pl;
   return x < 0.f ? 3.14159265f - r : r;
 }
-template <class PR>
-__device__ __forceinline__ double dt_initial(const PR& pr, int lane) {
+template <class PR, class X0>
+__device__ __forceinline__ double dt_initial_exact_lanes(const PR& pr, const X0& x0, int lane) {  // the exact path with its own lane -> axis map
+  const int ax = lane / 3;
+  const int i = ax < 3 ? ax : 2;
+  return dt_initial_exact(pr, x0.pos(i), x0.vel(i), x0.acc(i), lane);
+}
+template <class PR, class X0>
+__device__ __forceinline__ double dt_initial(const PR& pr, const X0& x0, int lane) {
 #ifdef FH_DT_EXACT_ONLY
-  return dt_initial_exact(pr, lane);
+  return dt_initial_exact_lanes(pr, x0, lane);
 #else
   const int ax = lane >> 2, j = lane & 3;
   const int i = ax < 3 ? ax : 2;  // (lanes beyond 11 repeat axis 2, lane j = 3 of a quad holds no candidate)
-  const double x0p = i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2]);
-  const double x0v = i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5]);
-  const double x0a = i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8]);
+  const double x0p = x0.pos(i), x0v = x0.vel(i), x0a = x0.acc(i);
   const double xfp = i == 0 ? pr.xf[0] : (i == 1 ? pr.xf[1] : pr.xf[2]);
   const double dx = xfp - x0p;
   const float tv = (float)(fabs(dx) / pr.v_max);                     // :672-674
@@ -411,7 +437,7 @@ __device__ __forceinline__ double dt_initial(const PR& pr, int lane) {
   // a |dx| below 1e-30 that is not zero goes there too and takes the general closed form)
   const bool ill = !(fabs(disc) >= 1e-6 * scale) || (scale > 0.0 && scale < 1e-40) || !(scale < 1e280) || !(qdisc >= 0.0) || (triple && B != 0.0) ||
                    !(fabs(dx) >= 1e-30);
-  if (wave_any(ill && lane < 12)) return dt_initial_exact(pr, opaque(lane));
+  if (wave_any(ill && lane < 12)) return dt_initial_exact_lanes(pr, x0, opaque(lane));
   double rj = 0.0;
   if (disc > 0) {  // one real root (the pair's imaginary part is far above 1e-12 here: j = 1 has no candidate)
     const double sq = __builtin_amdgcn_sqrt(disc);
@@ -461,6 +487,20 @@ __device__ __forceinline__ double dt_initial(const PR& pr, int lane) {
 #endif
 }
 
+// The safe problem of a fused pair as a record and rows in memory (what the staged hand-off writes: glue_write_safe), from what the
+// wavefront that solves it holds: x0 in its LDS slots, the polytope of the whole corridor its corridor starts at, the polytope count.
+// Out of line on purpose (its callers are the hand-off with fh_sched.pair_outputs and the first donation of a safe problem: rare, and
+// they must not cost the solve registers); explicit arguments, no `this`.  Write-through stores; the caller drains them.
+typedef const __attribute__((address_space(3))) double lds_cdouble;
+__device__ __attribute__((noinline)) void write_safe_problem(const fh_problem* whole, const fh_face* wfaces, fh_problem* ps, fh_face* sfaces, lds_cdouble* x0P,
+                                                             int x0_stride, int start, int cnt, double shrink, double r_margin, int lane) {
+  lds_cdouble* x0V = x0P + x0_stride;
+  lds_cdouble* x0A = x0V + x0_stride;
+  const double x0[9] = {x0P[0], x0P[1], x0P[2], x0V[0], x0V[1], x0V[2], x0A[0], x0A[1], x0A[2]};
+  const int fb = __builtin_amdgcn_readfirstlane(whole->face_begin);
+  glue_write_safe<true>(wfaces, fb, whole->face_off, start, cnt, x0, shrink, r_margin, *ps, sfaces, lane, nullptr);
+}
+
 // -----------------------------------------------------------------------------------------------------------------
 // NORMS_TABLE: the per-lane inverse row norms are re-read from the basis table by every scan (the build for three wavefronts per SIMD:
 // eight registers that are not spilled) instead of being kept in registers from setup_trial on (the build for two: nothing spills there,
@@ -496,7 +536,9 @@ struct Solver {
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *stk_keep, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
-         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_WORDS = 26 };
+         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_SAFE = 26, TB_WORDS = 27 };
+                                                                 // TB_SAFE: the safe problem of the fused pair in hand — bits 0..7 the polytope of the whole corridor its corridor starts
+                                                                 // at, bit 8: its record and rows are in memory (written back: always, or when the problem was first shared)
                                                                  // TB_NEXT / TB_NEXT + 1: this workgroup's own pool of tickets [next, end), drawn a chunk at a time (and ahead,
                                                                  // during a hand-off, with the control words TB_NEXT_EI / TB_NEXT_WT read at the same time); TB_DONE_LOCAL lives in tb[TB_ZN + ...]  // TB_WORK: active-set iterations of the unit in hand (reported with `done`);
                                                                  // TB_ZN: the N whose basis is in Zm (0: none yet)
@@ -755,7 +797,7 @@ struct Solver {
   // ---- per trial (step h): states for y = 0 and the inverse row norms.  bt: the basis table of this N (fh_basis.hip.hpp) ----
   // Returns true when the trial is refuted at y = 0 by the jerk box (only if may_end_early): nothing else was set up then.
   template <class PR>
-  __device__ bool setup_trial(const PR& pr, const double* __restrict__ bt, bool may_end_early = false) {
+  __device__ __forceinline__ bool setup_trial(const PR& pr, const double* __restrict__ bt, bool may_end_early = false) {
     // Inlined twice — the trial loop, and the worker that writes the result of a shared problem — and results must not depend on
     // which copy ran: no contraction into fused multiply-adds left to the optimiser's choice per site.
 #pragma clang fp contract(off)
@@ -776,9 +818,10 @@ struct Solver {
     {  // zero-jerk propagation of x0 to the start of segment tt = lane / 3
       const int tt = lane / 3, i = lane - 3 * tt;
       const bool on = lane < 3 * NT;
-      const double p0 = on ? (i == 0 ? pr.x0[0] : (i == 1 ? pr.x0[1] : pr.x0[2])) : 0.0;
-      const double v0 = on ? (i == 0 ? pr.x0[3] : (i == 1 ? pr.x0[4] : pr.x0[5])) : 0.0;
-      a = on ? (i == 0 ? pr.x0[6] : (i == 1 ? pr.x0[7] : pr.x0[8])) : 0.0;
+      // x0 lives in LDS: entries 0..2 of Pc / Vc / Ac (the state at the start of segment 0 IS x0; compute_states leaves them alone)
+      const double p0 = on ? Pc[i] : 0.0;
+      const double v0 = on ? Vc[i] : 0.0;
+      a = on ? Ac[i] : 0.0;
       const double T = (double)tt * h;
       p = p0 + T * (v0 + 0.5 * T * a);
       v = v0 + T * a;
@@ -917,7 +960,9 @@ struct Solver {
     if (lane < (N + 1) * 3) {
       double dp, dv, da;
       moments(dp, dv, da);
-      Pc[lane] = p0r + dp; Vc[lane] = v0r + dv; Ac[lane] = a0r + da;
+      // (lanes 0..2 — the start of segment 0 — would store x0 + 0: the slots hold x0 itself, staged once per problem, and everything
+      // that needs x0 reads it there: setup_trial, dt_initial, the screening, the hand-off of a fused pair)
+      if (lane >= 3) { Pc[lane] = p0r + dp; Vc[lane] = v0r + dv; Ac[lane] = a0r + da; }
     }
     FH_SYNC();
     if (lane < 4 * N) {  // lane = (segment, control point): three axes each, no integer divisions
@@ -1483,7 +1528,7 @@ struct Solver {
       const double h3 = h / 3.0, h23 = 2.0 * h / 3.0, h26 = h * h / 6.0;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        const double p0 = pr.x0[i], v0 = pr.x0[3 + i], a0 = pr.x0[6 + i];
+        const double p0 = Pc[i], v0 = Vc[i], a0 = Ac[i];  // x0 (LDS, see compute_states)
         const double pf = xfl[i], vf = xfl[3 + i], af = xfl[6 + i];
         c0[i] = p0; c0[3 + i] = p0 + v0 * h3; c0[6 + i] = p0 + v0 * h23 + a0 * h26;
         cN[i] = pf; cN[3 + i] = pf - vf * h3; cN[6 + i] = pf - vf * h23 + af * h26;
@@ -1728,7 +1773,7 @@ struct Solver {
   // something MUST be published.  Then the problem's share record: created on its first donation (the incumbent and the
   // bookkeeping move there), one more outstanding part otherwise.  ~0ull: nothing to publish (no taker, or no record left — an
   // empty frame has been published for the taker).
-  __device__ unsigned long long begin_donation(const ShareArgs& sa, double best_cost) {
+  __device__ __forceinline__ unsigned long long begin_donation(const ShareArgs& sa, double best_cost) {
     unsigned long long pos = ~0ull;
     if (lane == 0) pos = q_reserve(sa);
     pos = uniform_u64(pos);
@@ -1765,6 +1810,14 @@ struct Solver {
         ast(&R_->assign_lo, alo); ast(&R_->assign_hi, ahi);
       }
       rec = r;
+      // the safe problem of a fused pair exists only in this wavefront's LDS: whoever takes a frame of it stages it from memory
+      if (!sa.pair_outputs && sa.safe && uniform_i32(tb[TB_PHASE]) == 1 && !(uniform_i32(tb[TB_SAFE]) & 0x100)) {
+        const int unit_ = uniform_i32(tb[TB_B]);
+        FH_SYNC();
+        write_safe_problem(sa.whole + unit_, sa.wfaces, sa.safe + unit_, sa.sfaces, (lds_cdouble*)Pc, 3 * NT, uniform_i32(tb[TB_SAFE]) & 0xff, P, sa.shrink, sa.r_margin, lane);
+        if (lane == 0) tb[TB_SAFE] |= 0x100;
+        FH_SYNC();
+      }
     } else if (lane == 0) {
       aadd(&(sa.recs + rec)->pending, 1);
     }
@@ -2107,13 +2160,222 @@ struct Solver {
     }
   }
 
+
+  // =================================================================================================================
+  // The fused pair kernel: results leave through LDS, the safe problem never leaves the chip
+  // =================================================================================================================
+  // One face row of a problem into LDS as the solve reads it: a / |a| and -(b + feas_tol) / |a| (see `faces`).  ONE copy, used by the
+  // staging of a problem record (run_problem) and by the on-chip hand-off of a fused pair (handoff_onchip): the same roundings.
+  __device__ __forceinline__ void stage_face(fh_face fc, double feas_tol, int f, bool& degenerate_violated) {
+#pragma clang fp contract(off)  // (two inline sites, one result: no contraction left to the optimiser's choice per site)
+    const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
+    if (nr > 0.0) {
+      const double inv = 1.0 / nr;
+      fc.a[0] *= inv; fc.a[1] *= inv; fc.a[2] *= inv;
+      fc.b = -(fc.b + feas_tol) * inv;
+      tolf[f] = (float)(feas_tol * inv);
+    } else {  // 0 <= b: never binding if b >= -tol, else no point satisfies it
+      degenerate_violated = -fc.b > feas_tol;
+      fc.b = -1.0;
+      tolf[f] = 0.0f;
+    }
+    faces[f] = fc;
+  }
+  // x0[j] in LDS (see compute_states).  Pc, Vc, Ac are consecutive arrays of 3 NT doubles (carve): ONE base pointer and an index — a
+  // per-lane choice between three pointers would turn every array of the carve into a 64-bit generic pointer held in vector registers
+  // The per-lane state of a problem (the registers below `per-lane state kept in registers`) is dead between two problems — said
+  // explicitly, at the start of a problem and before the hand-off of a pair: the compiler cannot see it (the members are written by one
+  // iteration of the kernel loop and, as far as it knows, read by the next), carried 24 registers across the ticket, the staging and
+  // the hand-off, and spilled them there (measured: 29 -> 13 spilled registers in the plain N = 10 kernel).
+  __device__ __forceinline__ void forget_lane_state() {
+    p0r = v0r = a0r = xpr = xj = bestx_r = 0.0;
+    cp_r[0] = cp_r[1] = cp_r[2] = 0.0;
+    wbj = wbv = wba = wcp = 0.0;
+    scan_f0 = scan_F = 0;
+  }
+  __device__ __forceinline__ double* x0_slot(int j) const { return Pc + (j < 3 ? j : (j < 6 ? 3 * NT + (j - 3) : 6 * NT + (j - 6))); }
+
+  // ---- the result record, assembled in LDS (where Q was: the solve is over) and stored with ONE 16-byte-per-lane instruction per 1 KiB ----
+  // Layout of the table T = Q: doubles 0..5 the head of fh_result (solved | trials, status | nodes, qp_iters | kflops, factor, dt, cost),
+  // 6 .. 6 + 12 rows the coefficient rows (fh_result.coeff is contiguous behind the head), then the 16 bytes of fh_result.assign.  Chunk c
+  // (16 bytes) goes to byte 16 c of the record, the last chunk to offsetof(assign).  rows: coefficient rows that are written — FH_MAX_SEG
+  // (every word of the record, no memset needed) or, with fh_sched.compact_results, the segment count the kernel is built for (rows
+  // beyond a problem's n_seg carry no information: 576 of 1600 bytes at N = 10).  The hand-off of a fused pair reads the coefficient
+  // table from T + 6 (fin_solved, fin_dt) — not from memory.
+  static constexpr int RES_HEAD = 6;
+  __device__ __forceinline__ void emit_result(bool solved, int trials, int status, int nodes, int iters, double factor, double dt, double cost, int rows) {
+    const int lane = opaque(this->lane);
+    double* T = Q;
+    FH_SYNC();
+    for (int idx = lane; idx < 12 * rows; idx += 64) {
+      const int t = idx / 12, rem = idx - 12 * t, kind = rem / 3, i = rem - 3 * kind;
+      double v = 0.0;
+      if (solved && t < N) {  // polynomial coefficients in the reference variable order (createVars :70-84)
+        const int o = 3 * t + i;
+        v = kind == 0 ? xs[o] / 6.0 : (kind == 1 ? Ac[o] / 2.0 : (kind == 2 ? Vc[o] : Pc[o]));
+      }
+      T[RES_HEAD + idx] = v;
+    }
+    if (lane < FH_MAX_SEG)
+      reinterpret_cast<signed char*>(T + RES_HEAD + 12 * rows)[lane] = (solved && lane < N && P > 0) ? (signed char)bestassign[lane] : (signed char)-1;
+    if (lane == 0) {
+      const unsigned long long kf = flops / 1000ull;
+      const int kfl = kf > 0x7fffffffull ? 0x7fffffff : (int)kf;
+      int* Ti = reinterpret_cast<int*>(T);
+      Ti[0] = solved ? 1 : 0; Ti[1] = trials; Ti[2] = status; Ti[3] = nodes; Ti[4] = iters; Ti[5] = kfl;
+      T[3] = solved ? factor : 0.0;
+      T[4] = dt;
+      T[5] = solved ? cost : 0.0;
+      tb[TB_WORK] += iters;
+    }
+    fin_solved = solved ? 1 : 0;
+    fin_dt = dt;
+    fin_rows = rows;
+    FH_SYNC();
+  }
+  __device__ __forceinline__ void flush_result(fh_result& res) {
+    const int lane = opaque(this->lane);
+    const int rows = fin_rows;
+    const int body = (RES_HEAD + 12 * rows) >> 1;  // 16-byte chunks of head + coefficient rows; one more for assign
+    unsigned char* out = reinterpret_cast<unsigned char*>(&res);
+    const double2* T2 = reinterpret_cast<const double2*>(Q);
+    for (int c = lane; c <= body; c += 64) {
+#ifdef FH_SHARE_PROFILE
+      if (c == (RES_HEAD + (FH_MAX_SEG - 1) * 12 + 8) / 2) continue;  // (diagnostic: the owner's start time, written when the problem was begun)
+#endif
+#ifdef FH_TRACE
+      if (!fin_solved && c >= RES_HEAD / 2 && c < body) continue;  // (diagnostic: the trace of an unsolved problem lives in its coefficient rows)
+#endif
+      const double2 v = T2[c];
+      *reinterpret_cast<double2*>(out + (c < body ? (size_t)16 * c : offsetof(fh_result, assign))) = v;
+    }
+  }
+  int fin_rows;  // coefficient rows in the table emit_result left behind
+
+  // ---- the hand-off of a fused pair without a trip through memory -----------------------------------------------------
+  // What pair_glue_one (fh_sample.hip.hpp) does for the staged pipeline — R from the whole trajectory (Faster::replan, faster.cpp:475), the
+  // run of polytopes of the whole corridor from the one that holds R, shrunk — with the whole problem still staged in this wavefront's LDS
+  // and its result table in T: the rows of the safe corridor are fetched ONCE (the whole problem's rows, L2-resident: this wavefront
+  // staged them), tested against R, shifted, and normalised straight into `faces` — exactly what staging the written record would have
+  // put there (stage_face, glue_face_b: one copy of each formula) —, x0 = R goes into the LDS slots the solve reads x0 from, and the
+  // template's xf into xfl.  Nothing is written to memory: no write-through stores, no drain, no scalar-cache invalidate, no read-back
+  // (round 5: 20 k cycles of hand-off + 14 k of staging per pair, 59 MB written and read per 32768-pair launch).  The record and the rows
+  // of the safe problem exist in memory only if somebody needs them: always with fh_sched.pair_outputs (the tests compare them with the
+  // staged pipeline), otherwise when the safe problem is first shared with another workgroup (begin_donation -> write_safe_problem).
+  // returns 1: the safe problem is staged (faces, face_off, P, maxF, poly_ok, x0, xfl); 2: the pair has no safe problem.
+  template <class PW, class PS>
+  __device__ __forceinline__ int handoff_onchip(const PW& pw, const PS& ps, const fh_face* __restrict__ wfaces, double feas_tol, double r_frac, double shrink,
+                                                int max_safe_poly, double r_margin, const fh_pair_rule& rule, const UnknownGrid* ug,
+                                                unsigned long long* probe) {
+    const int lane = opaque(this->lane);
+    forget_lane_state();
+    ProblemView pv;
+    pv.n_seg = N; pv.n_poly = P; pv.face_begin = pw.face_begin; pv.dc = pw.dc; pv.a_max = pw.a_max;
+    pv.x0[0] = uniform_f64(Pc[0]); pv.x0[1] = uniform_f64(Pc[1]); pv.x0[2] = uniform_f64(Pc[2]);
+    pv.face_off = face_off;
+    ResultView rv;
+    rv.solved = fin_solved; rv.dt = fin_dt;
+    rv.coeff = reinterpret_cast<const double (*)[12]>(Q + RES_HEAD);
+    // the template's goal state: requested now, stored with the rows (lane = word; the record is read-only during the launch)
+    typedef const __attribute__((address_space(4))) double cdouble;
+    const double xfv = (reinterpret_cast<cdouble*>(&ps.xf[0]))[lane < 9 ? lane : 0];
+    fh_state R;
+    // ONE way through: a pair without a safe problem (no whole trajectory, or none is needed) runs on — R is the start of the trajectory
+    // then, what is staged is never used — and says so through LDS at the end: an early return, or a corridor emptied by a flag in a
+    // register, took the N = 10 pair kernel from 39 to 103 spilled registers (the allocation of this kernel is chaotic: DESIGN.md 4d).
+    {
+      const bool found = glue_find_r(pv, rv, r_frac, rule, lane, ug, R, probe);
+      if (lane == 0) tb[TB_SAFE] = found ? 0 : 0x200;
+    }
+    // x0 of the safe problem = R, at once (nothing reads the whole problem's x0 any more): only R's position stays in registers
+    if (lane < 9) {  // (selected, not indexed: an array indexed by the lane would live in scratch memory)
+      const double rv9[9] = {R.pos[0], R.pos[1], R.pos[2], R.vel[0], R.vel[1], R.vel[2], R.accel[0], R.accel[1], R.accel[2]};
+      double v = rv9[0];
+#pragma unroll
+      for (int j = 1; j < 9; j++) v = lane == j ? rv9[j] : v;
+      *x0_slot(lane) = v;
+      xfl[lane] = xfv;
+    }
+    const double Rp[3] = {R.pos[0], R.pos[1], R.pos[2]};
+    const bool keep_r = r_margin >= 0.0;
+    const double test_shrink = keep_r ? 0.0 : shrink;
+    const double slack_ok = keep_r ? 1e-7 : 0.0;
+    const int Pw = P, fb = pv.face_begin;
+    const int nf = Pw ? uniform_i32(face_off[Pw]) : 0;
+    double worst = -INFINITY;  // lane p: how far R is outside polytope p (its worst row)
+    fh_face fc0 = {{0.0, 0.0, 0.0}, 0.0};  // rows 0..63 of the whole corridor stay in registers for the second pass
+    for (int f0 = 0; f0 < nf; f0 += 64) {
+      const int f = f0 + lane;
+      double v = -INFINITY;
+      int pf = -1;
+      if (f < nf) {
+        const fh_face fc = wfaces[fb + f];
+        if (f0 == 0) fc0 = fc;
+        v = glue_face_test(fc, glue_face_norm(fc), Rp, test_shrink);
+        pf = 0;
+        for (int p = 1; p < Pw; p++) pf += (f >= face_off[p]) ? 1 : 0;
+      }
+      for (int p = 0; p < Pw; p++) {
+        const double m = glue_wave_max(pf == p ? v : -INFINITY);
+        worst = lane == p ? fmax(worst, m) : worst;
+      }
+    }
+    if (probe) probe[2] = __builtin_readcyclecounter();
+    // glue_pick_start across the lanes: the first polytope that lets R in (worst <= slack), else the first of the least violated ones
+    int start = first_lane(lane < Pw && worst <= slack_ok);
+    if (start < 0) {
+      const double least = wave_min(lane < Pw ? worst : INFINITY);
+      start = first_lane(lane < Pw && worst == least);
+      if (start < 0) start = 0;  // (no polytope at all, or NaN rows)
+    }
+    int cnt = Pw - start;
+    if (cnt > max_safe_poly) cnt = max_safe_poly;
+    if (Pw == 0) cnt = 0;
+    const int src0 = cnt ? uniform_i32(face_off[start]) : 0;
+    const int total = cnt ? uniform_i32(face_off[start + cnt]) - src0 : 0;
+    // the safe problem's own face offsets: lane p holds entry p (entries beyond cnt repeat the total, as the staged hand-off writes them)
+    const int noff = (cnt && lane <= FH_MAX_POLY) ? face_off[start + (lane < cnt ? lane : cnt)] - src0 : 0;
+    const int first_end = __builtin_amdgcn_readlane(noff, 1);  // rows of the polytope that holds R
+    FH_SYNC();
+    unsigned badpoly = 0u;
+    for (int f0 = 0; f0 < src0 + total; f0 += 64) {  // f: row of the whole corridor, j = f - src0: row of the safe corridor
+      const int f = f0 + lane, j = f - src0;
+      const bool on = j >= 0 && j < total;
+      bool degenerate_violated = false;
+      fh_face fc = fc0;
+      if (f0 > 0 && on) fc = wfaces[fb + f];
+      if (on) {
+        fc.b = glue_face_b(fc, glue_face_norm(fc), Rp, shrink, keep_r, j < first_end, r_margin);
+        stage_face(fc, feas_tol, j, degenerate_violated);
+      }
+      if (wave_any(degenerate_violated)) {
+        int pf = 0;
+        for (int p = 1; p < cnt; p++) pf += (j >= __builtin_amdgcn_readlane(noff, p)) ? 1 : 0;
+        for (int p = 0; p < cnt; p++)
+          if (wave_any(degenerate_violated && pf == p)) badpoly |= 1u << p;
+      }
+    }
+    if (probe) probe[3] = __builtin_readcyclecounter();
+    if (lane <= FH_MAX_POLY) face_off[lane] = noff;
+    {
+      int mf = 0;
+      for (int p = 0; p < cnt; p++) mf = max(mf, __builtin_amdgcn_readlane(noff, p + 1) - __builtin_amdgcn_readlane(noff, p));
+      maxF = mf;
+    }
+    P = cnt;
+    poly_ok = ~badpoly;
+    if (lane == 0) tb[TB_SAFE] |= start;
+    FH_SYNC();
+    return (uniform_i32(tb[TB_SAFE]) & 0x200) ? 2 : 1;
+  }
+
   // ---- MIQP for one dt: depth-first branch and bound.  entry 0: from the root; entry 1: from the frame installed as
   // stack level 0 (install_frame).  returns FH_ST_* (OPTIMAL / INFEASIBLE refer to what THIS worker saw) ----
   // jerk-independent rows of the box: |v0| <= v_max, |a0| <= a_max (setMaxConstraints t = 0, :397-401)
   template <class PR>
   __device__ __forceinline__ bool x0_outside_box(const PR& pr) const {
     bool x0bad = false;
-    for (int i = 0; i < 3; i++) x0bad |= (fabs(pr.x0[3 + i]) - vmax > tol) || (fabs(pr.x0[6 + i]) - amax > tol);
+    for (int i = 0; i < 3; i++) x0bad |= (fabs(uniform_f64(Vc[i])) - vmax > tol) || (fabs(uniform_f64(Ac[i])) - amax > tol);  // x0 (LDS, see compute_states)
     return x0bad;
   }
 
@@ -2407,37 +2669,58 @@ struct Solver {
   }
 };
 
+// What makes a record unusable, in two parts: the scalars (everything a solve reads from the record itself, also of the safe problem of a
+// fused pair, whose corridor and x0 never exist as a record) and the corridor layout.  x0 and xf are tested where they are staged.
 template <class PR>
-__device__ inline bool bad_input(const PR& pr, int nseg_cap, int face_cap) {
-  if (pr.n_seg < 1 || pr.n_seg > nseg_cap || pr.n_poly < 0 || pr.n_poly > FH_MAX_POLY) return true;
+__device__ inline bool bad_scalars(const PR& pr, int nseg_cap, int n_poly) {
+  if (pr.n_seg < 1 || pr.n_seg > nseg_cap || n_poly < 0 || n_poly > FH_MAX_POLY) return true;
+  if (!(pr.f_inc > 0) || !isfinite(pr.f_init) || !isfinite(pr.f_final)) return true;
+  if ((pr.f_final - pr.f_init) / pr.f_inc > (double)FH_MAX_TRIALS) return true;
+  if (!(pr.dc > 0) || !(pr.v_max > 0) || !(pr.a_max > 0) || !(pr.j_max > 0)) return true;
+  const unsigned long long pins = (unsigned long long)pr.pin[0] | ((unsigned long long)pr.pin[1] << 32);
+  for (int t = 0; t < FH_MAX_SEG; t++) {
+    const int v = (int)((pins >> (4 * t)) & 15ull);
+    if (v && (t >= pr.n_seg || v > n_poly)) return true;
+  }
+  return false;
+}
+template <class PR>
+__device__ inline bool bad_corridor(const PR& pr, int face_cap) {
+  if (pr.n_poly < 0 || pr.n_poly > FH_MAX_POLY) return true;
   if (pr.face_off[0] != 0 || pr.face_begin < 0) return true;
   for (int p = 0; p < pr.n_poly; p++) {
     const int c = pr.face_off[p + 1] - pr.face_off[p];
     if (c < 0 || c > FH_MAX_FACES_POLY) return true;
   }
   if (pr.n_poly && pr.face_off[pr.n_poly] > face_cap) return true;
-  if (!(pr.f_inc > 0) || !isfinite(pr.f_init) || !isfinite(pr.f_final)) return true;
-  if ((pr.f_final - pr.f_init) / pr.f_inc > (double)FH_MAX_TRIALS) return true;
-  if (!(pr.dc > 0) || !(pr.v_max > 0) || !(pr.a_max > 0) || !(pr.j_max > 0)) return true;
-  for (int i = 0; i < 9; i++)
-    if (!isfinite(pr.x0[i]) || !isfinite(pr.xf[i])) return true;
-  const unsigned long long pins = (unsigned long long)pr.pin[0] | ((unsigned long long)pr.pin[1] << 32);
-  for (int t = 0; t < FH_MAX_SEG; t++) {
-    const int v = (int)((pins >> (4 * t)) & 15ull);
-    if (v && (t >= pr.n_seg || v > pr.n_poly)) return true;
-  }
   return false;
+}
+
+// coefficient rows of a result record that a kernel built for NSEG segments writes (Solver::emit_result; fh_sched.compact_results)
+template <int NSEG>
+__device__ __forceinline__ int result_rows(const ShareArgs& sa) {
+#if defined(FH_PROFILE) || defined(FH_SHARE_PROFILE) || defined(FH_TRACE)
+  return FH_MAX_SEG;  // (the diagnostic builds keep their numbers in the rows a problem does not use)
+#else
+  return sa.compact_results ? NSEG : FH_MAX_SEG;
+#endif
 }
 
 // One problem (= one genNewTraj call), from the root of its first trial (entry 0) or from a frame of one of its trees taken
 // from the queue (entry 1), until its final result is written (returns true) or until the tree this worker contributed to is
 // still being explored elsewhere (returns false: the worker that finishes the last part continues the problem).
+// staged: 0 the problem is staged from its record (x0, xf, the face rows); 1 the hand-off of a fused pair has staged it in LDS (the safe
+// problem: handoff_onchip) — `pr` is then the caller's TEMPLATE of the safe problem, of which only the scalars are read; 2 the pair has no
+// safe problem (its result says FH_ST_BAD_INPUT, as that of a record the staged hand-off marks with n_seg = 0).
+// defer_store: the result is left in the LDS table (Solver::emit_result) and the caller stores it (Solver::flush_result) — the fused pair
+// kernel runs the hand-off first, so that its loads are not queued behind the result's stores.
 template <int NSEG, class SV, class PR>
 __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face* __restrict__ gfaces, int max_faces,
                             const fh_params& par, const ShareArgs& sa, const double* __restrict__ basis, double* __restrict__ ws, int entry,
-                            bool interrupted, fh_result& res) {
+                            bool interrupted, int staged, bool defer_store, fh_result& res) {
   const int lane = sv.lane;
   sv.fin_solved = 0;
+  const int rows = result_rows<NSEG>(sa);  // coefficient rows of the record that are written (Solver::emit_result)
 #ifdef FH_SHARE_PROFILE
   const unsigned long long sp_tp__ = wall_ticks();
 #endif
@@ -2454,13 +2737,30 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   const unsigned long long gp0__ = sv.glue_parts[0], gp1__ = sv.glue_parts[1], gp2__ = sv.glue_parts[2], gp3__ = sv.glue_parts[3];
   sv.glue_parts[0] = sv.glue_parts[1] = sv.glue_parts[2] = sv.glue_parts[3] = 0;
 #endif
-  if (entry == 0 && (interrupted || bad_input(pr, NSEG, max_faces))) {
-    if (lane == 0) {
-      res.solved = 0; res.trials = 0; res.status = interrupted ? FH_ST_INTERRUPTED : FH_ST_BAD_INPUT; res.nodes = 0; res.qp_iters = 0;
-      res.kflops = 0; res.factor = 0; res.dt = 0; res.cost = 0;
-    }
-    if (lane < FH_MAX_SEG) res.assign[lane] = -1;
-    for (int i = lane; i < FH_MAX_SEG * 12; i += 64) (&res.coeff[0][0])[i] = 0.0;
+  sv.forget_lane_state();
+  FH_SYNC();  // the previous problem of this workgroup is completely done with LDS
+  // x0 and xf: 18 consecutive doubles of the record, one load (lane = word), into the LDS slots the solve reads them from
+  double x0xf = 0.0;
+  if (staged == 0) {
+    typedef const __attribute__((address_space(4))) double cdouble;
+    static_assert(offsetof(fh_problem, xf) == offsetof(fh_problem, x0) + 9 * sizeof(double), "x0 and xf are adjacent");
+    x0xf = (reinterpret_cast<cdouble*>(&pr.x0[0]))[lane < 18 ? lane : 0];
+  }
+  bool bad = interrupted;
+  if (entry == 0 && !bad) bad = bad_scalars(pr, NSEG, staged ? sv.P : (int)pr.n_poly) || (staged == 0 && bad_corridor(pr, max_faces));
+  if (staged == 0) {
+    if (lane < 9) *sv.x0_slot(lane) = x0xf;
+    else if (lane < 18) sv.xfl[lane - 9] = x0xf;
+    FH_SYNC();
+  }
+  if (entry == 0 && !bad) {
+    const double v = lane < 9 ? *sv.x0_slot(lane) : sv.xfl[lane < 18 ? lane - 9 : 0];
+    bad = wave_any(!isfinite(v));
+  }
+  if (entry == 0 && bad) {
+    sv.N = 0; sv.flops = 0ull;
+    sv.emit_result(false, 0, interrupted ? FH_ST_INTERRUPTED : FH_ST_BAD_INPUT, 0, 0, 0.0, 0.0, 0.0, rows);
+    if (!defer_store) sv.flush_result(res);
     return true;
   }
 
@@ -2479,14 +2779,12 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   sv.zc0 = pr.force_final_pos ? 3 : 2;
   sv.K = max(pr.n_seg - sv.zc0, 0);
   sv.n = 3 * sv.K;
-  sv.P = pr.n_poly;
+  if (staged == 0) sv.P = pr.n_poly;
   sv.tol = par.feas_tol;
   sv.dep2 = par.dep_tol * par.dep_tol;
   sv.vmax = pr.v_max; sv.amax = pr.a_max; sv.jmax = pr.j_max;
   sv.box_ub = (double)(3 * pr.n_seg) * pr.j_max * pr.j_max * (1.0 + 1e-9);
   sv.force_final = pr.force_final_pos;
-  FH_SYNC();  // the previous problem of this workgroup is completely done with LDS
-  if (lane < 9) sv.xfl[lane] = pr.xf[lane];
   sv.init_problem();
 #ifdef FH_PROFILE
   sv.prof2[4] = pinned_clock() - tstart__;
@@ -2505,52 +2803,42 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   sv.prof2[5] = pinned_clock() - tstart__ - sv.prof2[4];
 #endif
 
-  // stage the corridor once: coalesced 32-B face rows HBM -> LDS, and |a_f|
-  const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
-  if (lane <= FH_MAX_POLY) sv.face_off[lane] = pr.face_off[lane];
-  {
-    int mf = 0;
-    for (int p = 0; p < pr.n_poly; p++) mf = max(mf, pr.face_off[p + 1] - pr.face_off[p]);
-    sv.maxF = mf;
-  }
-  unsigned badpoly = 0u;
-  for (int f0_ = 0; f0_ < nf; f0_ += 64) {
-    const int f = f0_ + lane;
-    bool degenerate_violated = false;
-    int pf = 0;
-    if (f < nf) {
-      fh_face fc = gfaces[pr.face_begin + f];
-      const double nr = sqrt(fc.a[0] * fc.a[0] + fc.a[1] * fc.a[1] + fc.a[2] * fc.a[2]);
-      if (nr > 0.0) {
-        const double inv = 1.0 / nr;
-        fc.a[0] *= inv; fc.a[1] *= inv; fc.a[2] *= inv;
-        fc.b = -(fc.b + par.feas_tol) * inv;
-        sv.tolf[f] = (float)(par.feas_tol * inv);
-      } else {  // 0 <= b: never binding if b >= -tol, else no point satisfies it
-        degenerate_violated = -fc.b > par.feas_tol;
-        fc.b = -1.0;
-        sv.tolf[f] = 0.0f;
-        for (int p = 0; p < pr.n_poly; p++) pf = (f >= pr.face_off[p]) ? p : pf;
-      }
-      sv.faces[f] = fc;
+  if (staged == 0) {  // stage the corridor once: coalesced 32-B face rows HBM -> LDS, normalised (stage_face)
+    const int nf = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
+    if (lane <= FH_MAX_POLY) sv.face_off[lane] = pr.face_off[lane];
+    {
+      int mf = 0;
+      for (int p = 0; p < pr.n_poly; p++) mf = max(mf, pr.face_off[p + 1] - pr.face_off[p]);
+      sv.maxF = mf;
     }
-    for (int p = 0; p < pr.n_poly; p++)
-      if (wave_any(degenerate_violated && pf == p)) badpoly |= 1u << p;
+    unsigned badpoly = 0u;
+    for (int f0_ = 0; f0_ < nf; f0_ += 64) {
+      const int f = f0_ + lane;
+      bool degenerate_violated = false;
+      if (f < nf) sv.stage_face(gfaces[pr.face_begin + f], par.feas_tol, f, degenerate_violated);
+      if (wave_any(degenerate_violated)) {
+        int pf = 0;
+        for (int p = 0; p < pr.n_poly; p++) pf = (f >= pr.face_off[p]) ? p : pf;
+        for (int p = 0; p < pr.n_poly; p++)
+          if (wave_any(degenerate_violated && pf == p)) badpoly |= 1u << p;
+      }
+    }
+    sv.poly_ok = ~badpoly;
   }
-  sv.poly_ok = ~badpoly;
   FH_SYNC();
 
 #ifdef FH_PROFILE
   sv.prof[0] = pinned_clock() - tstart__;
 #endif
-  const double dt0 = dt_initial(pr, lane);
+  const X0Lds x0l = {sv.Pc, 3 * sv.NT};
+  const double dt0 = dt_initial(pr, x0l, lane);
   const double base = fmax(dt0, 2 * pr.dc);  // findDT :494-497
 #ifdef FH_PROFILE
   sv.prof[14] = pinned_clock() - tstart__ - sv.prof[0]; sv.cnt[14] = 1;
 #ifdef FH_PROFILE_ICACHE  // the same code again, now warm in the instruction cache: how much of the first call was instruction fetch?
   {
     const unsigned long long t2__ = __builtin_readcyclecounter();
-    const double again = dt_initial(pr, opaque(lane));
+    const double again = dt_initial(pr, x0l, opaque(lane));
     if (again != dt0) sv.cnt[22] += 1000;
     sv.prof[22] = __builtin_readcyclecounter() - t2__; sv.cnt[22] += 1;
   }
@@ -2694,7 +2982,7 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   const unsigned long long tres__ = pinned_clock();
   sv.prof2[7] = tres__ - tpost__;
 #endif
-  if (solved) {  // polynomial coefficients in the reference variable order (createVars :70-84)
+  if (solved) {  // the jerks and the states of the optimum: what the coefficient rows are made of (emit_result)
     FH_SYNC();
     if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
     FH_SYNC();
@@ -2703,56 +2991,32 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     if (lane < sv.NXP) sv.xs[lane] = (lane < sv.nx) ? sv.xj : 0.0;  // the jerks xp + Z y
     FH_SYNC();
   }
-  // every word of the result is written by the kernel (no memset of the result buffer is needed)
-  for (int idx = lane; idx < FH_MAX_SEG * 12; idx += 64) {
-    const int t = idx / 12, rem = idx - 12 * t, kind = rem / 3, i = rem - 3 * kind;
-    double v = 0.0;
-    if (solved && t < sv.N) {
-      const int o = 3 * t + i;
-      v = kind == 0 ? sv.xs[o] / 6.0 : (kind == 1 ? sv.Ac[o] / 2.0 : (kind == 2 ? sv.Vc[o] : sv.Pc[o]));
-    }
-#ifdef FH_SHARE_PROFILE
-    if (idx == (FH_MAX_SEG - 1) * 12 + 8) continue;  // (diagnostic: the owner's start time, written when the problem was begun)
-#endif
-#ifdef FH_TRACE
-    if (!solved) continue;
-#endif
-#ifdef FH_NT_RESULTS  // the record is written once and not read again by this launch (the hand-off of a pair reads the LDS copy below):
-    __builtin_nontemporal_store(v, &res.coeff[t][rem]);  // streamed past the L2 instead of evicting the lines the solves come back to
-#else
-    res.coeff[t][rem] = v;
-#endif
-    if (t < NSEG) sv.Q[idx] = v;  // (Q is free now; the hand-off of a pair evaluates R from this table: fin_solved, fin_dt)
-  }
-  sv.fin_solved = solved ? 1 : 0;
-  sv.fin_dt = dt;
+  // every word of the result (of its first `rows` coefficient rows with fh_sched.compact_results) is written by the kernel: no memset of
+  // the result buffer is needed
+  sv.emit_result(solved, trials, status, nodes, iters, factor, dt, cost, rows);
 #ifdef FH_PROFILE
   sv.prof[17] = pinned_clock() - tres__; sv.cnt[17] = 1;
-#ifdef FH_PROFILE_DRAIN  // how long until the result stores of this problem are acknowledged (changes the timing of what follows)
-  {
-    const unsigned long long td__ = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sv.prof[22] = __builtin_readcyclecounter() - td__; sv.cnt[22] = 1;
-  }
-#endif
   sv.prof[12] = pinned_clock() - tstart__;
   if (lane < 12 && sv.N <= FH_MAX_SEG - 4) {  // rows 15 / 14: cycles / calls of slots 0..11, rows 13 / 12: of slots 12..23
     unsigned long long pv = 0, pw = 0;
     unsigned int cv = 0, cw = 0;
     for (int i = 0; i < 12; i++) { pv = (i == lane) ? sv.prof[i] : pv; cv = (i == lane) ? sv.cnt[i] : cv; }
     for (int i = 0; i < 12; i++) { pw = (i == lane) ? sv.prof[12 + i] : pw; cw = (i == lane) ? sv.cnt[12 + i] : cw; }
-    res.coeff[FH_MAX_SEG - 1][lane] = (double)pv;
-    res.coeff[FH_MAX_SEG - 2][lane] = (double)cv;
-    res.coeff[FH_MAX_SEG - 3][lane] = (double)pw;
-    res.coeff[FH_MAX_SEG - 4][lane] = (double)cw;
-    if (lane < 4) res.coeff[FH_MAX_SEG - 5][lane] = (double)(lane == 0 ? gp0__ : (lane == 1 ? gp1__ : (lane == 2 ? gp2__ : gp3__)));
+    double* Tc = sv.Q + sv.RES_HEAD;  // (the coefficient rows of the table: [FH_MAX_SEG][12])
+    Tc[(FH_MAX_SEG - 1) * 12 + lane] = (double)pv;
+    Tc[(FH_MAX_SEG - 2) * 12 + lane] = (double)cv;
+    Tc[(FH_MAX_SEG - 3) * 12 + lane] = (double)pw;
+    Tc[(FH_MAX_SEG - 4) * 12 + lane] = (double)cw;
+    if (lane < 4) Tc[(FH_MAX_SEG - 5) * 12 + lane] = (double)(lane == 0 ? gp0__ : (lane == 1 ? gp1__ : (lane == 2 ? gp2__ : gp3__)));
     if (sv.N <= FH_MAX_SEG - 6) {
       unsigned long long pu = 0;
       for (int i = 0; i < 12; i++) pu = (i == lane) ? sv.prof2[i] : pu;
-      res.coeff[FH_MAX_SEG - 6][lane] = (double)pu;
+      Tc[(FH_MAX_SEG - 6) * 12 + lane] = (double)pu;
     }
   }
+  FH_SYNC();
 #endif
+  if (!defer_store) sv.flush_result(res);
 #ifdef FH_SHARE_PROFILE
   if (lane == 0 && sv.N < FH_MAX_SEG) {  // diagnostic: when (us since this workgroup started) the problem began here / ended, shared?
     const unsigned long long t00 = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
@@ -2761,20 +3025,6 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     res.coeff[FH_MAX_SEG - 1][9] = sv.rec >= 0 ? 1.0 : 0.0;
   }
 #endif
-  if (lane < FH_MAX_SEG) res.assign[lane] = (solved && lane < sv.N && sv.P > 0) ? (int8_t)sv.bestassign[lane] : (int8_t)-1;
-  if (lane == 0) {
-    const unsigned long long kf = sv.flops / 1000ull;
-    res.solved = solved ? 1 : 0;
-    res.trials = trials;
-    res.status = status;
-    res.nodes = nodes;
-    res.qp_iters = iters;
-    sv.tb[sv.TB_WORK] += iters;
-    res.kflops = kf > 0x7fffffffull ? 0x7fffffff : (int32_t)kf;
-    res.factor = solved ? factor : 0.0;
-    res.dt = dt;
-    res.cost = solved ? cost : 0.0;
-  }
   return true;
 }
 
@@ -2938,19 +3188,23 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       sv.pre_parts[0] = tpre1__ - tpre__; sv.pre_parts[1] = tpre2__ - tpre1__; sv.pre_parts[2] = tpre3__ - tpre2__;
     }
 #endif
+    int staged = 0;  // (a pair: 1 the safe problem was staged in LDS by the hand-off, 2 the pair has none; see run_problem)
     for (;;) {  // the problems of the unit (a pair has two)
       bool finished;
       if constexpr (PAIRS) {
-        // The problem record of a pair launch may have been written inside this launch (the safe problem, by this or another
-        // workgroup, write-through): the scalar data cache is invalidated, after which the record is read like the read-only
-        // records of a plain launch — uniform scalar loads through the constant address space (a generic pointer would keep the
-        // address and every field in vector registers: 130 spilled VGPRs).  A record does not change while it is being solved.
-        __builtin_amdgcn_s_dcache_inv();
+        // The problem record of a pair launch may have been written inside this launch (the safe problem of a pair that is shared between
+        // workgroups: write_safe_problem, write-through) — only a workgroup that TAKES a frame of it reads what was written: it invalidates
+        // the scalar data cache, after which the record is read like the read-only records of a plain launch — uniform scalar loads through
+        // the constant address space (a generic pointer would keep the address and every field in vector registers: 130 spilled VGPRs).
+        // A record does not change while it is being solved.
+        if (entry && phase) __builtin_amdgcn_s_dcache_inv();
         typedef const __attribute__((address_space(4))) fh_problem const_problem;
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(phase ? &ka.safe[unit] : &problems[unit]));
         const fh_face* fcs = reinterpret_cast<const fh_face*>(sv.uniform_u64((unsigned long long)(phase ? ka.sfaces : faces)));
         fh_result* out = reinterpret_cast<fh_result*>(sv.uniform_u64((unsigned long long)(phase ? &ka.sres[unit] : &results[unit])));
-        finished = run_problem<NSEG, SolverT, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted, *out);
+        // (the whole problem's result stays in LDS until the hand-off has issued its loads: FH_DEFER_RESULT)
+        finished = run_problem<NSEG, SolverT, const_problem>(sv, *(const_problem*)pr_addr, fcs, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
+                                                             entry ? 0 : staged, FH_DEFER_RESULT && phase == 0, *out);
       }
       else {
         // Nothing writes the problem records during a plain solve launch: reading them through the constant address space keeps
@@ -2959,14 +3213,14 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
         typedef const __attribute__((address_space(4))) fh_problem const_problem;
         const unsigned long long pr_addr = sv.uniform_u64((unsigned long long)(problems + unit));  // (provably wave-uniform)
         finished = run_problem<NSEG, SolverT, const_problem>(sv, *(const_problem*)pr_addr, faces, ka.max_faces, ka.par, sa, ka.basis, ws, entry, interrupted,
-                                                    results[unit]);
+                                                    0, false, results[unit]);
       }
       if (!finished) break;  // the unit continues in another workgroup
       if constexpr (PAIRS) {
         if (phase == 0) {
-          // The hand-off reads what this wavefront still holds — sizes and face offsets in registers / LDS, the coefficient table left
-          // in Q's LDS by run_problem, the scalars of the problem record through the scalar cache — not the result record it has just
-          // written (a drain of the stores and a read-back: two dependent memory round trips per pair).
+          // The hand-off reads what this wavefront still holds — the whole problem staged in LDS, the result table emit_result left where Q
+          // was, the scalars of the problem record through the scalar cache — and leaves the safe problem staged in the same LDS
+          // (Solver::handoff_onchip): nothing of it goes through memory.
 #ifdef FH_PROFILE
           const unsigned long long tglue__ = pinned_clock();
 #endif
@@ -2978,7 +3232,7 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
           const bool draw_ahead = tickets_left && uniform_i32(sv.tb[sv.TB_NEXT]) >= pool_end_now;
 #endif
           const int ahead_ch = sv.ticket_chunk(ka.n, (int)gridDim.x, pool_end_now);
-          if (draw_ahead && threadIdx.x == 0) {  // issued here, stored after the hand-off's own drain below
+          if (draw_ahead && threadIdx.x == 0) {  // issued here, stored after the hand-off
             ahead_b = aadd(&sa.ctl->ticket, (unsigned long long)ahead_ch);
             ahead_ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
             ahead_wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
@@ -2986,52 +3240,61 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
           {
             typedef const __attribute__((address_space(4))) fh_problem const_problem;
             const const_problem& pw = *(const_problem*)sv.uniform_u64((unsigned long long)&problems[unit]);
-            ProblemView pv;
-            pv.n_seg = sv.N; pv.n_poly = sv.P; pv.face_begin = pw.face_begin; pv.dc = pw.dc; pv.a_max = pw.a_max;
-            pv.x0[0] = pw.x0[0]; pv.x0[1] = pw.x0[1]; pv.x0[2] = pw.x0[2];
-            pv.face_off = sv.face_off;
-            ResultView rv;
-            rv.solved = sv.fin_solved; rv.dt = sv.fin_dt;
-            rv.coeff = reinterpret_cast<const double (*)[12]>(sv.Q);
-            FH_SYNC();
+            const const_problem& ps = *(const_problem*)sv.uniform_u64((unsigned long long)&ka.safe[unit]);
 #ifdef FH_PROFILE
             unsigned long long probe[4] = {0ull, 0ull, 0ull, 0ull};
-            pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
-                                opaque((int)threadIdx.x), probe, UNK ? &ka.unknown : nullptr);
+            staged = sv.handoff_onchip(pw, ps, faces, ka.par.feas_tol, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, UNK ? &ka.unknown : nullptr, probe);
             if (probe[0]) {
               sv.glue_parts[0] = probe[0] - tglue__; sv.glue_parts[1] = probe[1] - probe[0]; sv.glue_parts[2] = probe[2] - probe[1];
               sv.glue_parts[3] = probe[3] - probe[2];
             }
 #else
-            pair_glue_one<true>(pv, rv, faces, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, ka.safe[unit], ka.sfaces,
-                                opaque((int)threadIdx.x), nullptr, UNK ? &ka.unknown : nullptr);
+            staged = sv.handoff_onchip(pw, ps, faces, ka.par.feas_tol, ka.r_frac, ka.shrink, ka.max_safe_poly, ka.r_margin, ka.rule, UNK ? &ka.unknown : nullptr, nullptr);
 #endif
+            staged = uniform_i32(staged);
           }
-          // the safe problem went out write-through and is drained: this wavefront reads its own stores back (a CU's L1 follows
-          // that CU's stores; no agent-scope acquire here — it made every pair drop the CU's L1 and, measured, 0.5 GB of dirty
-          // snapshot lines per launch leave L2); a workgroup that takes a frame of it later acquires in take_task
 #ifdef FH_PROFILE
           const unsigned long long tdrain__ = __builtin_readcyclecounter();
 #endif
-          drain_stores();
+          if (draw_ahead) {
+            drain_stores();  // the ticket has arrived (with the hand-off's rows as a rule: issued before them, the counter is in order)
+            if (threadIdx.x == 0) {
+              const unsigned long long nn = (unsigned long long)ka.n;
+              if (ahead_b < nn) {
+                sv.tb[sv.TB_NEXT] = (int)ahead_b;
+                sv.tb[sv.TB_NEXT + 1] = (int)min(ahead_b + (unsigned long long)ahead_ch, nn);
+              } else {  // beyond the batch: an empty pool at the end of the batch (the next draw finds the same and ends the tickets)
+                sv.tb[sv.TB_NEXT] = ka.n;
+                sv.tb[sv.TB_NEXT + 1] = ka.n;
+              }
+              sv.tb_put64(sv.TB_NEXT_EI, ahead_ei);
+              sv.tb_put64(sv.TB_NEXT_WT, ahead_wt);
+            }
+          }
 #ifdef FH_PROFILE
           sv.drain_cycles = __builtin_readcyclecounter() - tdrain__;
 #endif
-          if (draw_ahead && threadIdx.x == 0) {
-            const unsigned long long nn = (unsigned long long)ka.n;
-            if (ahead_b < nn) {
-              sv.tb[sv.TB_NEXT] = (int)ahead_b;
-              sv.tb[sv.TB_NEXT + 1] = (int)min(ahead_b + (unsigned long long)ahead_ch, nn);
-            } else {  // beyond the batch: an empty pool at the end of the batch (the next draw finds the same and ends the tickets)
-              sv.tb[sv.TB_NEXT] = ka.n;
-              sv.tb[sv.TB_NEXT + 1] = ka.n;
+          // the whole problem's result: its stores come after every load of the hand-off, and nothing waits for them
+          if (FH_DEFER_RESULT) sv.flush_result(results[unit]);
+          if (sa.pair_outputs) {  // the safe problem as a record and rows in memory, as the staged hand-off leaves them (the tests compare)
+            if (staged == 1) {
+              write_safe_problem(&problems[unit], faces, &ka.safe[unit], ka.sfaces, (lds_cdouble*)sv.Pc, 3 * sv.NT, uniform_i32(sv.tb[sv.TB_SAFE]) & 0xff, sv.P, ka.shrink,
+                                 ka.r_margin, opaque((int)threadIdx.x));
+              if (threadIdx.x == 0) sv.tb[sv.TB_SAFE] |= 0x100;
+            } else if (threadIdx.x == 0) {
+              __hip_atomic_store(&ka.safe[unit].n_seg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            sv.tb_put64(sv.TB_NEXT_EI, ahead_ei);
-            sv.tb_put64(sv.TB_NEXT_WT, ahead_wt);
           }
 #ifdef FH_PROFILE
           sv.glue_cycles = pinned_clock() - tglue__;
 #endif
+          if (staged == 2) {  // the pair has no safe problem: its safe result says FH_ST_BAD_INPUT, as that of a record the staged hand-off marks with n_seg = 0
+            sv.N = 0; sv.flops = 0ull;
+            sv.emit_result(false, 0, FH_ST_BAD_INPUT, 0, 0, 0.0, 0.0, 0.0, result_rows<NSEG>(sa));
+            sv.flush_result(ka.sres[unit]);
+            sv.unit_done(sa);
+            break;
+          }
           phase = 1;
           entry = 0;
           if (threadIdx.x == 0) sv.tb[sv.TB_PHASE] = 1;

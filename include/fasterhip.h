@@ -192,6 +192,19 @@ typedef struct fh_sched {
                                  the trees are half as large).  1: every child is visited, the tree of the CPU oracle.
                                  (Round 4 called this field child_bound with 1 = default; inverted so that a caller who fills a
                                  zero-initialised struct by hand keeps the default behaviour.)                                        */
+  int32_t compact_results;    /* 1: a solve writes only the coefficient rows its kernel is built for (the smallest of 6, 10, 15, 16 segments that
+                                 holds max_seg): rows fh_result.coeff[t] with t >= that count — they carry no information, a problem has
+                                 n_seg <= max_seg segments — are left as the caller's buffer had them.  0 (default): every word of every
+                                 fh_result is written (no memset needed).  At N = 10 a record is 1600 bytes of which 1024 are written
+                                 with 1: what a caller that streams batches wants (bench.py sets it).                                     */
+  int32_t pair_outputs;       /* fh_solve_pairs_device / fh_pool_solve_pairs: 1: d_safe and d_safe_faces are OUTPUTS, complete for every
+                                 pair, exactly as fh_pair_glue_device leaves them (x0 = R, n_poly, face_off, face_begin, the rows; n_seg = 0
+                                 marks a pair without a safe problem).  0 (default): they are scratch — the safe problem of a pair is built
+                                 in the LDS of the wavefront that solves it and is written to these buffers only when it is handed to
+                                 another workgroup (a tree that several wavefronts explore; a few dozen of 32768 pairs): what is in them
+                                 after the launch is unspecified, the TEMPLATE fields of d_safe (n_seg, bounds, dc, factor window,
+                                 force_final_pos, xf) are never written, and the results are the same bit for bit.  The safe problem's x0
+                                 is the whole trajectory at sample k_safe (fh_sample_batch / fh_append_plans_device give it).              */
   int32_t struct_size;        /* sizeof(fh_sched) as the CALLER was compiled (fh_default_sched sets it), or 0 = not stated.  fh_set_sched
                                  refuses any other value: the struct has changed between rounds (round 4's child_bound became
                                  no_child_bound with the opposite meaning at the same offset), and a binary built against an older
@@ -199,7 +212,7 @@ typedef struct fh_sched {
 } fh_sched;
 /* The layout generation of the structs in this header: bumped whenever a field changes its meaning, offset or size.  A caller compares
  * FH_ABI_VERSION (its compile time) with fh_abi_version() (the loaded library) once; SolverHip does. */
-#define FH_ABI_VERSION 6
+#define FH_ABI_VERSION 7
 int fh_abi_version(void);
 void fh_default_sched(fh_sched* s);
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s);

@@ -200,3 +200,73 @@ def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ct
         assert s is not None and s[0] == pytest.approx(r["cost"], rel=1e-6, abs=1e-7), (kind, s and s[0], r["cost"])
     print("%d problems, %d pinned QPs on the GPU" % (len(cases), total_qps))
     assert total_qps > 1_500_000
+
+
+def test_lazy_pair_outputs_and_compact_results_give_the_same_bits():
+    """fh_sched.pair_outputs = 0 (the library's default: the safe problem of a pair never leaves the chip unless it is shared between
+    workgroups) and fh_sched.compact_results = 1 (only the coefficient rows the kernel is built for are written) against the complete
+    outputs: every result field of every whole and safe problem bit for bit, the rows that are not written untouched, the caller's
+    templates not written in their template fields — and with complete outputs the written safe problems equal the staged hand-off's
+    (fh_pair_glue_device) record for record and row for row.  8192 C4 pairs (the bench batch's generator), sharing on: some safe
+    problems ARE handed to other workgroups and staged from what write_safe_problem wrote."""
+    import torch
+
+    from tests.test_gpu_round3 import _dev
+
+    B, N = 8192, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    tmpl = corridor.safe_templates(whole)
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    RS = abi.result_dtype.itemsize
+
+    def run(pair_outputs, compact, fill):
+        c = capi.Context(0, pair_outputs=pair_outputs, compact_results=compact)
+        c.set_pair_margin(0.05)
+        d_whole, d_faces, d_safe = _dev(whole), _dev(faces), _dev(tmpl)
+        d_sf = torch.zeros_like(d_faces)
+        d_wr = torch.full((B * RS,), fill, dtype=torch.uint8, device="cuda:0")
+        d_sr = torch.full((B * RS,), fill, dtype=torch.uint8, device="cuda:0")
+        c.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.2, 3, d_wr.data_ptr(), d_safe.data_ptr(), d_sf.data_ptr(), d_sr.data_ptr())
+        c.sync()
+        st = c.share_stats()
+        out = (d_wr.cpu().numpy().view(abi.result_dtype), d_sr.cpu().numpy().view(abi.result_dtype), d_safe.cpu().numpy().view(abi.problem_dtype),
+               d_sf.cpu().numpy().view(abi.face_dtype), st)
+        c.close()
+        return out
+
+    w1, s1, safe1, sf1, st1 = run(True, False, 0xAB)
+    w0, s0, safe0, sf0, st0 = run(False, True, 0xCD)
+    fields = [f for f in abi.result_dtype.names if f not in ("nodes", "qp_iters", "kflops", "coeff")]
+    for a, b, name in ((w1, w0, "whole"), (s1, s0, "safe")):
+        for f in fields:
+            assert np.array_equal(a[f], b[f]), (name, f)
+        assert np.array_equal(a["coeff"][:, :N], b["coeff"][:, :N]), name
+        # complete outputs: every word written (rows beyond the problem's segments are zero); compact: rows >= 10 keep the caller's bytes
+        assert not a["coeff"][:, N:].any()
+        assert (b["coeff"][:, N:].view(np.uint8) == 0xCD).all(), name
+    assert w1["solved"].mean() > 0.99 and 0.5 < s1["solved"].mean() < 1.0
+    # the template fields of the safe records are never written in either mode (n_seg = 0 marks a pair without a safe problem in the complete outputs only)
+    live = w1["solved"] == 1
+    for f in ("force_final_pos", "dc", "v_max", "a_max", "j_max", "f_init", "f_final", "f_inc", "xf", "pin"):
+        assert np.array_equal(safe0[f], tmpl[f]) and np.array_equal(safe1[f], tmpl[f]), f
+    assert np.array_equal(safe0["n_seg"], tmpl["n_seg"]) and np.array_equal(safe1["n_seg"][live], tmpl["n_seg"][live])
+    # complete outputs = the staged hand-off's, record for record and row for row
+    c = capi.Context(0)
+    c.set_pair_margin(0.05)
+    d_whole, d_faces, d_safe, d_wr = _dev(whole), _dev(faces), _dev(tmpl), _dev(w1)
+    d_sf = torch.zeros_like(d_faces)
+    c.pair_glue_device(d_whole.data_ptr(), d_wr.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, d_safe.data_ptr(), d_sf.data_ptr())
+    c.sync()
+    safe_ref, sf_ref = d_safe.cpu().numpy().view(abi.problem_dtype), d_sf.cpu().numpy().view(abi.face_dtype)
+    c.close()
+    for f in abi.problem_dtype.names:
+        assert np.array_equal(safe1[f], safe_ref[f]), f
+    for i in np.flatnonzero(live):
+        f0 = int(safe_ref["face_begin"][i]); n = int(safe_ref["face_off"][i][safe_ref["n_poly"][i]])
+        assert np.array_equal(sf1["a"][f0:f0 + n], sf_ref["a"][f0:f0 + n]) and np.array_equal(sf1["b"][f0:f0 + n], sf_ref["b"][f0:f0 + n]), i
+    # lazy outputs: what WAS written (pairs whose safe problem was shared) is the same record; everything else is the template
+    written = np.flatnonzero((safe0["x0"] != tmpl["x0"]).any(axis=1))
+    for i in written:
+        for f in abi.problem_dtype.names:
+            assert np.array_equal(safe0[f][i], safe_ref[f][i]), (i, f)
+    print("lazy outputs: %d of %d safe records written (shared safe problems); donations %d / %d" % (len(written), B, st0["donated"], st1["donated"]))
