@@ -98,6 +98,7 @@ __global__ void share_init_kernel(fh::ShareCtl* ctl, unsigned long long* seqs) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (unsigned)FH_QCAP) seqs[i] = (unsigned long long)i;
   if (i < sizeof(fh::ShareCtl) / 4) reinterpret_cast<unsigned int*>(ctl)[i] = 0u;
+  if (i < (unsigned)FH_MAX_GRID) reinterpret_cast<unsigned int*>(seqs + FH_QCAP)[i] = 0u;  // claims[] (ShareArgs)
 }
 
 #ifndef FH_ORDER_WINDOW
@@ -142,7 +143,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * SV::SNAP_PADDED)) != FH_OK) return rc;
   const size_t slot_stride = sizeof(fh::TaskHdr) + sizeof(double) * (size_t)SV::SNAP_PADDED;
   if (!ctx->d_buf[6]) ctx->ctl_ready = false;
-  if ((rc = ensure(ctx, 6, 4096 + sizeof(unsigned long long) * FH_QCAP)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 6, 4096 + sizeof(unsigned long long) * FH_QCAP + sizeof(unsigned int) * FH_MAX_GRID)) != FH_OK) return rc;
   if ((rc = ensure(ctx, 8, slot_stride * FH_QCAP)) != FH_OK) return rc;
   if ((rc = ensure(ctx, 9, sizeof(fh::ShareRec) * FH_NRECS)) != FH_OK) return rc;
   fh::ShareArgs& sa = ka.sa;
@@ -173,6 +174,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   sa.compact_results = ctx->sched.compact_results ? 1 : 0;
   sa.pair_outputs = ctx->sched.pair_outputs ? 1 : 0;
   sa.pad0 = 0;
+  sa.claims = grid <= FH_MAX_GRID ? reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(ctx->d_buf[6]) + 4096 + sizeof(unsigned long long) * FH_QCAP) : nullptr;
   sa.whole = PAIRS ? d_problems : nullptr;
   sa.wfaces = d_faces;
   sa.safe = PAIRS ? ka.safe : nullptr;
@@ -199,7 +201,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
       }
   }
   if (!ctx->ctl_ready) {
-    hipLaunchKernelGGL(share_init_kernel, dim3((FH_QCAP + 255) / 256), dim3(256), 0, ctx->stream, sa.ctl, sa.seqs);
+    hipLaunchKernelGGL(share_init_kernel, dim3((std::max(FH_QCAP, FH_MAX_GRID) + 255) / 256), dim3(256), 0, ctx->stream, sa.ctl, sa.seqs);
     FH_HIP(hipGetLastError());
   }
   ctx->ctl_ready = false;  // (true again once the launch below has been issued: it resets the block when it ends)

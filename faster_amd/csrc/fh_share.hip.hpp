@@ -38,6 +38,7 @@ namespace fh {
 
 #define FH_QCAP 1024          // task slots in the ring (power of two)
 #define FH_NRECS 4096         // share records per launch (problems that gave work away)
+#define FH_MAX_GRID 4096      // workgroups of a launch whose first tickets can be dealt (claims[])
 #define FH_SPIN_LIMIT (1u << 22)
 #define FH_WATCHDOG_TICKS (20ull * 100000000ull)  // 20 s of the 100 MHz s_memrealtime clock: a hungry worker gives up
 
@@ -54,7 +55,8 @@ struct ShareCtl {
   unsigned int donated, stolen, q_full, rec_full, lock_spins, max_fill;  // statistics
   unsigned int exited;        // workgroups that have left the kernel: the last one re-initialises this block for the next launch
   unsigned int started;       // workgroups that have begun: publishing ahead is for a launch that has the device to itself (all begun)
-  unsigned int pad1[5];
+  unsigned int steal_tries;   // workgroups that ran out of tickets and looked for an unclaimed dealt chunk (ShareArgs::claims, steal_chunk)
+  unsigned int pad1[4];
   // ---- line 2: the hand-off counters (zeroed before every launch; written only when a worker runs out of problems or a frame
   // is published, read by the busy workers every few nodes) ----
   unsigned int wait_ticket;  // wait tickets drawn: takers committed to frame numbers 0 .. wait_ticket-1   } one aligned 8-byte
@@ -146,6 +148,8 @@ struct ShareArgs {
   // memory at the hand-off (pair_outputs: fh_sched.pair_outputs) or when the problem is first shared with another workgroup (otherwise)
   int pair_outputs;
   int pad0;
+  unsigned int* claims;       // [FH_MAX_GRID] claims[w] != 0: the chunk of tickets dealt to workgroup w has been taken — by w itself when it
+                              // started, or by a workgroup that ran out of tickets before w had started (null: nothing is dealt)
   const fh_problem* whole;    // [n] the whole problems of the launch
   const fh_face* wfaces;      // their rows
   fh_problem* safe;           // [n] the safe problems: the caller's templates + (if written) x0, n_poly, face_off, face_begin

@@ -47,6 +47,8 @@ namespace fh {
 // multi-wave kernel would need a barrier for only needs the compiler not to reorder the accesses.
 #ifdef FH_SYNC_BARRIER
 #define FH_SYNC() __syncthreads()
+#elif defined(FH_SYNC_ASM)
+#define FH_SYNC() asm volatile("" ::: "memory")
 #else
 #define FH_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 #endif
@@ -1935,6 +1937,26 @@ struct Solver {
 
   // How many tickets the next draw takes: FH_TICKET_CHUNK while every workgroup of the launch still has that many units ahead of it,
   // then 2, then 1 (the units a workgroup holds but has not started cannot be given away: the tail of a launch stays one unit deep)
+  // the tickets that are dealt to the workgroups at the start of a launch instead of being drawn: c0 each (as many as a chunk, fewer when the
+  // batch is small), static_tickets in total; the ticket counter of the launch counts the tickets behind them
+  static __device__ __forceinline__ int static_chunk(int n, int grid) { return n >= grid ? min(FH_TICKET_CHUNK, n / max(grid, 1)) : 1; }
+  static __device__ __forceinline__ int static_tickets(int n, int grid) { return min(n, static_chunk(n, grid) * grid); }
+  // A dealt chunk that nobody has claimed (its workgroup has not started yet): -1 if the one this call may look at is taken.  Called by a
+  // workgroup for which the ticket counter has run dry.  The k-th such call of a launch (ctl->steal_tries) looks at chunk grid - 1 - k —
+  // the workgroups that start last first — and at no other: every workgroup runs dry at least once, so every chunk is looked at once
+  // unless its workgroup has claimed it before; no loop, no shared scan, three memory round trips at the end of a workgroup's life.
+  static __device__ __forceinline__ int steal_chunk(ShareCtl* ctl, unsigned int* claims, int grid, int lane) {
+    int got = -1;
+    if (lane == 0) {
+      const unsigned int k = aadd(&ctl->steal_tries, 1u);
+      if (k < (unsigned int)grid) {
+        const int idx = grid - 1 - (int)k;
+        unsigned int expect = 0u;
+        if (__hip_atomic_compare_exchange_strong(&claims[idx], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) got = idx;
+      }
+    }
+    return uniform_i32(got);
+  }
   static __device__ __forceinline__ int ticket_chunk(int n, int grid, int last_ticket) {
     const long long left = (long long)n - (long long)last_ticket;
     if (FH_TICKET_CHUNK >= 4 && left >= 4ll * FH_TICKET_CHUNK * (long long)grid / 4) return FH_TICKET_CHUNK;
@@ -3066,7 +3088,10 @@ template <int NSEG, bool PAIRS, int WPS = FH_WAVES_PER_SIMD, bool UNK = false>
 __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
                                                    fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Solver<NSEG, (WPS > 2)> SolverT;  // (three wavefronts per SIMD: the row norms from the table, see Solver)
+#ifndef FH_NORMS_FROM_TABLE
+#define FH_NORMS_FROM_TABLE (WPS > 2)
+#endif
+  typedef Solver<NSEG, FH_NORMS_FROM_TABLE> SolverT;  // (three wavefronts per SIMD: the row norms from the table, see Solver)
   SolverT sv;
   sv.carve(smem, ka.max_faces);
   sv.lane = threadIdx.x;
@@ -3092,6 +3117,7 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
   for (;;) {
     int entry = 0, unit = 0, phase = 0;
     bool interrupted = false;
+    sv.forget_lane_state();  // (nothing of the unit before is carried through the ticket phase)
 #ifdef FH_PROFILE
     const unsigned long long tpre__ = pinned_clock();
 #endif
@@ -3113,6 +3139,9 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       const unsigned long long ttake__ = pinned_clock();
 #endif
       entry = sv.take_task(sa, ws, !tickets_left);
+      // (the control words are a chunk of tickets old: ONE attempt per reading — the units that follow in the chunk do not ask again
+      // for a frame that was pending back then; 98 % of such attempts found it gone and cost a memory round trip each)
+      if (tickets_left && threadIdx.x == 0) sv.tb_put64(sv.TB_NEXT_WT, 0ull);
 #ifdef FH_PROFILE
       if (tickets_left) { sv.take_cycles += pinned_clock() - ttake__; sv.take_calls += 1; }
 #endif
@@ -3130,9 +3159,34 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       unsigned int intr = 0;
       if (pool_next >= pool_end) {  // the pool is empty: draw a chunk now
         unsigned long long b0 = 0ull, ei = 0ull, wt = 0ull;
-        const int ch = sv.ticket_chunk(ka.n, (int)gridDim.x, pool_end);
+        // The FIRST chunk of every workgroup is dealt, not drawn: workgroup w starts with the tickets [w c0, (w + 1) c0) and the counter
+        // hands out what follows them (static_tickets).  All workgroups of a launch that has the device to itself start together, and
+        // their first draws were 2816 read-modify-writes of ONE word: the phase profile showed a first unit waiting 200 k cycles (85 us)
+        // for its ticket where every later one waits 600 — 8 % of the units of a C4 launch, 18 % of the time of one launch alone.
+        // A dealt chunk is CLAIMED (claims[w]: one compare-and-swap on a word of its own) by its workgroup when it starts — or, once
+        // the counter has run dry, by any workgroup that finds it unclaimed (steal_chunk): with other launches in flight the
+        // workgroups of a launch start one by one as wavefront slots become free, and tickets dealt to a workgroup that is not
+        // resident yet must not wait for it (measured without the claim: 12 launches in flight 417 ms per step instead of 1.4).
+        const bool deal = sa.claims != nullptr;
+        const int c0 = sv.static_chunk(ka.n, (int)gridDim.x), dealt_total = deal ? sv.static_tickets(ka.n, (int)gridDim.x) : 0;
+        int claimed = -1;
+        if (deal && pool_end == 0) {  // (a pool that was ever filled ends at a positive ticket: this is the workgroup's first draw)
+          unsigned int expect = 0u;
+          if (threadIdx.x == 0 && __hip_atomic_compare_exchange_strong(&sa.claims[blockIdx.x], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT))
+            claimed = (int)blockIdx.x;
+          claimed = uniform_i32(claimed);
+        }
+        int ch = sv.ticket_chunk(ka.n, (int)gridDim.x, pool_end);
+        if (claimed < 0) {
+          if (threadIdx.x == 0) b0 = aadd(&sa.ctl->ticket, (unsigned long long)ch) + (unsigned long long)dealt_total;
+          b0 = sv.uniform_u64(b0);
+          if (deal && b0 >= (unsigned long long)ka.n) claimed = SolverT::steal_chunk(sa.ctl, sa.claims, (int)gridDim.x, (int)threadIdx.x);  // the counter is dry: a chunk whose workgroup has not started?
+        }
+        if (claimed >= 0) {
+          b0 = (unsigned long long)min(claimed * c0, dealt_total);
+          ch = min((claimed + 1) * c0, dealt_total) - (int)b0;
+        }
         if (threadIdx.x == 0) {
-          b0 = aadd(&sa.ctl->ticket, (unsigned long long)ch);
           ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
           wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
           sv.tb_put64(sv.TB_NEXT_EI, ei);
@@ -3149,14 +3203,13 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
         sv.tb[sv.TB_NEXT + 1] = pool_end;
         const unsigned long long ei = ((unsigned long long)(unsigned)sv.tb[sv.TB_NEXT_EI + 1] << 32) | (unsigned)sv.tb[sv.TB_NEXT_EI];
         intr = (unsigned int)ei | (unsigned int)(ei >> 32);
-        if (!intr && pool_next < pool_end) {  // the host's stop word costs a PCIe read: one workgroup in 32 polls it, with every draw
+        if (!intr && pool_next < pool_end && (fresh_words || (b & (FH_TICKET_CHUNK - 1)) == 0u)) {  // the host's stop word costs a PCIe read: one workgroup in 32 polls it, once per chunk of tickets
           const unsigned long long t_start = ((unsigned long long)(unsigned)sv.tb[sv.TB_T0 + 1] << 32) | (unsigned)sv.tb[sv.TB_T0];
           if (sa.deadline_ticks && wall_ticks() - t_start > sa.deadline_ticks) intr = 2u;
           else if (sa.host_abort && (blockIdx.x & 31u) == 0u && __hip_atomic_load(sa.host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) intr = 1u;
           if (intr) ast(&sa.ctl->interrupted, intr);
         }
       }
-      (void)fresh_words;
       interrupted = __builtin_amdgcn_readfirstlane((int)intr) != 0;
 #ifdef FH_PROFILE
       tpre2__ = pinned_clock();
@@ -3233,7 +3286,7 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
 #endif
           const int ahead_ch = sv.ticket_chunk(ka.n, (int)gridDim.x, pool_end_now);
           if (draw_ahead && threadIdx.x == 0) {  // issued here, stored after the hand-off
-            ahead_b = aadd(&sa.ctl->ticket, (unsigned long long)ahead_ch);
+            ahead_b = aadd(&sa.ctl->ticket, (unsigned long long)ahead_ch) + (unsigned long long)(sa.claims ? sv.static_tickets(ka.n, (int)gridDim.x) : 0);
             ahead_ei = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->error));
             ahead_wt = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
           }
@@ -3327,6 +3380,8 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
     unsigned int* w = reinterpret_cast<unsigned int*>(c);
     if (threadIdx.x < 48) ast(&w[threadIdx.x], 0u);  // lines 0-2: done/error/interrupted, ticket/statistics/exited, wait_ticket/q_tail
     for (int i = threadIdx.x; i < FH_QCAP; i += 64) ast(&sa.seqs[i], (unsigned long long)i);
+    if (sa.claims)
+      for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) ast(&sa.claims[i], 0u);
   }
 }
 

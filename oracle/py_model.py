@@ -184,3 +184,17 @@ def milp_feasible(N, dt, x0, xf, vmax, amax, jmax, force_final, polys, big_m=1.0
     if res.status == 2:
         return False
     return None
+
+
+def milp_job(job):
+    """(tag, expect_feasible, N, dt, x0, xf, v, a, j, force, polys) -> (tag, expect, verdict, marginal): milp_feasible for one question of a
+    test (tests/test_gpu_round6.py), in a worker process of its own.  HiGHS decides with a primal tolerance of 1e-7, the kernels with
+    1e-9: on a disagreement it is asked again with every inequality moved by 1e-6 TOWARDS the expected answer — if it then agrees the
+    instance is marginal (its verdict hangs on 1e-6 of slack), if not it is a real disagreement."""
+    tag, expect, N, dt, x0, xf, v, a, j, force, polys = job
+    got = milp_feasible(N, dt, x0, xf, v, a, j, force, polys)
+    marginal = False
+    if got is not None and got != expect:
+        again = milp_feasible(N, dt, x0, xf, v, a, j, force, polys, ineq_slack=1e-6 if expect else -1e-6)
+        marginal = again == expect
+    return tag, expect, got, marginal

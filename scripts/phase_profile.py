@@ -16,7 +16,7 @@ names = ["staging (record, faces, LDS init)", "setup_trial", "states+CP", "scan"
          "  of ticket: take_task (a frame pending?)", "  of the hand-off: drain of its stores"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 mode = sys.argv[2] if len(sys.argv) > 2 else "pairs"
-ctx = capi.Context(0)
+ctx = capi.Context(0, pair_outputs=bool(int(os.environ.get("FH_PAIR_OUTPUTS", "0"))))  # (the library default: lazy pair outputs; FH_PROFILE builds write all 16 rows)
 if len(sys.argv) > 3 and int(sys.argv[3]):
     ctx.set_sched(workgroups_per_cu=int(sys.argv[3]))
 whole, faces, _ = corridor.whole_batch(B, seed=3, n_seg=10, p_choices=(2, 3, 4, 5, 6))
@@ -59,6 +59,15 @@ def report(tag, res, min_nodes=0):
               "between the loop and the result write %.0f" % (p2[4], p2[5], slot(0) - p2[4] - p2[5], p2[6], slot(1), search_total.mean(),
               p2[6] - slot(1) - search_total.mean(), p2[7]))
         print("   [r6] ticket phase: up to take_task %.0f | pool / draw %.0f | order word %.0f" % (p2[8], p2[9], p2[10]))
+        for k, nm in ((8, "up to take_task"), (9, "pool / draw"), (10, "order word")):
+            v = res["coeff"][:, M - 6, k]
+            if v.sum() > 0:
+                print("        %-16s percentiles 10/50/90/99/max: %s ; share of the slot's cycles in its top 1 %% of problems: %.2f" % (
+                    nm, " ".join("%.0f" % x for x in np.percentile(v, [10, 50, 90, 99, 100])), np.sort(v)[-max(len(v) // 100, 1):].sum() / v.sum()))
+        for k, nm in ((0, "staging"), (17, "result write"), (18, "hand-off"), (19, "ticket phase")):
+            v = prof[:, k]
+            if v.sum() > 0:
+                print("        %-16s percentiles 10/50/90/99/max: %s" % (nm, " ".join("%.0f" % x for x in np.percentile(v, [10, 50, 90, 99, 100]))))
     return denom / n
 
 

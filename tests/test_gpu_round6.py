@@ -36,29 +36,18 @@ def _polys_of(p, faces):
             for q in range(int(p["n_poly"]))]
 
 
-def _highs_job(job):
-    """(tag, expect_feasible, N, dt, x0, xf, v, a, j, force, polys) -> (tag, expect, verdict, marginal)"""
+def _run_highs(jobs):
+    """jobs through oracle/py_model.py:milp_job (HiGHS: feasible? and, on a disagreement, whether 1e-6 of slack flips it) on all host
+    cores.  The pool is SPAWNED, not forked: this process has the HIP runtime, its threads and (in a full run of the suite) a dozen
+    contexts behind it — a forked child of that can hang before it runs a line of SciPy (seen: the suite stopped here for 15 minutes)."""
     from oracle import py_model
 
-    tag, expect, N, dt, x0, xf, v, a, j, force, polys = job
-    got = py_model.milp_feasible(N, dt, x0, xf, v, a, j, force, polys)
-    marginal = False
-    if got is not None and got != expect:
-        # HiGHS decides with a primal tolerance of 1e-7, the kernel with 1e-9: ask again with every inequality moved by 1e-6 TOWARDS the
-        # kernel's answer.  If HiGHS then agrees the instance is marginal (its verdict hangs on 1e-6 of slack); if not, it is a real
-        # disagreement.
-        again = py_model.milp_feasible(N, dt, x0, xf, v, a, j, force, polys, ineq_slack=1e-6 if expect else -1e-6)
-        marginal = again == expect
-    return tag, expect, got, marginal
-
-
-def _run_highs(jobs):
     workers = max(1, min(16, (os.cpu_count() or 2) - 1))
     try:
-        with multiprocessing.get_context("fork").Pool(workers) as pool:  # (the children run SciPy only: nothing of HIP is touched after the fork)
-            return pool.map(_highs_job, jobs, chunksize=4)
+        with multiprocessing.get_context("spawn").Pool(workers) as pool:
+            return pool.map(py_model.milp_job, jobs, chunksize=4)
     except Exception:
-        return [_highs_job(j) for j in jobs]
+        return [py_model.milp_job(j) for j in jobs]
 
 
 def _factor_jobs(tag, p, faces, r, base, n_seg, force, all_factors_if_unsolved=True):
