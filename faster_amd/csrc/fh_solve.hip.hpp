@@ -3088,10 +3088,14 @@ template <int NSEG, bool PAIRS, int WPS = FH_WAVES_PER_SIMD, bool UNK = false>
 __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __restrict__ problems, const fh_face* __restrict__ faces,
                                                    fh_result* __restrict__ results, SolveArgs ka) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [r6] The row norms stay in registers in every build (NORMS_TABLE = false).  Round 5 re-read them from the basis table in the
+  // three-wavefront build to save eight registers; with x0 in LDS and the safe problem built on chip the allocation is a different one:
+  // the table variant has 41 spilled registers in <10, true, 3>, this one 19, and it is 1 % faster (A/B, same box: 23.15 against 22.9 M
+  // pairs/s, one launch alone 2.77 against 2.9 ms) — the loads the table variant issues in every scan wait behind every store in flight.
 #ifndef FH_NORMS_FROM_TABLE
-#define FH_NORMS_FROM_TABLE (WPS > 2)
+#define FH_NORMS_FROM_TABLE false
 #endif
-  typedef Solver<NSEG, FH_NORMS_FROM_TABLE> SolverT;  // (three wavefronts per SIMD: the row norms from the table, see Solver)
+  typedef Solver<NSEG, FH_NORMS_FROM_TABLE> SolverT;
   SolverT sv;
   sv.carve(smem, ka.max_faces);
   sv.lane = threadIdx.x;
