@@ -47,7 +47,7 @@ def algorithmic_bytes(problems, n_seg_out):
     return reads + writes
 
 
-ROUND = "r05"   # the round whose profiles/ this bench line may quote (never an older round's counters for a newer kernel)
+ROUND = "r06"   # the round whose profiles/ this bench line may quote (never an older round's counters for a newer kernel)
 
 
 def measured_traffic(kernel_name):
@@ -817,6 +817,66 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
         wprob, safe = d_whole.cpu().numpy().view(abi.problem_dtype).copy(), d_safe.cpu().numpy().view(abi.problem_dtype).copy()
         counts = d_counts.cpu().numpy().copy()
         pops = int(d_ex.sum().item())
+        # ---- [r6] the same chain with its stages OVERLAPPED: three batches in flight, each on a lane of its own (a map, a context and a
+        # stream: every call of the chain is asynchronous on its lane's stream), so that the path search of one batch — issue-bound, 73 % of
+        # a staged replan — runs beside the solves and decompositions of the others.  Every batch is the whole chain from the cloud to
+        # the committed plans; the plans of a lane are compared with the staged run's.
+        pipelined = None
+        try:
+            class RLane:
+                pass
+
+            rl = []
+            for k in range(3):
+                ln = RLane()
+                ln.stream = torch.cuda.Stream(device=dev)
+                ln.ctx, ln.vmap = capi.Context(local_rank), capi.Map(local_rank)
+                ln.ctx.set_stream(ln.stream.cuda_stream); ln.vmap.set_stream(ln.stream.cuda_stream)
+                ln.ctx.set_params(par)
+                ln.ctx.set_pair_rule(mode=1, r_known=r_known, drone_radius=drone_r, delta_h=1.0, delta_a=0.5)
+                ln.vmap.set_search("jps"); ln.vmap.set_sphere(r_known)
+                for nm, t in (("whole", d_whole), ("safe", d_safe), ("paths", d_paths), ("np", d_np), ("ex", d_ex), ("wf", d_wf), ("sf", d_sf), ("off", d_off),
+                              ("npoly", d_npoly), ("last", d_last), ("wr", d_wr), ("sr", d_sr), ("plans", d_plans), ("counts", d_counts), ("k", d_k)):
+                    setattr(ln, nm, torch.zeros_like(t))
+                rl.append(ln)
+
+            def issue(ln):
+                with torch.cuda.stream(ln.stream):
+                    ln.whole.copy_(d_whole_t, non_blocking=True)
+                    ln.safe.copy_(d_tmpl, non_blocking=True)
+                ln.vmap.read_device(d_cloud.data_ptr(), len(cloud), cells, res, center, 0.0, zmax, infl)
+                ln.vmap.plan_batch_device(d_starts.data_ptr(), d_goals.data_ptr(), B, mp, ln.paths.data_ptr(), ln.np.data_ptr(), ln.ex.data_ptr(), 1.5, 0)
+                ln.ctx.corridor_batch_device(d_cloud.data_ptr(), len(cloud), ln.paths.data_ptr(), ln.np.data_ptr(), B, mp, max_poly, fpp, ln.wf.data_ptr(),
+                                             ln.off.data_ptr(), ln.npoly.data_ptr(), ln.last.data_ptr(), decomp_r, 0.0)
+                ln.ctx.corridor_problems_device(ln.np.data_ptr(), ln.last.data_ptr(), d_goals.data_ptr(), ln.wf.data_ptr(), ln.off.data_ptr(), ln.npoly.data_ptr(),
+                                                B, fpp, N, ln.whole.data_ptr())
+                ln.ctx.solve_batch_device(ln.whole.data_ptr(), ln.wf.data_ptr(), B, N, fpp, ln.wr.data_ptr())
+                ln.ctx.safe_corridor_batch_device(ln.whole.data_ptr(), ln.wr.data_ptr(), ln.paths.data_ptr(), ln.np.data_ptr(), mp, d_goals.data_ptr(),
+                                                  d_cloud.data_ptr(), len(cloud), origin, res, dims, B, 0.5, max_poly, (2.0, 2.0, 1.0), decomp_r, 0.0, fpp, N,
+                                                  ln.safe.data_ptr(), ln.sf.data_ptr())
+                ln.ctx.solve_batch_device(ln.safe.data_ptr(), ln.sf.data_ptr(), B, N, fpp, ln.sr.data_ptr())
+                ln.ctx.append_plans_device(ln.whole.data_ptr(), ln.wr.data_ptr(), ln.safe.data_ptr(), ln.sr.data_ptr(), B, 0.5, max_states, ln.plans.data_ptr(),
+                                           ln.counts.data_ptr(), ln.k.data_ptr())
+
+            for ln in rl:  # allocations, jump tables, first-launch set-up: untimed
+                issue(ln)
+            torch.cuda.synchronize()
+            batches = 9
+            t = time.perf_counter()
+            for b in range(batches):
+                issue(rl[b % len(rl)])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t
+            same_counts = all(bool(torch.equal(ln.counts, d_counts)) for ln in rl)
+            same_plans = all(bool(torch.equal(ln.plans, d_plans)) for ln in rl)
+            pipelined = {"lanes": len(rl), "batches": batches, "ms_per_batch": 1e3 * el / batches, "replans_per_s": batches * B / el,
+                         "plans_identical_to_the_staged_run": bool(same_counts and same_plans),
+                         "note": "the whole chain of a batch (map, path search, corridors, both solves, appendToPlan) issued asynchronously on the stream of "
+                                 "its lane, three lanes in flight: throughput is bound by what the stages share of the device, not by their sum"}
+            for ln in rl:
+                ln.vmap.close(); ln.ctx.close()
+        except Exception as e:  # (the staged figures stand on their own)
+            pipelined = {"error": repr(e)[:300]}
         # ---- the same pairs with unknown space as an INPUT (fh_pair_rule mode 2): the voxels of the map's lattice that a vehicle which has
         # explored a dozen spheres has not seen.  Map, paths and whole trajectories do not depend on it: the three stages that do, again.
         iz, iy, ix = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
@@ -886,6 +946,7 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
             "safe_solved_frac": float(sres["solved"][need].mean()) if need.any() else None,
             "plans_committed_frac": float((counts > 0).mean()), "mean_plan_states": float(counts[counts > 0].mean()) if (counts > 0).any() else 0.0,
             "unknown_space_as_an_input": unknown_input,
+            "pipelined": pipelined,
             "note": "unknown space is MODELLED (a batch has no mapper): everything farther than Ra from the start — distance queries use "
                     "Ra - |p - A|, the decomposition sees the voxels of the map's grid out there; path_search includes building the jump tables "
                     "of the map; whole_corridor includes fh_corridor_problems_device (E = G or the last vertex)"}
