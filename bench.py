@@ -925,6 +925,9 @@ def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
                          "fused": {"kernel": fused_kernel, "ms": med2["fused_whole_handoff_safe"], "pairs_needing_a_safe_trajectory": int(need3.sum()),
                                    "same_r_as_the_staged_chain": float(np.all(np.abs(safe3["x0"][both] - safe2["x0"][both]) <= 1e-12, axis=1).mean()) if both.any() else None,
                                    "safe_solved_frac": float(sres3["solved"][need3].mean()) if need3.any() else None,
+                                   "label": "OCCUPIED-SPACE corridor, NOT FASTER's safe corridor (its polytopes are the whole corridor's: decomposed against "
+                                            "occupied points only, not against unknown + occupied space as faster.cpp:493-499) - not an alternative to the "
+                                            "staged chain's safe_corridor + safe_solve, a different and easier problem",
                                    "note": "fh_solve_pairs_device with rule mode 2: whole solve + hand-off + safe solve of all pairs in one launch "
                                            "(stages_ms.fused_whole_handoff_safe) — against whole_solve above + safe_corridor + safe_solve of the staged "
                                            "chain; its safe corridor is the run of polytopes of the whole corridor from the one that holds R"},

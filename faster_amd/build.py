@@ -13,7 +13,7 @@ import glob  # noqa: E402
 DEPS = SOURCES + sorted(glob.glob(os.path.join(HERE, "csrc", "*.hpp"))) + [os.path.join(ROOT, "include", "fasterhip.h")]
 HOST_SO = os.path.join(HERE, "libsolverhip.so")
 HOST_SOURCES = [os.path.join(HERE, "host", "solver_hip.cpp"), os.path.join(HERE, "host", "decomp_hip.cpp"),
-                os.path.join(HERE, "host", "jps_hip.cpp")]
+                os.path.join(HERE, "host", "jps_hip.cpp"), os.path.join(HERE, "host", "corridor_frontend.cpp")]  # (JpsHip searches ONE query on the host)
 HOST_DEPS = HOST_SOURCES + [os.path.join(HERE, "host", "solver_hip.hpp"), os.path.join(HERE, "host", "faster_stub.hpp"),
                             os.path.join(HERE, "host", "decomp_hip.hpp"), os.path.join(HERE, "host", "jps_hip.hpp"),
                             os.path.join(HERE, "host", "corridor_frontend.hpp"),

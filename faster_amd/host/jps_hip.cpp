@@ -37,8 +37,13 @@ bool JpsHip::updateJPSMap(const std::vector<fhfront::V3>& cloud, const fhfront::
   if (rc_ != FH_OK) {
     err_ = fh_map_last_error(map_);
     std::fprintf(stderr, "JpsHip: updateJPSMap: rc=%d %s\n", rc_, err_.c_str());
+    have_cloud_ = false;
     return false;
   }
+  cloud_ = cloud;
+  center_ = center;
+  have_cloud_ = true;
+  grid_stale_ = true;
   return true;
 }
 
@@ -82,6 +87,21 @@ std::vector<std::vector<fhfront::V3>> JpsHip::solveJPS3DBatch(const std::vector<
 }
 
 std::vector<fhfront::V3> JpsHip::solveJPS3D(const fhfront::V3& start, const fhfront::V3& goal, bool* solved) {
+  if (single_on_host_ && have_cloud_) {  // one query: the host restatement of the same search (see jps_hip.hpp)
+    if (grid_stale_) {
+      grid_.build(cloud_, cells_[0], cells_[1], cells_[2], factor_jps_ * res_, center_, z_ground_, z_max_, inflation_jps_);
+      grid_stale_ = false;
+    }
+    std::vector<fhfront::V3> path;
+    const bool found = jump_point_search_ ? fhfront::plan_path_jps(grid_, start, goal, inflation_jps_, path)
+                                          : fhfront::plan_path(grid_, start, goal, inflation_jps_, path);
+    if (solved) *solved = found;
+    if (!found) {
+      std::fprintf(stderr, "JPS didn't find a solution from (%g %g %g) to (%g %g %g)\n", start.x, start.y, start.z, goal.x, goal.y, goal.z);
+      path.clear();
+    }
+    return path;
+  }
   std::vector<char> ok;
   std::vector<std::vector<fhfront::V3>> r = solveJPS3DBatch({start}, {goal}, &ok);
   if (solved) *solved = !ok.empty() && ok[0];

@@ -326,6 +326,11 @@ int fh_set_pair_margin(fh_ctx* ctx, double r_margin);
  *   fh_pool_set_unknown_grid): H, R and "is a safe trajectory needed" are then the reference's decisions inside the one launch; the
  *   safe corridor of the fused kernel stays the run of polytopes of the WHOLE corridor from the one that holds R — the corridor
  *   decomposed around R against unknown + occupied space, as FASTER builds it, is fh_safe_corridor_batch_device (the staged path).
+ *   NOTE: the fused kernel's safe corridor is therefore an OCCUPIED-SPACE corridor, NOT FASTER's safe corridor (faster.cpp:475-499:
+ *   cvxEllipsoidDecomp(JPS_safe, UNKOWN_AND_OCCUPIED_SPACE, ...)): its polytopes were decomposed against occupied points only, so its safe
+ *   trajectories are NOT confined to known space — the property the safe trajectory exists for.  It is a different, easier problem
+ *   (bench.py: 0.995 of its safe problems are solved, 0.387 of the faithful chain's); a caller that needs FASTER's guarantee runs the
+ *   staged chain: fh_solve_batch_device -> fh_safe_corridor_batch_device -> fh_solve_batch_device.
  *   The fused mode-2 launch runs kernel instantiations of its own, built for two wavefronts per SIMD (<= 8 solves per CU).
  * r_frac of the calls is ignored in modes 1 and 2.  The safe corridor is built from R as described above in every mode. */
 typedef struct fh_pair_rule {

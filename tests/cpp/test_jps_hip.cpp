@@ -51,6 +51,17 @@ int main(int argc, char** argv) {
   bool one = false;
   const auto p0 = jps.solveJPS3D(starts[0], goals[0], &one);
   if (one != (bool)solved[0] || p0.size() != paths[0].size()) { std::printf("solveJPS3D differs from the batch\n"); return 1; }
+  // ... which JpsHip searches on the host by default (one query: 0.1 ms there, 3 ms on a lone wavefront); the same call sent to the device
+  for (int i = 0; i < (n_q < 8 ? n_q : 8); i++) {
+    bool on_host = false, on_device = false;
+    jps.setSingleQueryOnHost(true);
+    const auto ph = jps.solveJPS3D(starts[i], goals[i], &on_host);
+    jps.setSingleQueryOnHost(false);
+    const auto pd = jps.solveJPS3D(starts[i], goals[i], &on_device);
+    if (on_host != on_device || ph.size() != pd.size()) { std::printf("single query %d: host route and device route differ\n", i); return 1; }
+    for (size_t k = 0; k < ph.size(); k++)
+      if (ph[k].x != pd[k].x || ph[k].y != pd[k].y || ph[k].z != pd[k].z) { std::printf("single query %d vertex %zu: host route and device route differ\n", i, k); return 1; }
+  }
   std::printf("JPS_OK %d %d\n", n_q, n_solved);
   return 0;
 }
