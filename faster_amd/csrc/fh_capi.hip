@@ -174,7 +174,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   sa.compact_results = ctx->sched.compact_results ? 1 : 0;
   sa.pair_outputs = ctx->sched.pair_outputs ? 1 : 0;
   sa.pad0 = 0;
+#ifdef FH_NO_DEAL  // (A/B builds: every ticket is drawn)
+  sa.claims = nullptr;
+#else
   sa.claims = grid <= FH_MAX_GRID ? reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(ctx->d_buf[6]) + 4096 + sizeof(unsigned long long) * FH_QCAP) : nullptr;
+#endif
   sa.whole = PAIRS ? d_problems : nullptr;
   sa.wfaces = d_faces;
   sa.safe = PAIRS ? ka.safe : nullptr;
