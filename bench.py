@@ -230,6 +230,9 @@ def main():
     ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N>1 run: nccl (= RCCL over xGMI, default); gloo only with --dry-run")
+    ap.add_argument("--waiting-workgroups", type=int, default=0,
+                    help="fh_sched.waiting_workgroups of the timed pipelines: workgroups that keep waiting for frames of hard trees when the fresh "
+                         "problems of their launch run out (0: the library's default, CUs / 16)")
     ap.add_argument("--pair-outputs", action="store_true",
                     help="fh_sched.pair_outputs = 1 for the timed pipelines: the fused pair launch writes every safe problem (record + rows) to memory, as the "
                          "staged hand-off does; default off = the library's default: a safe problem is built in LDS and written only if it is shared")
@@ -329,6 +332,8 @@ def main():
     class Pipe:
         pass
 
+    sched_kw = {k: v for k, v in (("workgroups_per_cu", args.wg_per_cu), ("waiting_workgroups", args.waiting_workgroups)) if v}
+
     def make_pipe(r_margin):
         pp = Pipe()
         pp.stream = torch.cuda.Stream(device=dev)
@@ -338,8 +343,8 @@ def main():
         pp.ctx.set_pair_margin(r_margin)
         if args.workload == "c5" and args.c5_rule == "reference":
             pp.ctx.set_pair_rule(mode=1, r_known=4.0, drone_radius=0.3, delta_h=1.0, delta_a=0.5)   # Ra, delta_H, delta_a: faster.yaml
-        if args.wg_per_cu:
-            pp.ctx.set_sched(workgroups_per_cu=args.wg_per_cu)
+        if args.wg_per_cu or args.waiting_workgroups:
+            pp.ctx.set_sched(**sched_kw)
         pp.d_safe = to_dev(safe_t)
         pp.d_sfaces = torch.zeros_like(d_faces)
         pp.d_wres = torch.zeros(per_rank * RES, dtype=torch.uint8, device=dev)  # (strong: padded to the largest shard)
@@ -422,10 +427,10 @@ def main():
         # the timed launches built the safe problems on chip; their records and rows (face counts for the algorithmic bytes, the pinned
         # re-solve of the compute leg) come from ONE more launch, untimed, with complete pair outputs — the same results bit for bit
         for pp in {id(last): last, id(pipes[0]): pipes[0]}.values():
-            pp.ctx.set_sched(pair_outputs=1, **({"workgroups_per_cu": args.wg_per_cu} if args.wg_per_cu else {}))
+            pp.ctx.set_sched(pair_outputs=1, **sched_kw)
             run_step(pp, True)
             pp.ctx.sync()
-            pp.ctx.set_sched(pair_outputs=0, **({"workgroups_per_cu": args.wg_per_cu} if args.wg_per_cu else {}))
+            pp.ctx.set_sched(pair_outputs=0, **sched_kw)
         again = last.d_sres.cpu().numpy().view(abi.result_dtype)[:B]
         assert all(np.array_equal(again[f], sres[f]) for f in ("solved", "trials", "status", "factor", "dt", "cost")), "pair_outputs changed a result"
     safe_h = last.d_safe.cpu().numpy().view(abi.problem_dtype)

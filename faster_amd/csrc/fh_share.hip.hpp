@@ -202,10 +202,10 @@ __device__ __forceinline__ unsigned long long wall_ticks() { return __builtin_am
 // Reserve the next frame number for writing — ONE attempt: ~0ull if no uncommitted taker is waiting, the ring is full, or
 // another donor took the number (when the fresh problems run out, every busy workgroup sees the new takers at its next
 // look-around: a retry loop here made ~2000 donors hammer q_tail for 512 numbers, 600 us per donation).
-__device__ inline unsigned long long q_reserve(const ShareArgs& sa) {
+__device__ inline unsigned long long q_reserve(const ShareArgs& sa, int backlog = -1) {  // backlog < 0: the launch's (sa.backlog)
   const unsigned long long both = ald(reinterpret_cast<unsigned long long*>(&sa.ctl->wait_ticket));
   const unsigned int waiters = (unsigned int)both, pos = (unsigned int)(both >> 32);
-  if (pos >= waiters + (unsigned int)sa.backlog) return ~0ull;                        // enough frames are pending already
+  if (pos >= waiters + (unsigned int)(backlog < 0 ? sa.backlog : backlog)) return ~0ull;  // enough frames are pending already
   if (ald(&sa.seqs[pos & (FH_QCAP - 1)]) != (unsigned long long)pos) return ~0ull;    // slot not released yet (ring full) or the number is gone
   unsigned int expect = pos;
   if (__hip_atomic_compare_exchange_strong(&sa.ctl->q_tail, &expect, pos + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, FH_AGENT)) return pos;

@@ -108,6 +108,9 @@ __device__ __forceinline__ unsigned long long pinned_clock() {
 #ifndef FH_DONE_BATCH
 #define FH_DONE_BATCH 4
 #endif
+#ifndef FH_TICKET_BACKLOG
+#define FH_TICKET_BACKLOG 512  // ticket frames (give_tickets) that may wait ahead of the takers (the ring has FH_QCAP = 1024 slots)
+#endif
 #ifndef FH_TAIL_LEVELS_BIG
 #define FH_TAIL_LEVELS_BIG 0
 #endif
@@ -538,7 +541,9 @@ struct Solver {
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *stk_keep, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
-         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_SAFE = 26, TB_WORDS = 27 };
+         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_SAFE = 26, TB_POOL2 = 27, TB_WORDS = 29 };
+                                                                 // TB_POOL2 / + 1: a second range of tickets [next, end): tickets another workgroup gave away (give_tickets) while this one
+                                                                 // still had some of its own; it becomes the pool when the pool is empty
                                                                  // TB_SAFE: the safe problem of the fused pair in hand — bits 0..7 the polytope of the whole corridor its corridor starts
                                                                  // at, bit 8: its record and rows are in memory (written back: always, or when the problem was first shared)
                                                                  // TB_NEXT / TB_NEXT + 1: this workgroup's own pool of tickets [next, end), drawn a chunk at a time (and ahead,
@@ -1963,6 +1968,30 @@ struct Solver {
     if (FH_TICKET_CHUNK >= 2 && left >= 2ll * (long long)grid) return 2;
     return 1;
   }
+  // [r6] The tickets this workgroup holds but has not started go to a workgroup that waits for work: a frame of kind 2 (header only:
+  // the range).  A chunk of tickets is drawn — or dealt — four at a time, and a workgroup whose problem in hand runs for 2 ms kept the
+  // other three hostage: what one launch alone ended on were 20-us pairs that BEGAN at 2.7 ms (scripts/r4/tail_shape.py), behind
+  // the 380 hardest problems, which the launch order puts first.  Called where a problem looks around (every FH_LOOK_EVERY-th node of a
+  // tree: a problem that gets there is not a short one); the frames wait ahead of the takers, up to FH_TICKET_BACKLOG of them.
+  __device__ __forceinline__ void give_tickets(const ShareArgs& sa) {
+    const int a = uniform_i32(tb[TB_NEXT]), b = uniform_i32(tb[TB_NEXT + 1]);
+    if (a >= b) return;
+    unsigned long long pos = ~0ull;
+    if (lane == 0) pos = q_reserve(sa, FH_TICKET_BACKLOG);  // (ahead of the takers: a workgroup that runs dry finds them at once; header-only frames)
+    pos = uniform_u64(pos);
+    if (pos == ~0ull) return;
+    if (lane == 0) {
+      TaskHdr* th = slot_hdr(sa, pos);
+      wt_store(&th->w[TH_REC_B], pack2(0, 0));
+      wt_store(&th->w[TH_TRIALS_SEG], pack2(a, b));
+      wt_store(&th->w[TH_KIND], 2ull);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      q_publish(sa, pos);
+      aadd(&sa.ctl->donated, 1u);
+      tb[TB_NEXT] = b;  // (the pool is empty now: the next hand-off draws ahead as usual)
+    }
+    FH_SYNC();
+  }
   // Units finished here are reported FH_DONE_BATCH at a time (one 8-byte add: count | iterations << 32); flush_done before waiting / leaving
   __device__ __forceinline__ void unit_done(const ShareArgs& sa) {
     if (lane == 0) {
@@ -2047,7 +2076,19 @@ struct Solver {
       if (!idle) return 0;
       continue;
     }
-    if (uniform_u64(cc_load(&hp->w[TH_KIND])) != 0ull) {  // the remaining trials of a problem: header only
+    const unsigned long long w_kind = uniform_u64(cc_load(&hp->w[TH_KIND]));
+    if (w_kind == 2ull) {  // a range of fresh tickets another workgroup held and had not started (give_tickets): header only
+      const unsigned long long w_ts = cc_load(&hp->w[TH_TRIALS_SEG]);
+      if (lane == 0) {
+        const int at = tb[TB_NEXT] < tb[TB_NEXT + 1] ? TB_POOL2 : TB_NEXT;  // (behind this workgroup's own tickets, if it has any)
+        tb[at] = (int)(unsigned)w_ts; tb[at + 1] = (int)(w_ts >> 32);
+        q_release(sa, pos);
+        aadd(&sa.ctl->stolen, 1u);
+      }
+      FH_SYNC();
+      return 3;
+    }
+    if (w_kind != 0ull) {  // the remaining trials of a problem: header only
       const unsigned long long w_ts = cc_load(&hp->w[TH_TRIALS_SEG]);
       if (lane == 0) {
         tb[TB_REC] = (int)(unsigned)w_rec_b; tb[TB_B] = (int)(w_rec_b >> 32); tb[TB_WORK] = 0; tb[TB_WORK] = 0;
@@ -2535,6 +2576,9 @@ struct Solver {
         FH_T0();
         int fl = look_around(sa, local_nodes, iters);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }
+#ifndef FH_NO_GIVE_TICKETS
+        if (sa.enabled) give_tickets(sa);  // the tickets this workgroup holds behind the problem in hand: not hostages of a long problem
+#endif
         // somebody is out of work: a problem that has proved hard (it already has a share record, or sa.min_nodes nodes so far)
         // gives its shallowest open frame away, and — once it is shared — the factor trials after this one, or a second frame.
         // (sa.enabled is 0 with a work cap or a MIP gap.)
@@ -2780,7 +2824,10 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     bad = wave_any(!isfinite(v));
   }
   if (entry == 0 && bad) {
-    sv.N = 0; sv.flops = 0ull;
+    // (nothing of this problem is staged: an empty corridor, so that the hand-off of a pair — which runs on unconditionally and decides
+    // at its end — walks no rows; LDS holds the previous problem's, or nothing at all for a workgroup's first unit)
+    sv.N = 0; sv.flops = 0ull; sv.P = 0; sv.maxF = 0;
+    if (lane <= FH_MAX_POLY) sv.face_off[lane] = 0;
     sv.emit_result(false, 0, interrupted ? FH_ST_INTERRUPTED : FH_ST_BAD_INPUT, 0, 0, 0.0, 0.0, 0.0, rows);
     if (!defer_store) sv.flush_result(res);
     return true;
@@ -3101,7 +3148,7 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
   sv.lane = threadIdx.x;
   sv.q = 0;
   sv.qe = 0;
-  if (threadIdx.x == 0) { sv.tb[sv.TB_ZN] = 0; sv.tb_put64(sv.TB_NEXT, 0ull); sv.tb[sv.TB_DONE_N] = 0; sv.tb[sv.TB_DONE_IT] = 0; }
+  if (threadIdx.x == 0) { sv.tb[sv.TB_ZN] = 0; sv.tb_put64(sv.TB_NEXT, 0ull); sv.tb_put64(sv.TB_POOL2, 0ull); sv.tb_put64(sv.TB_NEXT_EI, 0ull); sv.tb_put64(sv.TB_NEXT_WT, 0ull); sv.tb[sv.TB_DONE_N] = 0; sv.tb[sv.TB_DONE_IT] = 0; }
   const ShareArgs& sa = ka.sa;
   double* ws = ka.workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   if (threadIdx.x == 0) {
@@ -3132,9 +3179,19 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
     // units later (the trees poll it themselves).
     int pool_next = uniform_i32(sv.tb[sv.TB_NEXT]), pool_end = uniform_i32(sv.tb[sv.TB_NEXT + 1]);
     bool frame_pending = true, fresh_words = false;
+    if (pool_next >= pool_end && pool_end > 0) {  // the pool is empty: tickets another workgroup gave away?
+      const int p2a = uniform_i32(sv.tb[sv.TB_POOL2]), p2b = uniform_i32(sv.tb[sv.TB_POOL2 + 1]);
+      if (p2a < p2b) {
+        pool_next = p2a; pool_end = p2b;
+        FH_SYNC();
+        if (threadIdx.x == 0) { sv.tb[sv.TB_NEXT] = p2a; sv.tb[sv.TB_NEXT + 1] = p2b; sv.tb_put64(sv.TB_POOL2, 0ull); }
+        FH_SYNC();
+      }
+    }
     if (tickets_left && pool_next < pool_end) {
       const unsigned long long wt = sv.tb_get64(sv.TB_NEXT_WT);
-      frame_pending = (int)((unsigned int)(wt >> 32) - (unsigned int)wt) > 0;
+      frame_pending = (int)((unsigned int)(wt >> 32) - (unsigned int)wt) > 0 &&
+                      uniform_i32(sv.tb[sv.TB_POOL2]) >= uniform_i32(sv.tb[sv.TB_POOL2 + 1]);  // (one range of given tickets at a time)
     }
     // a frame of a hard problem comes before a fresh problem; without fresh problems the workgroup waits for frames
     if (sa.enabled && (sa.backlog > 0 || !tickets_left) && (frame_pending || !tickets_left)) {
@@ -3146,6 +3203,10 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       // (the control words are a chunk of tickets old: ONE attempt per reading — the units that follow in the chunk do not ask again
       // for a frame that was pending back then; 98 % of such attempts found it gone and cost a memory round trip each)
       if (tickets_left && threadIdx.x == 0) sv.tb_put64(sv.TB_NEXT_WT, 0ull);
+      if (entry == 3) {  // a range of fresh tickets (give_tickets): they are in the pool, or behind it
+        tickets_left = true;
+        continue;
+      }
 #ifdef FH_PROFILE
       if (tickets_left) { sv.take_cycles += pinned_clock() - ttake__; sv.take_calls += 1; }
 #endif
@@ -3157,6 +3218,9 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
     if (entry) {
       unit = uniform_i32(sv.tb[sv.TB_B]);
       phase = uniform_i32(sv.tb[sv.TB_PHASE]);
+#ifdef FH_DEBUG_BOUNDS
+      if ((unsigned)unit >= (unsigned)ka.n || (unsigned)phase > 1u || entry > 2) { if (threadIdx.x == 0) ast(&sa.ctl->error, 103u + (unsigned)entry); break; }
+#endif
     } else if (!tickets_left) {
       break;  // every unit is done (or enough others are waiting, or sharing is off)
     } else {
@@ -3227,7 +3291,13 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
       } else {
         // (the launch order was written by order_scatter_kernel before this launch began: a scalar load through the constant address space)
         typedef const __attribute__((address_space(4))) int cint_t;
+#ifdef FH_DEBUG_BOUNDS
+        if (b >= (unsigned)ka.n) { if (threadIdx.x == 0) ast(&sa.ctl->error, 101u); tickets_left = false; continue; }
+#endif
         unit = ka.order ? *(cint_t*)sv.uniform_u64((unsigned long long)(ka.order + b)) : (int)b;
+#ifdef FH_DEBUG_BOUNDS
+        if ((unsigned)unit >= (unsigned)ka.n) { if (threadIdx.x == 0) ast(&sa.ctl->error, 102u); tickets_left = false; continue; }
+#endif
         if (threadIdx.x == 0) { sv.tb[sv.TB_B] = unit; sv.tb[sv.TB_PHASE] = 0; sv.tb[sv.TB_WORK] = 0; }
       }
     }

@@ -259,3 +259,65 @@ def test_lazy_pair_outputs_and_compact_results_give_the_same_bits():
         for f in abi.problem_dtype.names:
             assert np.array_equal(safe0[f][i], safe_ref[f][i]), (i, f)
     print("lazy outputs: %d of %d safe records written (shared safe problems); donations %d / %d" % (len(written), B, st0["donated"], st1["donated"]))
+
+
+def test_pairs_with_unusable_whole_problems_first_in_line():
+    """A pair whose whole problem is unusable (bad input) or has no solution never stages a corridor — and the hand-off of the fused
+    kernel runs on unconditionally and decides at its end.  Such problems as the FIRST units of their workgroups (nothing at all in LDS
+    yet: launch order off, so unit = ticket, and the first tickets are dealt to the workgroups one chunk each) must give what the three
+    launches give, with other launches of other contexts in flight (workgroups that start late take given tickets before they draw any)."""
+    import torch
+
+    from tests.test_gpu_round3 import _dev
+
+    B, N = 16384, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=77, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    whole = whole.copy()
+    whole["n_seg"][0:4096:4] = 0            # bad input
+    whole["x0"][1:4096:4, 4] = np.nan       # bad input (found where x0 is staged)
+    whole["f_final"][2:4096:4] = 1.0        # mostly without a solution
+    whole["face_off"][3:4096:16, 1] = -5    # bad corridor layout
+    tmpl = corridor.safe_templates(whole)
+    mf = int(whole["face_off"][np.arange(B), np.clip(whole["n_poly"], 0, 8)].max())
+    RS = abi.result_dtype.itemsize
+
+    def staged(c):
+        d_whole, d_faces, d_safe = _dev(whole), _dev(faces), _dev(tmpl)
+        d_sf = torch.zeros_like(d_faces)
+        d_wr, d_sr = torch.zeros(B * RS, dtype=torch.uint8, device="cuda:0"), torch.zeros(B * RS, dtype=torch.uint8, device="cuda:0")
+        c.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, d_wr.data_ptr())
+        c.pair_glue_device(d_whole.data_ptr(), d_wr.data_ptr(), d_faces.data_ptr(), B, 0.5, 0.2, 3, d_safe.data_ptr(), d_sf.data_ptr())
+        c.solve_batch_device(d_safe.data_ptr(), d_sf.data_ptr(), B, N, mf, d_sr.data_ptr())
+        c.sync()
+        return d_wr.cpu().numpy().view(abi.result_dtype).copy(), d_sr.cpu().numpy().view(abi.result_dtype).copy()
+
+    ref = capi.Context(0)
+    ref.set_pair_margin(0.05)
+    ref.set_sched(launch_order=0)
+    wref, sref = staged(ref)
+    ref.close()
+    assert (wref["status"][0:4096:4] == abi.FH_ST_BAD_INPUT).all() and (wref["status"][1:4096:4] == abi.FH_ST_BAD_INPUT).all()
+    lanes = []
+    for k in range(4):  # four contexts, their fused launches in flight together, twice each
+        c = capi.Context(0, pair_outputs=False, compact_results=True)
+        s = torch.cuda.Stream()
+        c.set_stream(s.cuda_stream)
+        c.set_pair_margin(0.05)
+        c.set_sched(launch_order=0)
+        bufs = [_dev(whole), _dev(faces), _dev(tmpl)]
+        bufs += [torch.zeros_like(bufs[1]), torch.zeros(B * RS, dtype=torch.uint8, device="cuda:0"), torch.zeros(B * RS, dtype=torch.uint8, device="cuda:0")]
+        lanes.append((c, s, bufs))
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for c, s, (dw, df, ds, dsf, dwr, dsr) in lanes:
+            c.solve_pairs_device(dw.data_ptr(), df.data_ptr(), B, N, mf, 0.5, 0.2, 3, dwr.data_ptr(), ds.data_ptr(), dsf.data_ptr(), dsr.data_ptr())
+    torch.cuda.synchronize()
+    fields = [f for f in abi.result_dtype.names if f not in ("nodes", "qp_iters", "kflops", "coeff")]
+    for c, s, (dw, df, ds, dsf, dwr, dsr) in lanes:
+        w, sr = dwr.cpu().numpy().view(abi.result_dtype), dsr.cpu().numpy().view(abi.result_dtype)
+        for f in fields:
+            assert np.array_equal(w[f], wref[f]), ("whole", f)
+            assert np.array_equal(sr[f], sref[f]), ("safe", f)
+        assert np.array_equal(w["coeff"][:, :N], wref["coeff"][:, :N]) and np.array_equal(sr["coeff"][:, :N], sref["coeff"][:, :N])
+        assert c.share_stats()["error"] == 0
+        c.close()
