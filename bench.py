@@ -232,7 +232,7 @@ def main():
                     help="torch.distributed backend of the N>1 run: nccl (= RCCL over xGMI, default); gloo only with --dry-run")
     ap.add_argument("--waiting-workgroups", type=int, default=0,
                     help="fh_sched.waiting_workgroups of the timed pipelines: workgroups that keep waiting for frames of hard trees when the fresh "
-                         "problems of their launch run out (0: the library's default, CUs / 16)")
+                         "problems of their launch run out (0: the library's default, CUs / 64 for big batches)")
     ap.add_argument("--pair-outputs", action="store_true",
                     help="fh_sched.pair_outputs = 1 for the timed pipelines: the fused pair launch writes every safe problem (record + rows) to memory, as the "
                          "staged hand-off does; default off = the library's default: a safe problem is built in LDS and written only if it is shared")

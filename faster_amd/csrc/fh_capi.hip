@@ -159,7 +159,11 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // Waiting workgroups.  Measured on C4 (32768 pairs per launch): 16 of them shorten a launch as much as 64 or 512 do (the tail is
   // bound by its critical path — the sequential factor trials of the hardest problem — not by hands), and every waiter holds
   // LDS that another launch of the same device could use (12 launches in flight: 7.4 M pairs/s with 16, 7.0 M with 64, 5.9 M with 256).
-  sa.max_hungry = ctx->sched.waiting_workgroups > 0 ? ctx->sched.waiting_workgroups : std::max(8, ctx->n_cu / 16);
+  // [r6] CUs / 64 (4): since held tickets are given away ahead of the takers (give_tickets) one launch alone ends as soon with 2-4 waiting
+  // workgroups as with 16 (2.64-2.67 against 2.71 ms), and with launches in flight every waiter holds a slot their bulk could use
+  // (23.45-23.6 against 23.3 M pairs/s)
+  // (a batch of up to 8 problems per CU — one vehicle's replan: one problem and a helper workgroup per CU — keeps CUs / 16: its helpers ARE the waiters)
+  sa.max_hungry = ctx->sched.waiting_workgroups > 0 ? ctx->sched.waiting_workgroups : (n <= 8 * ctx->n_cu ? std::max(8, ctx->n_cu / 16) : std::max(2, ctx->n_cu / 64));
   sa.min_nodes = ctx->sched.min_nodes;
   // Frames published AHEAD of the takers (served by workgroups between two problems).  What a launch ends on are problems with
   // 1200-4300 active-set iterations (C4: ~140 of 32768 pairs, mostly safe problems that are infeasible for all ten factors) that

@@ -541,7 +541,8 @@ struct Solver {
   int *act, *assign, *bestassign, *fullassign, *stk_seg, *stk_next, *stk_cnt, *stk_q, *stk_mask, *stk_keep, *face_off;
   int* tb;                                            // [TB_WORDS] wave-uniform words that would otherwise sit in SGPRs for the whole solve
   enum { TB_B = 0, TB_PHASE = 1, TB_F = 2, TB_TRIALS = 4, TB_BASE = 5, TB_H = 7, TB_REC = 9, TB_DEPTH0 = 10, TB_KEY = 11, TB_QE = 13,
-         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_SAFE = 26, TB_POOL2 = 27, TB_WORDS = 29 };
+         TB_T0 = 14, TB_WORK = 16, TB_ZN = 17, TB_NEXT = 18, TB_NEXT_EI = 20, TB_NEXT_WT = 22, TB_DONE_N = 24, TB_DONE_IT = 25, TB_SAFE = 26, TB_POOL2 = 27, TB_FRESH = 29, TB_WORDS = 30 };
+                                                                 // TB_FRESH: the states and jerks in LDS / registers are those of the incumbent leaf (no node was solved since it was found)
                                                                  // TB_POOL2 / + 1: a second range of tickets [next, end): tickets another workgroup gave away (give_tickets) while this one
                                                                  // still had some of its own; it becomes the pool when the pool is empty
                                                                  // TB_SAFE: the safe problem of the fused pair in hand — bits 0..7 the polytope of the whole corridor its corridor starts
@@ -1382,6 +1383,7 @@ struct Solver {
   // comes earlier in depth-first order than this node: the sequential search keeps the FIRST leaf of minimal cost)
   __device__ int qp_run(double ub, bool tie, int max_iters, int& iters, double& cost) {
     int it = 0;
+    if (lane == 0) tb[TB_FRESH] = 0;  // (the states of the incumbent leaf, if they were still there, are about to be overwritten)
     bind_assignment();
     const int q0 = q;
     const int st = qp_loop(ub, tie, max_iters, it, cost);
@@ -2640,6 +2642,7 @@ struct Solver {
             best_key = cur_key;
             if (lane < n) bestx_r = x[lane];
             if (lane < N) bestassign[lane] = fullassign[lane];
+            if (lane == 0) tb[TB_FRESH] = 1;  // Pc / Vc / Ac and the jerks xj are this leaf's until the next node is solved
             FH_SYNC();
             if (rec >= 0) publish_incumbent(sa, cost);
           }
@@ -2814,6 +2817,15 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   }
   bool bad = interrupted;
   if (entry == 0 && !bad) bad = bad_scalars(pr, NSEG, staged ? sv.P : (int)pr.n_poly) || (staged == 0 && bad_corridor(pr, max_faces));
+#ifndef FH_NO_EARLY_FACES
+  // [r6] the first 64 rows of the corridor are requested NOW — the layout has just been checked — so that they travel together with x0
+  // and xf: one memory round trip for the staging of a problem instead of two (both are first touches of their lines)
+  fh_face fc_first = {{0.0, 0.0, 0.0}, 0.0};
+  if (staged == 0 && !bad) {
+    const int nf_ = pr.n_poly ? pr.face_off[pr.n_poly] : 0;
+    if (lane < nf_) fc_first = gfaces[pr.face_begin + lane];
+  }
+#endif
   if (staged == 0) {
     if (lane < 9) *sv.x0_slot(lane) = x0xf;
     else if (lane < 18) sv.xfl[lane - 9] = x0xf;
@@ -2884,7 +2896,11 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     for (int f0_ = 0; f0_ < nf; f0_ += 64) {
       const int f = f0_ + lane;
       bool degenerate_violated = false;
+#ifndef FH_NO_EARLY_FACES
+      if (f < nf) sv.stage_face(f0_ == 0 ? fc_first : gfaces[pr.face_begin + f], par.feas_tol, f, degenerate_violated);
+#else
       if (f < nf) sv.stage_face(gfaces[pr.face_begin + f], par.feas_tol, f, degenerate_violated);
+#endif
       if (wave_any(degenerate_violated)) {
         int pf = 0;
         for (int p = 0; p < pr.n_poly; p++) pf = (f >= pr.face_off[p]) ? p : pf;
@@ -3053,9 +3069,14 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
 #endif
   if (solved) {  // the jerks and the states of the optimum: what the coefficient rows are made of (emit_result)
     FH_SYNC();
-    if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
-    FH_SYNC();
-    sv.compute_states();
+    // [r6] ... which are still in LDS and registers when no node was solved after the incumbent leaf (the siblings behind it were
+    // pruned by their bounds: half of the solved problems) — the same numbers compute_states would produce again from the same y
+    const bool fresh = sv.rec < 0 && uniform_i32(sv.tb[sv.TB_FRESH]) != 0;
+    if (!fresh) {
+      if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
+      FH_SYNC();
+      sv.compute_states();
+    }
     FH_SYNC();
     if (lane < sv.NXP) sv.xs[lane] = (lane < sv.nx) ? sv.xj : 0.0;  // the jerks xp + Z y
     FH_SYNC();

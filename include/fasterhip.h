@@ -175,7 +175,7 @@ typedef struct fh_sched {
   int32_t publish_factor;     /* a problem that has used this many times the running mean of active-set iterations may publish
                                  frames ahead of the idle workgroups (default 4; 0: never)                                      */
   int32_t backlog;            /* frames that may be published ahead of the takers (default 32; 0: none)                        */
-  int32_t waiting_workgroups; /* workgroups that keep waiting for frames when the fresh problems run out (0 = default: CUs / 16) */
+  int32_t waiting_workgroups; /* workgroups that keep waiting for frames when the fresh problems run out (0 = default: CUs / 64; CUs / 16 for batches of up to 8 problems per CU) */
   int32_t min_nodes;          /* a problem gives work to an IDLE workgroup only after this many nodes of its trees (default 2)  */
   int32_t cloud_blocks;       /* 1 (default): the decomposition skips blocks of 64 cloud points whose bounding box misses the
                                  local box of a segment                                                                         */
