@@ -1507,6 +1507,9 @@ struct Solver {
         if (t2 <= t1) {
           FH_T0();
           add_row(id, zi, zz, dc, up);
+#ifdef FH_QMAX_STAT
+          qmax = max(qmax, q);
+#endif
           FH_T1(7);
           break;
         }
@@ -2288,6 +2291,9 @@ struct Solver {
       const int kfl = kf > 0x7fffffffull ? 0x7fffffff : (int)kf;
       int* Ti = reinterpret_cast<int*>(T);
       Ti[0] = solved ? 1 : 0; Ti[1] = trials; Ti[2] = status; Ti[3] = nodes; Ti[4] = iters; Ti[5] = kfl;
+#ifdef FH_QMAX_STAT
+      Ti[5] = qmax;
+#endif
       T[3] = solved ? factor : 0.0;
       T[4] = dt;
       T[5] = solved ? cost : 0.0;
@@ -2316,6 +2322,9 @@ struct Solver {
     }
   }
   int fin_rows;  // coefficient rows in the table emit_result left behind
+#ifdef FH_QMAX_STAT
+  int qmax;      // (diagnostic build: the largest number of active rows of the problem in hand, reported in fh_result.kflops)
+#endif
 
   // ---- the hand-off of a fused pair without a trip through memory -----------------------------------------------------
   // What pair_glue_one (fh_sample.hip.hpp) does for the staged pipeline — R from the whole trajectory (Faster::replan, faster.cpp:475), the
@@ -2807,6 +2816,9 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
   sv.glue_parts[0] = sv.glue_parts[1] = sv.glue_parts[2] = sv.glue_parts[3] = 0;
 #endif
   sv.forget_lane_state();
+#ifdef FH_QMAX_STAT
+  sv.qmax = 0;
+#endif
   FH_SYNC();  // the previous problem of this workgroup is completely done with LDS
   // x0 and xf: 18 consecutive doubles of the record, one load (lane = word), into the LDS slots the solve reads them from
   double x0xf = 0.0;

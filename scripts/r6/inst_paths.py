@@ -5,7 +5,7 @@ sym = sys.argv[1]
 T = "/tmp/fh_code_size"
 lines = open(T + "/dis.txt").read().split("\n")
 start = [i for i, l in enumerate(lines) if sym in l and l.endswith(">:")][0]
-end = [i for i, l in enumerate(lines[start + 1:], start + 1) if re.match(r"^[0-9a-f]+ <", l)][0]
+end = ([i for i, l in enumerate(lines[start + 1:], start + 1) if re.match(r"^[0-9a-f]+ <", l)] + [len(lines)])[0]
 addrs, ops = [], []
 for i in range(start, end):
     m = re.match(r"^\s+(\S+).*?// ([0-9A-Fa-f]+):", lines[i])
