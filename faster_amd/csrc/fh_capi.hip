@@ -950,7 +950,7 @@ static int decompose_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud,
   if (!(local_bbox[0] > 0) || !(local_bbox[1] > 0) || !(local_bbox[2] > 0) || !(drone_radius >= 0)) return FH_ERR_ARG;
   const int grid = std::min(n_segments, ctx->n_cu * 12);  // LDS: 10.5 KB per workgroup
   int rc;
-  if ((rc = ensure(ctx, 7, sizeof(double) * (size_t)grid * (3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8))) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 7, sizeof(double) * (size_t)grid * (size_t)FH_DECOMP_WS_DOUBLES)) != FH_OK) return rc;
   // bounding boxes of the blocks of 64 cloud points: most blocks cannot touch a segment's local box and are skipped (same results)
   double* d_blocks = nullptr;
   const int n_blocks = (n_cloud + 63) / 64;
@@ -973,6 +973,16 @@ static int decompose_device(fh_ctx* ctx, const double* d_cloud_xyz, int n_cloud,
                      local_bbox[0], local_bbox[1], local_bbox[2], drone_radius, z_ground, max_faces, (double*)ctx->d_buf[7], d_faces,
                      d_counts, d_blocks, lat, lat.on ? d_seg_spheres : nullptr, (int*)ctx->d_buf[18]);
   FH_HIP(hipGetLastError());
+#ifdef FHD_EXPERIMENT
+  if (std::getenv("FHD_HIST")) {  // (diagnostic: how long the lists of this launch were)
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    FH_HIP(hipStreamSynchronize(ctx->stream));
+    FH_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(fh::fhd_hist), sizeof(h)));
+    FH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fh::fhd_hist), z, sizeof(z)));
+    std::fprintf(stderr, "FHD_HIST segments %d lattice %d | lists <=256: %llu <=1536: %llu <=16384: %llu more: %llu | points %llu cells swept %llu\n", n_segments, lat.on,
+                 h[0], h[1], h[2], h[3], h[4], h[5]);
+  }
+#endif
   return FH_OK;
 }
 

@@ -25,10 +25,14 @@ namespace fh {
 
 #define FH_DECOMP_CAP 256  // points inside the local box whose (inflated) COORDINATES fit the LDS list of a segment
                             // (256: 10.5 KB of LDS, 12 workgroups per CU at 165 VGPRs — with 1024 and 4 per CU the same launches took 1.6x as long)
-#define FH_DECOMP_CAP_IDS 1536  // ... longer lists are kept in the SAME LDS as 4-byte ids (a cloud index, or the packed cell of an unknown
+#define FH_DECOMP_CAP_IDS 1728  // ... longer lists are kept in the SAME LDS as 4-byte ids (a cloud index, or the packed cell of an unknown
                             // voxel) + a flag byte, and a point is rebuilt — loaded or enumerated, inflated — whenever it is looked at: the
                             // lists of the safe corridor (2-3 k unknown voxels per local box) used to live in the workgroup's HBM workspace
-                            // and were rewritten there after every separating plane (3-5 GB of writes per dispatch)
+                            // and were rewritten there after every separating plane (3-5 GB of writes per dispatch).  (1728: with the
+                            // candidate-block list the workgroup's LDS is 12 736 B, ten granules of 1280 B: 12 workgroups per CU.)
+                            // [r6] A list longer than that keeps its first FH_DECOMP_CAP_IDS entries in LDS and the REST in the workspace
+                            // (HybridList): with the caller's unknown voxels 55 % of the replan workload's segments hold 1537-4000 points, and
+                            // their whole lists used to live in the workspace, filled by a second sweep.
 #define FH_DECOMP_EPS 1e-10  // DecompUtil's epsilon_
 
 struct D3 {
@@ -84,6 +88,7 @@ __device__ __forceinline__ int sgn_i(double v) { return (0.0 < v) - (v < 0.0); }
 // arg-min of the ellipsoid distance over the list entries whose flag has `bit`; returns the list index (-1 if none)
 #ifdef FHD_EXPERIMENT
 __constant__ int fhd_stop_after;
+__device__ unsigned long long fhd_hist[8];  // segments whose list has <= 256, <= 1536, <= 16384, more points; sum of the counts; cells swept
 #endif
 template <class L>
 __device__ __forceinline__ int closest_in(const L& list, int cnt, unsigned char bit, const Rot& R, D3 ax, D3 c, int lane) {
@@ -168,7 +173,8 @@ __device__ __forceinline__ bool lattice_point(const UnknownLattice& lat, const L
 }
 
 #define FH_DECOMP_BLIST 1024  // candidate blocks per segment (more: full sweep)
-#define FH_DECOMP_CAP_GLOBAL 16384  // list capacity when the (id) list lives in the HBM workspace (dense clouds); more => count = -1
+#define FH_DECOMP_CAP_GLOBAL 16384  // list capacity with the tail of the (id) list in the HBM workspace (dense clouds); more => count = -1
+#define FH_DECOMP_WS_DOUBLES (FH_DECOMP_CAP_GLOBAL / 2 + FH_DECOMP_CAP_GLOBAL / 8)  // workspace of a workgroup: 4-byte ids, then flag bytes
 
 // ---- what a segment's list of box points is made of ----
 // CoordList: the inflated coordinates themselves (short lists: a look is three LDS loads).
@@ -182,8 +188,6 @@ struct CoordList {
   __device__ __forceinline__ unsigned char flag(int i) const { return fl[i]; }
   __device__ __forceinline__ void set_flag(int i, unsigned char f) const { fl[i] = f; }
   __device__ __forceinline__ void store(int pos, const Entry& e, unsigned char f) const { px[pos] = e.x; py[pos] = e.y; pz[pos] = e.z; fl[pos] = f; }
-  __device__ __forceinline__ void put(int pos, D3 inflated, int) const { px[pos] = inflated.x; py[pos] = inflated.y; pz[pos] = inflated.z; }
-  static constexpr bool kNeedsPoint = true;  // put() wants the inflated point
 };
 // IdList: which point it is — cloud index (>= 0) or 0x80000000 | packed cell of the unknown lattice — rebuilt at every look with the
 // arithmetic that CoordList applied once (the same doubles).
@@ -207,13 +211,37 @@ struct IdList {
   __device__ __forceinline__ unsigned char flag(int i) const { return fl[i]; }
   __device__ __forceinline__ void set_flag(int i, unsigned char f) const { fl[i] = f; }
   __device__ __forceinline__ void store(int pos, const Entry& e, unsigned char f) const { id[pos] = e; fl[pos] = f; }
-  __device__ __forceinline__ void put(int pos, D3, int ident) const { id[pos] = ident; }
-  static constexpr bool kNeedsPoint = false;
 };
 
-// The decomposition of one segment with its list of box points in `list` (CoordList / IdList in LDS, IdList in the per-workgroup HBM
-// workspace for the densest clouds).  prebuilt >= 0: the caller's sweep has already put the `prebuilt` points of the box into the
-// list; -1: the list is filled here (a list that did not fit LDS and lives in the workspace).
+// HybridList: an id list whose entries [0, FH_DECOMP_CAP_IDS) are in LDS and the others in the workgroup's HBM workspace.  Every loop over
+// a list walks it in blocks of 64 that start at a multiple of 64, so a block lies on one side (the choice is wave-uniform); the
+// compaction after a separating plane moves entries towards the front, i.e. into LDS.
+struct HybridList : IdList {
+  int* gid;
+  unsigned char* gfl;
+  __device__ __forceinline__ Entry entry(int i) const {
+    int v;
+    if (i < FH_DECOMP_CAP_IDS) v = id[i]; else v = gid[i - FH_DECOMP_CAP_IDS];
+    return v;
+  }
+  __device__ __forceinline__ D3 get(int i) const { return point(entry(i)); }
+  __device__ __forceinline__ unsigned char flag(int i) const {
+    unsigned char v;
+    if (i < FH_DECOMP_CAP_IDS) v = fl[i]; else v = gfl[i - FH_DECOMP_CAP_IDS];
+    return v;
+  }
+  __device__ __forceinline__ void set_flag(int i, unsigned char f) const {
+    if (i < FH_DECOMP_CAP_IDS) fl[i] = f; else gfl[i - FH_DECOMP_CAP_IDS] = f;
+  }
+  __device__ __forceinline__ void store(int pos, const Entry& e, unsigned char f) const {
+    if (pos < FH_DECOMP_CAP_IDS) { id[pos] = e; fl[pos] = f; }
+    else { gid[pos - FH_DECOMP_CAP_IDS] = e; gfl[pos - FH_DECOMP_CAP_IDS] = f; }
+  }
+};
+
+// The decomposition of one segment with its list of box points in `list` (CoordList / IdList in LDS, HybridList with its tail in the
+// per-workgroup HBM workspace for longer lists).  prebuilt: the caller's sweep has put that many points of the box into the
+// list.
 template <class L>
 __device__ void decomp_segment(const L& list, const double* __restrict__ cloud, int n_cloud, D3 p1, D3 p2, const D3* bp,
                                const D3* bn, double inflate, double z_ground, int max_faces, fh_face* __restrict__ out,
@@ -223,43 +251,7 @@ __device__ void decomp_segment(const L& list, const double* __restrict__ cloud, 
   const double f = norm(dvec) / 2;
   const Rot Ri = rot_onto(dvec);
   const D3 c = (p1 + p2) * 0.5;
-  // ---- sweep the points: keep those inside the box, inflated towards the centre in the ellipsoid frame (:178-190)
-  int cnt = prebuilt >= 0 ? prebuilt : 0;
-  auto keep = [&](bool in, D3 q, int ident) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
-    const unsigned long long m = __ballot(in);
-    if (m) {
-      if (in) {
-        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        D3 qi = q;
-        if (L::kNeedsPoint) {
-          const D3 l = mulT(Ri, q - c);
-          qi = mul(Ri, d3(l.x - sgn_i(l.x) * inflate, l.y - sgn_i(l.y) * inflate, l.z - sgn_i(l.z) * inflate)) + c;
-        }
-        list.put(pos, qi, ident);
-      }
-      cnt += __popcll(m);
-    }
-  };
-  for (int base = 0; prebuilt < 0 && base < lrange.total; base += 64) {  // the unknown voxels first (a cloud of unknown + occupied points lists them first)
-    D3 q = d3(0, 0, 0);
-    int packed = 0;
-    const bool in = lattice_point(lat, lrange, base + lane, q, &packed);
-    keep(in, q, (int)(0x80000000u | (unsigned)packed));
-  }
-  const int n_sweep = prebuilt >= 0 ? 0 : (nb >= 0 ? nb : (n_cloud + 63) / 64);  // (the blocks of 64 cloud points that can touch the box, in cloud order)
-  for (int j = 0; j < n_sweep; j++) {
-    const int base = (nb >= 0 ? blist[j] : j) * 64;
-    const int i = base + lane;
-    bool in = false;
-    D3 q = d3(0, 0, 0);
-    if (i < n_cloud) {
-      q = d3(cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]);
-      in = true;
-    }
-    keep(in, q, i);
-  }
+  int cnt = prebuilt;  // (the caller's sweep has listed the points of the box: ids, or inflated coordinates)
   __syncthreads();
 #ifdef FHD_EXPERIMENT
   if (lat.on && fhd_stop_after == 2) {
@@ -384,7 +376,7 @@ __global__ void __launch_bounds__(64) cloud_blocks_kernel(const double* __restri
 // Persistent workgroups of one wavefront; segments are drawn from a counter (`ticket`, zeroed by the caller) — a segment's cost goes
 // with the number of points in its box (a few to 1500 and more with unknown voxels), so a fixed stride leaves the launch waiting
 // for the unluckiest workgroup.  segments: [n][6] = p1, p2.  faces: [n][max_faces] rows
-// (a, b); counts[n] = rows written, -1 on overflow.  workspace: per workgroup 3 * CAP_GLOBAL doubles + CAP_GLOBAL bytes.
+// (a, b); counts[n] = rows written, -1 on overflow.  workspace: per workgroup FH_DECOMP_WS_DOUBLES doubles (the tail of a long list: ids, flags).
 __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict__ cloud, int n_cloud, const double* __restrict__ segments,
                                                     int n_segments, double bx, double by, double bz, double inflate, double z_ground,
                                                     int max_faces, double* __restrict__ workspace, fh_face* __restrict__ faces,
@@ -392,11 +384,12 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
                                                     const double* __restrict__ spheres, int* __restrict__ ticket) {
   // the segment's list of box points: 256 inflated points (3 x 256 doubles + 256 flag bytes) or, in the same bytes, 1536 ids + flag bytes.
   // flags: bit0 first (inside the initial sphere), bit1 inside (current loop), bit2 remain
-  static_assert(FH_DECOMP_CAP_IDS * 4 <= 3 * FH_DECOMP_CAP * 8 && FH_DECOMP_CAP <= FH_DECOMP_CAP_IDS, "the id list aliases the coordinate list");
-  __shared__ double lraw[3 * FH_DECOMP_CAP + FH_DECOMP_CAP_IDS / 8];
+  static_assert(FH_DECOMP_CAP_IDS % 64 == 0 && FH_DECOMP_CAP <= FH_DECOMP_CAP_IDS, "the id list aliases the coordinate list; blocks of 64 do not straddle its end");
+  constexpr int LIST_DOUBLES = (FH_DECOMP_CAP_IDS / 2 > 3 * FH_DECOMP_CAP) ? FH_DECOMP_CAP_IDS / 2 : 3 * FH_DECOMP_CAP;  // ids or coordinates
+  __shared__ double lraw[LIST_DOUBLES + FH_DECOMP_CAP_IDS / 8];
   __shared__ int lblist[FH_DECOMP_BLIST];         // blocks of the cloud that can touch the local box, ascending
   const int lane = threadIdx.x;
-  double* gws = workspace + (size_t)blockIdx.x * (size_t)(3 * FH_DECOMP_CAP_GLOBAL + FH_DECOMP_CAP_GLOBAL / 8);  // (ids + flags of the densest clouds)
+  double* gws = workspace + (size_t)blockIdx.x * (size_t)FH_DECOMP_WS_DOUBLES;  // (ids + flags behind the LDS part of a long list)
   for (;;) {
     __syncthreads();
     int seg = 0;
@@ -464,27 +457,73 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
       __syncthreads();
     }
     // ONE sweep over the candidates: the points of the box are listed as ids (a cloud index, or the packed cell of an unknown voxel)
-    // in LDS, up to FH_DECOMP_CAP_IDS of them, and counted beyond that.  (Round 3 swept twice — count, then store: the count decided
-    // where the list lives.)  A short list is then turned into coordinates in place; a list that does not fit LDS is swept again
-    // into the workspace.
+    // in LDS, up to FH_DECOMP_CAP_IDS of them, behind that in the workspace (up to FH_DECOMP_CAP_GLOBAL in all), and counted beyond that.
+    // (Round 3 swept twice — count, then store: the count decided where the list lives; rounds 4-5 swept a list that did not fit LDS
+    // again into the workspace.)  A short list is then turned into coordinates in place.
     int* lids = reinterpret_cast<int*>(lraw);
-    unsigned char* lflags = reinterpret_cast<unsigned char*>(lraw + 3 * FH_DECOMP_CAP);
+    unsigned char* lflags = reinterpret_cast<unsigned char*>(lraw + LIST_DOUBLES);
+    int* gids = reinterpret_cast<int*>(gws);  // the tail of a list longer than FH_DECOMP_CAP_IDS: ids, and flags behind them
+    unsigned char* gflags = reinterpret_cast<unsigned char*>(gws + FH_DECOMP_CAP_GLOBAL / 2);
     int cnt = 0;
+    // [r6] The six plane tests of the local box (:57-98 with epsilon_) decide as the host's do — but only a candidate within `band` of a
+    // plane needs them: the box is |u| <= by, |w| <= bz, -bx <= d <= L + bx in the frame (dh, dir, dv) at p1, a candidate farther than
+    // `band` outside one of the pairs fails the exact test of that pair, one farther than `band` inside all of them passes all six
+    // (`band` is orders of magnitude above the rounding of either form and above epsilon_).  The sweep of the unknown lattice tests
+    // ~11 000 cells per segment: three dot products instead of six, and the exact tests for the rare trip that has a candidate in the band.
+    const double band = 1e-6 * (1.0 + fabs(p1.x) + fabs(p1.y) + fabs(p1.z) + fabs(p2.x) + fabs(p2.y) + fabs(p2.z) + bx + by + bz);
     auto note = [&](bool in, D3 q, int ident) {
+      {
+        const D3 r = q - p1;
+        const double u = fabs(dot(dh, r)), w = fabs(dot(dv, r)), d = dot(dir, r);
+        const bool sure_out = u > by + band || w > bz + band || d > dn + bx + band || d < -bx - band;
+        const bool sure_in = u < by - band && w < bz - band && d < dn + bx - band && d > -bx + band;
+        in = in && !sure_out;
+        if (__ballot(in && !sure_in)) {  // (a NaN coordinate lands here too and is decided by the exact tests)
 #pragma unroll
-      for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
+          for (int k = 0; k < 6; k++) in = in && !(dot(bn[k], q - bp[k]) > FH_DECOMP_EPS);
+        }
+      }
       const unsigned long long m = __ballot(in);
       if (m) {
         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < FH_DECOMP_CAP_IDS) lids[pos] = ident;
+        if (in) {
+          if (pos < FH_DECOMP_CAP_IDS) lids[pos] = ident;
+          else if (pos < FH_DECOMP_CAP_GLOBAL) gids[pos - FH_DECOMP_CAP_IDS] = ident;
+        }
         cnt += __popcll(m);
       }
     };
-    for (int base = 0; base < lrange.total; base += 64) {
-      D3 q = d3(0, 0, 0);
-      int packed = 0;
-      const bool in = lattice_point(lat, lrange, base + lane, q, &packed);
-      note(in, q, (int)(0x80000000u | (unsigned)packed));
+    if (lat.flags) {
+      // [r6] the caller's unknown voxels: a cell's flag is a byte in memory, and a trip of 64 cells that waits for its own load is a memory
+      // round trip per trip.  Four trips' flags are requested together; the cells are then noted in the same order as before (the list —
+      // and with it every tie rule — is unchanged).  (Measured: 8.9 -> 8.5 ms for the safe corridors of the replan workload.)
+      const int cxy = lrange.cx * lrange.cy;
+      for (int base = 0; base < lrange.total; base += 256) {
+        int packed[4];
+        unsigned char fl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int idx = base + 64 * u + lane;
+          const bool live = idx < lrange.total;
+          const int ic = live ? idx : 0;
+          const int iz = fhu::div(ic, cxy, lrange.inv_cxy), rem = ic - iz * cxy, iy = fhu::div(rem, lrange.cx, lrange.inv_cx), ix = rem - iy * lrange.cx;
+          packed[u] = live ? ((iz << 20) | (iy << 10) | ix) : -1;
+          fl[u] = lat.flags[((size_t)(lrange.z0 + iz) * lat.ny + (lrange.y0 + iy)) * lat.nx + (lrange.x0 + ix)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (base + 64 * u >= lrange.total) break;
+          const bool in = packed[u] >= 0 && fl[u] != 0;
+          note(in, lattice_centre(lat, lrange, packed[u] & 0x3fffffff), (int)(0x80000000u | (unsigned)(packed[u] & 0x3fffffff)));
+        }
+      }
+    } else {
+      for (int base = 0; base < lrange.total; base += 64) {
+        D3 q = d3(0, 0, 0);
+        int packed = 0;
+        const bool in = lattice_point(lat, lrange, base + lane, q, &packed);
+        note(in, q, (int)(0x80000000u | (unsigned)packed));
+      }
     }
     const int n_sweep = nb >= 0 ? nb : (n_cloud + 63) / 64;
     for (int j = 0; j < n_sweep; j++) {
@@ -500,6 +539,11 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
     }
     __syncthreads();
 #ifdef FHD_EXPERIMENT  // (timing experiments only: what a launch with unknown voxels costs up to here; FHD_STOP_AFTER in the environment)
+    if (lane == 0) {
+      atomicAdd(&fhd_hist[cnt <= FH_DECOMP_CAP ? 0 : (cnt <= FH_DECOMP_CAP_IDS ? 1 : (cnt <= FH_DECOMP_CAP_GLOBAL ? 2 : 3))], 1ull);
+      atomicAdd(&fhd_hist[4], (unsigned long long)cnt);
+      atomicAdd(&fhd_hist[5], (unsigned long long)lrange.total);
+    }
     if (lat.on && fhd_stop_after == 1) {
       if (lane == 0) counts[seg] = cnt ? 0 : 0;
       continue;
@@ -531,9 +575,10 @@ __global__ void __launch_bounds__(64, 3) decomp_kernel(const double* __restrict_
     } else if (cnt <= FH_DECOMP_CAP_IDS) {
       decomp_segment(I, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange, cnt);
     } else if (cnt <= FH_DECOMP_CAP_GLOBAL) {
-      I.id = reinterpret_cast<int*>(gws);
-      I.fl = reinterpret_cast<unsigned char*>(gws + FH_DECOMP_CAP_GLOBAL);
-      decomp_segment(I, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange, -1);
+      HybridList H;
+      H.id = lids; H.fl = lflags; H.gid = gids; H.gfl = gflags;
+      H.cloud = cloud; H.lat = &lat; H.lr = &lrange; H.Ri = Ri0; H.c = c0; H.inflate = inflate;
+      decomp_segment(H, cloud, n_cloud, p1, p2, bp, bn, inflate, z_ground, max_faces, out, &counts[seg], lane, lblist, nb, lat, lrange, cnt);
     }
     else if (lane == 0)
       counts[seg] = -1;
