@@ -636,11 +636,13 @@ def compute_leg(torch, dev, pp, whole, faces, solo_res, N, max_faces, solo_step_
                     "refuted at y = 0 without any QP, so executed can be BELOW this figure (useful_over_executed > 1)"}
 
 
-def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batches=6):
+def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batches=24, n_lanes=8):
     """PCIe-inclusive rate: problems and faces start in pinned host memory, both result arrays end there (never `value`).
     `serial`: one batch, one stream: H2D -> fused launch -> D2H of the full fh_result records (round 2's figure).
-    headline: `batches` batches streamed on two lanes (context + stream), PACKED result records (fh_pack_results_device) copied back:
-    the copies of one batch overlap the solve of the next."""
+    headline: `batches` batches streamed on `n_lanes` lanes (context + stream), PACKED result records (fh_pack_results_device) copied back:
+    the copies of one batch overlap the solves and copies of the others.  [r6] Eight lanes: with two (rounds 3-5) at most two launches were
+    in flight and the leg measured the solve of a launch alone, not the link — 9.3 M pairs/s against 13.6 M with eight (12 lanes: 13.7 M;
+    134.6 MB per batch both ways in 2.4 ms = 56 GB/s over PCIe)."""
     import numpy as np
 
     from faster_amd import abi, capi
@@ -674,12 +676,12 @@ def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batch
     serial = float(np.median(ms[1:]))
     serial_bytes = h_whole.numel() + h_faces.numel() + h_safe.numel() + 2 * B * RES
 
-    # ---- streamed: whole batches on two lanes, packed records back ----
+    # ---- streamed: whole batches on n_lanes lanes, packed records back ----
     class Lane:
         pass
 
     lanes = []
-    for k in range(2):
+    for k in range(n_lanes):
         ln = Lane()
         ln.stream = torch.cuda.Stream(device=dev)
         ln.ctx = capi.Context(dev.index or 0)
@@ -715,7 +717,7 @@ def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batch
         torch.cuda.synchronize()
         t = time.perf_counter()
         for k in range(batches):
-            one_batch(lanes[k % 2])
+            one_batch(lanes[k % n_lanes])
         for ln in lanes:
             ln.stream.synchronize()
         ms.append(1e3 * (time.perf_counter() - t) / batches)
@@ -728,12 +730,12 @@ def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batch
     for ln in lanes:
         ln.ctx.close()
     return {"step_ms_median": med, "repetitions": reps, "pairs_per_s": B / (med * 1e-3), "bytes_over_pcie_per_step": int(nbytes),
-            "batches_streamed": batches, "packed_record_bytes": PK, "packed_equals_full_records": bool(same),
+            "batches_streamed": batches, "lanes": n_lanes, "pcie_GBps_both_ways": nbytes / (med * 1e-3) / 1e9, "packed_record_bytes": PK, "packed_equals_full_records": bool(same),
             "serial_full_records": {"step_ms_median": serial, "pairs_per_s": B / (serial * 1e-3), "bytes_over_pcie_per_step": int(serial_bytes)},
-            "note": "pinned host memory; EVERY batch crosses PCIe both ways. headline: %d batches streamed on two lanes (context + stream each): "
+            "note": "pinned host memory; EVERY batch crosses PCIe both ways. headline: %d batches streamed on %d lanes (context + stream each): "
                     "H2D problems+faces+safe templates -> fused pair launch -> pack -> D2H of the packed result records (%d B instead of "
                     "%d), so that the copies of one batch overlap the solve of the next; serial_full_records: one batch at a time on one "
-                    "stream with the full records (round 2's figure)" % (batches, PK, RES)}
+                    "stream with the full records (round 2's figure)" % (batches, n_lanes, PK, RES)}
 
 
 def replan_leg(torch, dev, local_rank, par, pairs=65536, reps=3):
@@ -1007,11 +1009,52 @@ def c5_leg(torch, dev, local_rank, par, r_margin, pairs=65536, reps=3):
     med_half, wres_half, sres_half, live_half = run(0, 0.2, 3)   # C4's synthetic pairing applied to the forest corridors
     med, wres, sres, live = run(1, 0.0, 5)                       # FASTER's own rule for R; safe corridor long enough to reach from R to H
     fctx.close()
+    # [r6] ... and the same launch with several batches IN FLIGHT (what the C4 headline measures for its configuration): a lane = a context,
+    # a stream, its own safe problems and results; every batch is the complete launch over all B pairs; results compared with the launch alone
+    inflight = None
+    try:
+        class CLane:
+            pass
+
+        cl = []
+        for k in range(int(os.environ.get("FH_BENCH_C5_LANES", "4"))):
+            ln = CLane()
+            ln.stream = torch.cuda.Stream(device=dev)
+            ln.ctx = capi.Context(local_rank)
+            ln.ctx.set_stream(ln.stream.cuda_stream)
+            ln.ctx.set_params(par)
+            ln.ctx.set_pair_margin(r_margin)
+            ln.ctx.set_pair_rule(mode=1, r_known=4.0, drone_radius=0.3, delta_h=1.0, delta_a=0.5)
+            ln.d_safe, ln.d_sf, ln.d_wr, ln.d_sr = to_dev(tmpl), torch.zeros_like(d_faces), torch.zeros_like(d_wr), torch.zeros_like(d_wr)
+            cl.append(ln)
+
+        def c5_issue(ln):
+            ln.ctx.solve_pairs_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, 0.5, 0.0, 5, ln.d_wr.data_ptr(), ln.d_safe.data_ptr(), ln.d_sf.data_ptr(),
+                                      ln.d_sr.data_ptr())
+
+        for ln in cl:
+            c5_issue(ln)
+        torch.cuda.synchronize()
+        nb = 3 * len(cl)
+        t = time.perf_counter()
+        for b in range(nb):
+            c5_issue(cl[b % len(cl)])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t
+        w4 = cl[0].d_wr.cpu().numpy().view(abi.result_dtype)
+        s4 = cl[0].d_sr.cpu().numpy().view(abi.result_dtype)
+        same = all(np.array_equal(a[f], b[f]) for a, b in ((w4, wres), (s4, sres)) for f in ("solved", "trials", "factor", "dt", "cost", "coeff", "assign"))
+        inflight = {"lanes": len(cl), "batches": nb, "ms_per_batch": 1e3 * el / nb, "pairs_per_s": nb * B / el, "same_results_as_the_launch_alone": bool(same)}
+        for ln in cl:
+            ln.ctx.close()
+    except Exception as e:  # (the launch alone stands on its own)
+        inflight = {"error": repr(e)[:300]}
     ft = finfo["front_timing"]
     front_s = ft["map_s"] + ft["path_search_s"] + ft["decomposition_s"]
     return {"workload": "C5: %d whole+safe pairs (of %d queries with a path) in a random forest (20x20x3 m, 0.1 trees/m^2), N=15, <=8 polytopes, "
                         "corridors from the device front-end; one fused launch alone on the GPU" % (B, pairs),
             "kernel": "fh::solve_kernel<15, true, 2>", "pairs": B, "step_ms_median": med, "pairs_per_s": B / (med * 1e-3), "repetitions": reps,
+            "batches_in_flight": inflight,
             "front_end": {"map_s": ft["map_s"], "path_search_s": ft["path_search_s"], "decomposition_s": ft["decomposition_s"],
                           "corridors_per_s": pairs / front_s, "expansions": ft["expansions"],
                           "path_search": "jump point search in jps3d's own order (fh_map_set_search 1): FASTER's exact vertex lists; the jump "
