@@ -641,8 +641,10 @@ def e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces, reps=5, batch
     `serial`: one batch, one stream: H2D -> fused launch -> D2H of the full fh_result records (round 2's figure).
     headline: `batches` batches streamed on `n_lanes` lanes (context + stream), PACKED result records (fh_pack_results_device) copied back:
     the copies of one batch overlap the solves and copies of the others.  [r6] Eight lanes: with two (rounds 3-5) at most two launches were
-    in flight and the leg measured the solve of a launch alone, not the link — 9.3 M pairs/s against 13.6 M with eight (12 lanes: 13.7 M;
-    134.6 MB per batch both ways in 2.4 ms = 56 GB/s over PCIe)."""
+    in flight and the leg measured the solve of a launch alone, not the link — in a process with the HIP default of 4 hardware queues 9.3 M
+    pairs/s with two lanes against 13.6 M with eight (scripts/r6/e2e_lanes.py: 134.6 MB per batch both ways in 2.4 ms = 56 GB/s over PCIe).
+    Inside THIS process GPU_MAX_HW_QUEUES is 16 (what the twelve pipelines of the timed region want: 23.3 M pairs/s against 19.3 M with 4), and
+    with 16 queues the leg reads 9.3-9.7 M whatever its lane count."""
     import numpy as np
 
     from faster_amd import abi, capi
