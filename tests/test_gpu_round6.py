@@ -139,7 +139,7 @@ def _pinned_copies(p, n_seg, P, factor):
     return out, combos
 
 
-def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ctx):
+def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ctx, seed_whole=610, seed_pairs=611):
     """Global optimality at N = 10 without trusting the tree search: for 24 whole problems with 3 polytopes (3^10 = 59 049 assignments
     each) and 16 safe problems of fused C4 pairs (<= 3 polytopes), EVERY assignment is solved as a pure QP through fh_problem.pin at the
     factor the branch and bound reported (the GPU does ~2 M QPs here).  The minimum over the feasible ones must be the branch and
@@ -150,9 +150,9 @@ def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ct
     from oracle import py_model
     from test_gpu_round3 import fused_pairs
 
-    whole, faces, _ = corridor.whole_batch(24, seed=610, n_seg=10, p_choices=(3,))
+    whole, faces, _ = corridor.whole_batch(24, seed=seed_whole, n_seg=10, p_choices=(3,))
     wres = ctx.solve_batch(whole, faces)
-    w2, f2, _ = corridor.whole_batch(96, seed=611, n_seg=10, p_choices=(2, 3, 4, 5, 6))
+    w2, f2, _ = corridor.whole_batch(96, seed=seed_pairs, n_seg=10, p_choices=(2, 3, 4, 5, 6))
     w2res, sres, safe, sfaces = fused_pairs(ctx, w2, f2, corridor.safe_templates(w2), 10, 0.05)
     pick = [j for j in np.nonzero((safe["n_seg"] > 0) & (sres["solved"] == 1) & (safe["n_poly"] >= 2))[0]][:16]
     assert len(pick) == 16
@@ -189,6 +189,7 @@ def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ct
         assert s is not None and s[0] == pytest.approx(r["cost"], rel=1e-6, abs=1e-7), (kind, s and s[0], r["cost"])
     print("%d problems, %d pinned QPs on the GPU" % (len(cases), total_qps))
     assert total_qps > 1_500_000
+    return len(cases), total_qps
 
 
 def test_lazy_pair_outputs_and_compact_results_give_the_same_bits():
