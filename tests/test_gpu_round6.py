@@ -126,6 +126,9 @@ def test_highs_confirms_flag_and_first_feasible_factor_at_n15(ctx):
     assert res["solved"][:64].mean() > 0.8
 
 
+_last_enumeration = (0, 0)
+
+
 def _pinned_copies(p, n_seg, P, factor):
     """Every one of the P^N assignments of one problem as pinned copies solved at ONE factor (a pure QP each: BASELINE config 1's mechanism)."""
     combos = np.array(list(itertools.product(range(P), repeat=n_seg)), dtype=np.uint64)  # [P^N, N]
@@ -189,7 +192,8 @@ def test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ct
         assert s is not None and s[0] == pytest.approx(r["cost"], rel=1e-6, abs=1e-7), (kind, s and s[0], r["cost"])
     print("%d problems, %d pinned QPs on the GPU" % (len(cases), total_qps))
     assert total_qps > 1_500_000
-    return len(cases), total_qps
+    global _last_enumeration
+    _last_enumeration = (len(cases), total_qps)  # (read by tests/tools/enumeration_sweep.py)
 
 
 def test_lazy_pair_outputs_and_compact_results_give_the_same_bits():

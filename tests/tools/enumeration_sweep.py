@@ -18,7 +18,8 @@ def main():
     t0 = time.time()
     problems = qps = 0
     for k in range(seeds):
-        n, q = T.test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ctx, seed_whole=7000 + 2 * k, seed_pairs=7001 + 2 * k)
+        T.test_branch_and_bound_optimum_is_the_minimum_over_every_assignment_at_n10(ctx, seed_whole=7000 + 2 * k, seed_pairs=7001 + 2 * k)
+        n, q = T._last_enumeration
         problems += n
         qps += q
         print("seeds %d / %d: %d problems, %d pinned QPs so far, every minimum = the branch and bound's cost | %d s" % (7000 + 2 * k, 7001 + 2 * k, problems, qps, time.time() - t0), flush=True)
