@@ -71,12 +71,12 @@ assert params_dtype.itemsize == 48
 
 sched_dtype = np.dtype([("launch_order", "<i4"), ("publish_factor", "<i4"), ("backlog", "<i4"), ("waiting_workgroups", "<i4"),
                         ("min_nodes", "<i4"), ("cloud_blocks", "<i4"), ("workgroups_per_cu", "<i4"), ("no_child_bound", "<i4"), ("compact_results", "<i4"), ("pair_outputs", "<i4"),
-                        ("struct_size", "<i4")])
-assert sched_dtype.itemsize == 44
-FH_ABI_VERSION = 7   # include/fasterhip.h: the layout generation of its structs (checked against fh_abi_version() when the library is loaded)
+                        ("look_every", "<i4"), ("struct_size", "<i4")])
+assert sched_dtype.itemsize == 48
+FH_ABI_VERSION = 8   # include/fasterhip.h: the layout generation of its structs (checked against fh_abi_version() when the library is loaded)
 
 launch_info_dtype = np.dtype([("n_seg", "<i4"), ("pairs", "<i4"), ("waves_per_simd", "<i4"), ("grid", "<i4"), ("workgroups_per_cu", "<i4"),
-                              ("lds_bytes", "<i4"), ("unknown_space", "<i4"), ("reserved", "<i4")])
+                              ("lds_bytes", "<i4"), ("unknown_space", "<i4"), ("look_every", "<i4")])
 
 
 voxel_grid_dtype = np.dtype([("origin", "<f8", (3,)), ("res", "<f8"), ("dims", "<i4", (3,)), ("reserved", "<i4")])

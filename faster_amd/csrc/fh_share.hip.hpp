@@ -147,7 +147,7 @@ struct ShareArgs {
   // the fused pair kernel: the safe problem of a pair lives in the LDS of the wavefront that solves it; its record and rows are written to
   // memory at the hand-off (pair_outputs: fh_sched.pair_outputs) or when the problem is first shared with another workgroup (otherwise)
   int pair_outputs;
-  int pad0;
+  int look_mask;              // a tree looks around when (its node count & look_mask) == 0 (fh_sched.look_every - 1; a shared problem uses look_mask >> 1)
   unsigned int* claims;       // [FH_MAX_GRID] claims[w] != 0: the chunk of tickets dealt to workgroup w has been taken — by w itself when it
                               // started, or by a workgroup that ran out of tickets before w had started (null: nothing is dealt)
   const fh_problem* whole;    // [n] the whole problems of the launch

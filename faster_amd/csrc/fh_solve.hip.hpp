@@ -38,9 +38,14 @@
 
 namespace fh {
 
-// every FH_LOOK_EVERY-th node of a tree the worker reads the control block (stop request, hungry workers): power of two
+// every FH_LOOK_EVERY-th node of a tree the worker reads the control block (stop request, hungry workers): power of two.  The default of a
+// launch that has the device to itself; the period of a launch is fh_sched.look_every (ShareArgs.look_mask), which the library sets to
+// FH_LOOK_EVERY_BUSY when other solve launches of the process are in flight on the device (fh_capi.hip: launch_solve)
 #ifndef FH_LOOK_EVERY
 #define FH_LOOK_EVERY 8
+#endif
+#ifndef FH_LOOK_EVERY_BUSY
+#define FH_LOOK_EVERY_BUSY 16
 #endif
 
 // A workgroup is ONE wavefront (launch bounds 64): its LDS operations are issued and performed in program order, so what a
@@ -2583,7 +2588,7 @@ struct Solver {
       local_nodes++;
       // a problem that is already shared looks around twice as often; a taker looks before its first node (it hands the other
       // children of its frame, or the following trials, on at once if more takers are waiting)
-      if ((local_nodes & ((rec >= 0 ? FH_LOOK_EVERY / 2 : FH_LOOK_EVERY) - 1)) == 0 || (rec >= 0 && local_nodes == 1 && (entry == 1 || trial + 1 < trial_end))) {
+      if ((local_nodes & (rec >= 0 ? (sa.look_mask >> 1) : sa.look_mask)) == 0 || (rec >= 0 && local_nodes == 1 && (entry == 1 || trial + 1 < trial_end))) {
         FH_T0();
         int fl = look_around(sa, local_nodes, iters);
         if (fl & 1) { status_limit = FH_ST_INTERRUPTED; break; }

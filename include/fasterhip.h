@@ -205,6 +205,13 @@ typedef struct fh_sched {
                                  after the launch is unspecified, the TEMPLATE fields of d_safe (n_seg, bounds, dc, factor window,
                                  force_final_pos, xf) are never written, and the results are the same bit for bit.  The safe problem's x0
                                  is the whole trajectory at sample k_safe (fh_sample_batch / fh_append_plans_device give it).              */
+  int32_t look_every;         /* a branch-and-bound tree reads the launch's control words — stop request, deadline, is somebody out of work, do I hold
+                                 tickets somebody else could start — every look_every-th node (a power of two, 2..1024; a shared problem twice as
+                                 often).  0 (default): the library decides per launch — 8 for a launch that has the device to itself (what ends
+                                 such a launch is its tail: its long trees must find help early), 16 when another context of this process has a
+                                 solve launch in flight on the same device when this one is issued (the tail of a launch is then hidden behind
+                                 the others, and every frame that changes hands is overhead: C4, twelve launches in flight, +2.5 %; one launch
+                                 alone with 16: 2-5 % later).  fh_last_launch reports the value a launch ran with.                          */
   int32_t struct_size;        /* sizeof(fh_sched) as the CALLER was compiled (fh_default_sched sets it), or 0 = not stated.  fh_set_sched
                                  refuses any other value: the struct has changed between rounds (round 4's child_bound became
                                  no_child_bound with the opposite meaning at the same offset), and a binary built against an older
@@ -212,7 +219,7 @@ typedef struct fh_sched {
 } fh_sched;
 /* The layout generation of the structs in this header: bumped whenever a field changes its meaning, offset or size.  A caller compares
  * FH_ABI_VERSION (its compile time) with fh_abi_version() (the loaded library) once; SolverHip does. */
-#define FH_ABI_VERSION 7
+#define FH_ABI_VERSION 8
 int fh_abi_version(void);
 void fh_default_sched(fh_sched* s);
 int fh_set_sched(fh_ctx* ctx, const fh_sched* s);
@@ -562,7 +569,7 @@ double fh_last_kernel_ms(fh_ctx* ctx);
  * the caller's unknown voxels (fh_pair_rule mode 2) — with its grid, the resident solves per CU and the LDS bytes per workgroup.  Measurement only (bench.py matches its rocprofv3 summaries by this name);
  * returns FH_ERR_ARG before the first launch. */
 typedef struct fh_launch_info {
-  int32_t n_seg, pairs, waves_per_simd, grid, workgroups_per_cu, lds_bytes, unknown_space, reserved;
+  int32_t n_seg, pairs, waves_per_simd, grid, workgroups_per_cu, lds_bytes, unknown_space, look_every;
 } fh_launch_info;
 int fh_last_launch(const fh_ctx* ctx, fh_launch_info* out);
 

@@ -350,9 +350,10 @@ def test_results_do_not_depend_on_launch_order_or_publishing_ahead(ctx):
     # (fh_set_sched: explicit fields, no environment.  min_nodes 64: almost nothing is given to idle workgroups; child_bound 0: every
     # child of a node is visited — the tree of the CPU oracle, about twice the nodes; workgroups_per_cu 5: also ANOTHER BUILD of the
     # kernel — compiled for two wavefronts per SIMD, nothing spilled — selected by any value up to 8)
-    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0, "workgroups_per_cu": 5, "min_nodes": 64, "child_bound": 0}
+    variants = {"launch_order": 0, "publish_factor": 0, "backlog": 0, "workgroups_per_cu": 5, "min_nodes": 64, "child_bound": 0, "look_every": 2,
+                "look_every ": 64}
     for k, v in variants.items():
-        ctx.set_sched(**{k: v})
+        ctx.set_sched(**{k.strip(): v})
         try:
             got = run(ctx)
         finally:

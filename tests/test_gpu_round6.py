@@ -326,3 +326,40 @@ def test_pairs_with_unusable_whole_problems_first_in_line():
         assert np.array_equal(w["coeff"][:, :N], wref["coeff"][:, :N]) and np.array_equal(sr["coeff"][:, :N], sref["coeff"][:, :N])
         assert c.share_stats()["error"] == 0
         c.close()
+
+
+def test_a_launch_looks_around_less_often_while_other_launches_are_in_flight():
+    """fh_sched.look_every = 0 (default): a solve launch that is issued while ANOTHER context of the process has a solve launch in flight on the
+    device reads its control words every 16th node of a tree, a launch that has the device to itself every 8th (fh_last_launch reports
+    the period; a fixed value is taken as it is, an invalid one refused).  The results are the same bit for bit."""
+    import torch
+
+    B, N = 16384, 10
+    whole, faces, _ = corridor.whole_batch(B, seed=91, n_seg=N, p_choices=(2, 3, 4, 5, 6))
+    mf = int(whole["face_off"][np.arange(B), whole["n_poly"]].max())
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    d_whole, d_faces = to_dev(whole), to_dev(faces)
+    a, b = capi.Context(0), capi.Context(0)
+    try:
+        outs = [torch.zeros(B * abi.result_dtype.itemsize, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        a.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, outs[0].data_ptr())
+        a.sync()
+        assert a.last_launch()[0]["look_every"] == 8
+        alone = outs[0].cpu().numpy().view(abi.result_dtype).copy()
+        # two launches back to back on two contexts (two streams): the second one is issued while the first is running
+        a.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, outs[1].data_ptr())
+        b.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, outs[2].data_ptr())
+        a.sync(); b.sync()
+        assert a.last_launch()[0]["look_every"] == 8 and b.last_launch()[0]["look_every"] == 16
+        for o in outs[1:]:
+            got = o.cpu().numpy().view(abi.result_dtype)
+            for f in ("solved", "trials", "status", "factor", "dt", "cost", "coeff", "assign"):
+                assert np.array_equal(got[f], alone[f]), f
+        b.set_sched(look_every=32)
+        b.solve_batch_device(d_whole.data_ptr(), d_faces.data_ptr(), B, N, mf, outs[2].data_ptr())
+        b.sync()
+        assert b.last_launch()[0]["look_every"] == 32
+        with pytest.raises(Exception):
+            b.set_sched(look_every=12)
+    finally:
+        a.close(); b.close()
