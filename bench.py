@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--pipeline", choices=["fused", "split"], default="fused",
                     help="fused: one launch per step, each unit of work is a pair taken through whole solve, hand-off and safe solve; "
                          "split: whole launch -> hand-off launch -> safe launch (same results)")
-    ap.add_argument("--inflight", type=int, default=12,
+    ap.add_argument("--inflight", type=int, default=14,
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     ap.add_argument("--no-share", action="store_true", help="one wavefront per problem (fh_params.share = 0)")
     ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
