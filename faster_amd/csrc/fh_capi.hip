@@ -201,8 +201,9 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   // tail is hidden behind the other launches anyway); one launch ALONE ends 2-5 % later with 16 and 10 % later with 32-64 (2.64-2.71 ->
   // 2.71-2.81 -> 2.91-2.98 ms: its long trees find help later).  So a launch that is issued while another context has a solve launch in
   // flight on this device looks every 16th node, a launch that has the device to itself every 8th.
+  const bool busy = other_launches_in_flight(ctx) > 0;  // another context of the process has a solve launch in flight on this device right now
   {
-    const int period = ctx->sched.look_every > 0 ? ctx->sched.look_every : (other_launches_in_flight(ctx) > 0 ? FH_LOOK_EVERY_BUSY : FH_LOOK_EVERY);
+    const int period = ctx->sched.look_every > 0 ? ctx->sched.look_every : (busy ? FH_LOOK_EVERY_BUSY : FH_LOOK_EVERY);
     sa.look_mask = period - 1;
     ctx->last_launch.look_every = period;
   }
@@ -241,9 +242,12 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
     FH_HIP(hipGetLastError());
   }
   ctx->ctl_ready = false;  // (true again once the launch below has been issued: it resets the block when it ends)
-  // big batches are started hardest corridors first (order_kernel); results do not depend on the order
+  // big batches are started hardest corridors first (order_kernel); results do not depend on the order.  [r6] ... when the launch has the
+  // device to itself (fh_sched.launch_order = 1, the default; 2: always): the order keeps a launch from ENDING on a long tree, and with
+  // other launches in flight that end is hidden behind them, while the two small launches that sort the batch queue behind the resident
+  // grids (C4, fourteen in flight: 24.0 -> 24.25 M pairs/s without them)
   ka.order = nullptr;
-  if (n >= 2048 && ctx->sched.launch_order) {
+  if (n >= 2048 && (ctx->sched.launch_order >= 2 || (ctx->sched.launch_order == 1 && !busy))) {
     const bool fresh = ctx->d_cap[13] < sizeof(int) * ((size_t)n + 128) || !ctx->order_ready;
     ctx->order_ready = false;  // (true again once all three launches below have been issued: a failed launch must not leave dirty counters behind)
     if ((rc = ensure(ctx, 13, sizeof(int) * ((size_t)n + 128))) != FH_OK) return rc;
@@ -390,6 +394,7 @@ int fh_set_sched(fh_ctx* ctx, const fh_sched* s) {
     return FH_ERR_ARG;
   }
   if (s->publish_factor < 0 || s->backlog < 0 || s->backlog > 512 || s->waiting_workgroups < 0 || s->min_nodes < 0 || s->workgroups_per_cu < 0) return FH_ERR_ARG;
+  if (s->launch_order < 0 || s->launch_order > 2) return FH_ERR_ARG;
   if (s->look_every != 0 && (s->look_every < 2 || s->look_every > 1024 || (s->look_every & (s->look_every - 1)) != 0)) return FH_ERR_ARG;
   ctx->sched = *s;
   return FH_OK;

@@ -171,7 +171,9 @@ int fh_control_points(const fh_result* results, int n, int n_seg, double* cp);
  * ANY OF THESE (tests/test_gpu_round2.py solves 8192 pairs with each of them switched off and compares bit for bit); only
  * nodes / qp_iters / kflops, which count the work actually done, and the time a launch takes.  Defaults: fh_default_sched(). */
 typedef struct fh_sched {
-  int32_t launch_order;       /* 1 (default): batches of >= 2048 units start with the corridors that have most polytopes       */
+  int32_t launch_order;       /* 1 (default): batches of >= 2048 units start with the corridors that have most polytopes — unless another context
+                                 of this process has a solve launch in flight on the device (what the order is for, the END of a launch, is
+                                 hidden then, and the two small sorting launches queue behind the resident grids); 2: always; 0: never   */
   int32_t publish_factor;     /* a problem that has used this many times the running mean of active-set iterations may publish
                                  frames ahead of the idle workgroups (default 4; 0: never)                                      */
   int32_t backlog;            /* frames that may be published ahead of the takers (default 32; 0: none)                        */
