@@ -58,12 +58,19 @@ struct fh_ctx {
 
 // Every live context of the process (fh_create / fh_destroy): a solve launch asks the others whether they have a launch in flight on its
 // device (fh_sched.look_every = 0).  The events of a context live until fh_destroy, which leaves the registry first, under the same lock.
-static std::mutex g_live_mu;
-static std::vector<fh_ctx*> g_live;
+// (Never destroyed: a caller's static SolverHip may outlive the statics of this library at process exit.)
+static std::mutex& live_mu() {
+  static std::mutex* m = new std::mutex;
+  return *m;
+}
+static std::vector<fh_ctx*>& live_list() {
+  static std::vector<fh_ctx*>* v = new std::vector<fh_ctx*>;
+  return *v;
+}
 static int other_launches_in_flight(const fh_ctx* me) {
   int others = 0;
-  std::lock_guard<std::mutex> lock(g_live_mu);
-  for (const fh_ctx* c : g_live) {
+  std::lock_guard<std::mutex> lock(live_mu());
+  for (const fh_ctx* c : live_list()) {
     if (c == me || c->device != me->device) continue;
     const hipEvent_t e = c->last_end.load(std::memory_order_acquire);
     if (e && hipEventQuery(e) == hipErrorNotReady) others++;
@@ -440,8 +447,8 @@ int fh_create(fh_ctx** out, int device) {
   *out = ctx;
   FH_HIP(hipGetDevice(&ctx->device));
   {
-    std::lock_guard<std::mutex> lock(g_live_mu);
-    g_live.push_back(ctx);
+    std::lock_guard<std::mutex> lock(live_mu());
+    live_list().push_back(ctx);
   }
   hipDeviceProp_t prop;
   FH_HIP(hipGetDeviceProperties(&prop, ctx->device));
@@ -465,8 +472,8 @@ int fh_create(fh_ctx** out, int device) {
 void fh_destroy(fh_ctx* ctx) {
   if (!ctx) return;
   {
-    std::lock_guard<std::mutex> lock(g_live_mu);
-    g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
+    std::lock_guard<std::mutex> lock(live_mu());
+    live_list().erase(std::remove(live_list().begin(), live_list().end(), ctx), live_list().end());
   }
   if (ctx->device >= 0) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
