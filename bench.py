@@ -228,6 +228,9 @@ def main():
                     help="independent pipelines (context + HIP stream + output buffers); step i runs on pipeline i %% inflight")
     ap.add_argument("--no-share", action="store_true", help="one wavefront per problem (fh_params.share = 0)")
     ap.add_argument("--wg-per-cu", type=int, default=0, help="resident solves per CU (fh_sched.workgroups_per_cu; 0: the library's default)")
+    ap.add_argument("--e2e-child", action="store_true",
+                    help="internal: only the PCIe-inclusive leg, in a process of its own with the HIP runtime's default number of hardware queues "
+                         "(the parent's timed region wants 16 of them, this leg 4: DESIGN.md 6); prints that leg's record")
     ap.add_argument("--sched", default="", help="fh_sched fields of the timed pipelines, e.g. look_every=32,min_nodes=8 (experiments; no result depends on them)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N>1 run: nccl (= RCCL over xGMI, default); gloo only with --dry-run")
@@ -256,7 +259,8 @@ def main():
         raise SystemExit("bench.py: --backend gloo is for --dry-run only (the hot path has no CPU fallback)")
 
     # more hardware queues than the HIP default (4) so that the in-flight pipelines really run concurrently
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    if not args.e2e_child:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     launch_own_ranks(args)  # (--gpus N > 1 outside torch.distributed.run: does not return)
     import torch
 
@@ -362,6 +366,13 @@ def main():
                 pp.gather = [[torch.zeros(per_rank * GB, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(2)]
         return pp
 
+    if args.e2e_child:
+        pp = make_pipe(args.r_margin)
+        rec = e2e_leg(torch, dev, pp, whole, faces, safe_t, B, N, max_faces)
+        rec["hardware_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP default (4)")
+        print(json.dumps(rec))
+        pp.ctx.close()
+        return
     pipes = [make_pipe(args.r_margin) for _ in range(max(1, args.inflight))]
     torch.cuda.synchronize()
     step_no = [0]
@@ -549,6 +560,21 @@ def main():
             out["roofline"]["compute"] = compute_leg(torch, dev, pipes[0], whole, faces, solo_res, N, max_faces,
                                                      out["roofline"]["solo"]["step_ms_median"], elapsed / args.steps, to_dev)
             out["e2e_with_copies"] = e2e_leg(torch, dev, pipes[0], whole, faces, safe_t, B, N, max_faces)
+            out["e2e_with_copies"]["hardware_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
+            if args.workload == "c4":
+                # [r6] the same leg in a process of its own with the runtime's default number of hardware queues: what a caller that streams host
+                # buffers (and does not keep fourteen launches in flight) gets — the queue count is read once per process
+                try:
+                    import subprocess
+
+                    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-child", "--pairs", str(args.pairs)], env=env,
+                                        capture_output=True, text=True, timeout=240)
+                    child = json.loads(cp.stdout.strip().splitlines()[-1])
+                    out["e2e_with_copies"]["process_with_default_hardware_queues"] = {k: child[k] for k in (
+                        "step_ms_median", "pairs_per_s", "pcie_GBps_both_ways", "lanes", "batches_streamed", "hardware_queues", "packed_equals_full_records")}
+                except Exception as e:
+                    out["e2e_with_copies"]["process_with_default_hardware_queues"] = {"error": repr(e)[:200]}
             if args.workload == "c4":
                 lit_frac, lit_rate = literal_leg(torch, make_pipe, run_step, fused, abi, B, inflight=len(pipes))
                 out["config"]["safe_solved_frac_literal_8d"] = lit_frac
