@@ -166,7 +166,7 @@ static int launch_solve(fh_ctx* ctx, const fh_problem* d_problems, const fh_face
   const int grid = share ? std::min(resident, std::max(n, ctx->n_cu)) : std::min(resident, n);
   ctx->last_launch.grid = grid;
   int rc;
-  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * NSEG * SV::SNAP_PADDED)) != FH_OK) return rc;
+  if ((rc = ensure(ctx, 5, sizeof(double) * (size_t)grid * ((size_t)NSEG * SV::SNAP_PADDED + 64))) != FH_OK) return rc;
   const size_t slot_stride = sizeof(fh::TaskHdr) + sizeof(double) * (size_t)SV::SNAP_PADDED;
   if (!ctx->d_buf[6]) ctx->ctl_ready = false;
   if ((rc = ensure(ctx, 6, 4096 + sizeof(unsigned long long) * FH_QCAP + sizeof(unsigned int) * FH_MAX_GRID)) != FH_OK) return rc;

@@ -594,7 +594,7 @@ struct Solver {
   }
   double wbj, wbv, wba, wcp;  // inverse row norms IN THE REDUCED SPACE of this lane's box rows (lane = (t, i)) and corridor rows
                           //   (lane = (t, k)); 0: the row does not depend on y (per trial)
-  double bestx_r;         // lane < n: incumbent y
+  double* bestx_g;        // [NVP] incumbent y (lane < n) in the workgroup's workspace: written when a better leaf is found, read when the problem ends or is first shared
   double cp_r[3];         // lane = (t, k): control point k of segment t at the current x (compute_states -> scan)
   int scan_f0, scan_F;    // lane = (t, k): first row and row count of the polytope segment t is assigned to (0 rows: free) (per node)
   // ---- wave-uniform scalars ----
@@ -1814,7 +1814,7 @@ struct Solver {
       ShareRec* R_ = sa.recs + r;
       unsigned long long alo, ahi;
       pack_bytes(lane < NSEG ? bestassign[lane] : -1, N, alo, ahi);
-      if (lane < n) wt_store(&R_->x[lane], bestx_r);
+      if (lane < n) wt_store(&R_->x[lane], bestx_g[lane]);
       if (lane == 0) {
         ast(&R_->lock, 0u);
         ast(&R_->pending, 2);  // this worker's part + the frame about to be published
@@ -2186,7 +2186,7 @@ struct Solver {
     }
     take = uniform_i32(take);
     if (take == 1) {
-      if (lane < n) wt_store(&R_->x[lane], bestx_r);
+      if (lane < n) wt_store(&R_->x[lane], bestx_g[lane]);
       if (lane == 0) {
         ast(&R_->assign_lo, alo); ast(&R_->assign_hi, ahi);
         ast(&R_->inc_key, best_key); ast(&R_->inc_cost, f64_bits(cost));
@@ -2261,7 +2261,7 @@ struct Solver {
   // iteration of the kernel loop and, as far as it knows, read by the next), carried 24 registers across the ticket, the staging and
   // the hand-off, and spilled them there (measured: 29 -> 13 spilled registers in the plain N = 10 kernel).
   __device__ __forceinline__ void forget_lane_state() {
-    p0r = v0r = a0r = xpr = xj = bestx_r = 0.0;
+    p0r = v0r = a0r = xpr = xj = 0.0;
     cp_r[0] = cp_r[1] = cp_r[2] = 0.0;
     wbj = wbv = wba = wcp = 0.0;
     scan_f0 = scan_F = 0;
@@ -2654,7 +2654,7 @@ struct Solver {
           if (cost < best_cost || (cost == best_cost && cur_key < best_key)) {
             best_cost = cost;
             best_key = cur_key;
-            if (lane < n) bestx_r = x[lane];
+            if (lane < n) bestx_g[lane] = x[lane];
             if (lane < N) bestassign[lane] = fullassign[lane];
             if (lane == 0) tb[TB_FRESH] = 1;  // Pc / Vc / Ac and the jerks xj are this leaf's until the next node is solved
             FH_SYNC();
@@ -3062,7 +3062,7 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
       factor = uniform_f64(sv.bits_f64(ald(reinterpret_cast<const unsigned long long*>(&R_->inc_f))));
       dt = uniform_f64(sv.bits_f64(ald(reinterpret_cast<const unsigned long long*>(&R_->inc_h))));
       const unsigned long long alo = sv.uniform_u64(ald(&R_->assign_lo)), ahi = sv.uniform_u64(ald(&R_->assign_hi));
-      if (lane < sv.n) sv.bestx_r = cc_load(&R_->x[lane]);
+      if (lane < sv.n) sv.bestx_g[lane] = cc_load(&R_->x[lane]);
       if (lane < NSEG) sv.bestassign[lane] = sv.unpack_byte(alo, ahi, lane);
       sv.h = dt;
       (void)sv.setup_trial(pr, bt);  // the y = 0 states of the winning step (this worker may have been exploring another trial)
@@ -3096,7 +3096,8 @@ __device__ __forceinline__ bool run_problem(SV& sv, const PR& pr, const fh_face*
     const bool fresh = false;
 #endif
     if (!fresh) {
-      if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_r : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the incumbent was stored by this wavefront: its stores are drained before they are read back)
+      if (lane < sv.NVP) sv.x[lane] = (lane < sv.n) ? sv.bestx_g[lane] : 0.0;
       FH_SYNC();
       sv.compute_states();
     }
@@ -3194,7 +3195,8 @@ __global__ void __launch_bounds__(64, WPS) solve_kernel(const fh_problem* __rest
   sv.qe = 0;
   if (threadIdx.x == 0) { sv.tb[sv.TB_ZN] = 0; sv.tb_put64(sv.TB_NEXT, 0ull); sv.tb_put64(sv.TB_POOL2, 0ull); sv.tb_put64(sv.TB_NEXT_EI, 0ull); sv.tb_put64(sv.TB_NEXT_WT, 0ull); sv.tb[sv.TB_DONE_N] = 0; sv.tb[sv.TB_DONE_IT] = 0; }
   const ShareArgs& sa = ka.sa;
-  double* ws = ka.workspace + (size_t)blockIdx.x * (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
+  double* ws = ka.workspace + (size_t)blockIdx.x * ((size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED + 64);
+  sv.bestx_g = ws + (size_t)NSEG * (size_t)Solver<NSEG>::SNAP_PADDED;
   if (threadIdx.x == 0) {
     sv.tb_put64(sv.TB_T0, wall_ticks());
     aadd(&sa.ctl->started, 1u);
